@@ -1,0 +1,174 @@
+/* ptrace.h — C-ABI of the MI355X ray-trace/shade hot path (libptrace.so).
+ *
+ * The reference (ziotom78/pytracer) has no FFI: its seam is the Python call
+ *     ImageTracer.fire_all_rays(renderer)            src/pytracer/imagetracer.py:60-110
+ * with `renderer` one of the solvers of                src/pytracer/render.py:42-193.
+ * This header is what a ctypes binding for that seam binds (INTEGRATION.md shows the
+ * reference-side stub).  Every entry point is `extern "C"`, takes plain pointers and sizes,
+ * returns 0 or a negative error code, and never throws.
+ *
+ * Numerics contract: all scene/camera/param values are IEEE fp64 exactly as the reference
+ * holds them (Python float); the PCG is the reference's PCG-XSH-RR 64/32 (src/pytracer/pcg.py:23-62).
+ * The library is NOT thread-safe per handle: one call at a time per pt_scene.
+ */
+#ifndef PTRACE_H
+#define PTRACE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- enumerations ------------------------------------------------------------------------ */
+#define PT_SHAPE_SPHERE 0 /* shapes.py:86  unit sphere, transformed */
+#define PT_SHAPE_PLANE 1  /* shapes.py:154 xy plane, transformed  */
+
+#define PT_BRDF_DIFFUSE 0  /* materials.py:123 */
+#define PT_BRDF_SPECULAR 1 /* materials.py:155 */
+
+#define PT_PIGMENT_UNIFORM 0   /* materials.py:50 */
+#define PT_PIGMENT_CHECKERED 1 /* materials.py:85 */
+#define PT_PIGMENT_IMAGE 2     /* materials.py:62 */
+
+#define PT_CAMERA_ORTHOGONAL 0  /* camera.py:42 */
+#define PT_CAMERA_PERSPECTIVE 1 /* camera.py:81 */
+
+#define PT_RENDERER_ONOFF 0      /* render.py:42  */
+#define PT_RENDERER_FLAT 1       /* render.py:56  */
+#define PT_RENDERER_PATHTRACER 2 /* render.py:77  */
+#define PT_RENDERER_POINTLIGHT 3 /* render.py:142 */
+
+/* PCG stream assignment ("seed alignment").
+ * SEQ    : the reference's two global sequential streams (jitter + scattering), row-major
+ *          pixel order.  Inherently serial: accepted by the CPU oracle only.
+ * PIXEL  : pixel i = row*W+col owns PCG(path_state, path_seq + i) for jitter and scattering,
+ *          consumed in program order.  Depends only on the global pixel index.
+ * SAMPLE : sample k = sub_row*S+sub_col of pixel i owns PCG(path_state, path_seq + i*S*S + k).
+ */
+#define PT_PCG_SEQ 0
+#define PT_PCG_PIXEL 1
+#define PT_PCG_SAMPLE 2
+
+#define PT_OUT_F64 0 /* W*H*3 doubles: the reference's in-memory HdrImage (hdrimages.py:59-94) */
+#define PT_OUT_F32 1 /* W*H*3 floats : the reference's on-disk PFM precision (hdrimages.py:35-43) */
+
+#define PT_OK 0
+#define PT_ERR_INVALID (-1)     /* bad argument / inconsistent descriptor */
+#define PT_ERR_HIP (-2)         /* a HIP runtime call failed (see pt_last_error) */
+#define PT_ERR_UNSUPPORTED (-3) /* feature not available on the device path */
+#define PT_ERR_NOMEM (-4)
+#define PT_ERR_SIZE (-5)        /* output buffer too small */
+#define PT_ERR_NODEVICE (-6)
+
+/* ---- scene (flattened, structure-of-arrays, fp64) ------------------------------------------
+ * Replaces: World.shapes (world.py:38-45) with each Shape's transformation.m / .invm
+ * (transformations.py:48-56), Material.brdf / .emitted_radiance (materials.py:199-204).
+ * 3x4 affine matrices are stored element-major: element (r,c) of shape i at a[(r*4+c)*n + i].
+ * Colours are channel-major: channel k of shape i at a[k*n + i].
+ */
+typedef struct pt_scene_desc {
+  int32_t n_shapes;
+  const int32_t *kind;      /* [n] PT_SHAPE_*                                   */
+  const double *invm;       /* [12][n] rows 0..2 of transformation.invm         */
+  const double *m;          /* [12][n] rows 0..2 of transformation.m            */
+  const int32_t *brdf_kind; /* [n] PT_BRDF_*                                    */
+  const double *brdf_param; /* [n] SpecularBRDF.threshold_angle_rad (materials.py:158-162), else 0 */
+  /* material.brdf.pigment */
+  const int32_t *pig_kind;  /* [n] PT_PIGMENT_*                                 */
+  const double *pig_c1;     /* [3][n] uniform colour / checkered color1         */
+  const double *pig_c2;     /* [3][n] checkered color2                          */
+  const double *pig_steps;  /* [n] checkered num_of_steps                       */
+  const int32_t *pig_tex;   /* [n] texture index for PT_PIGMENT_IMAGE, else -1  */
+  /* material.emitted_radiance */
+  const int32_t *emi_kind;
+  const double *emi_c1;
+  const double *emi_c2;
+  const double *emi_steps;
+  const int32_t *emi_tex;
+  /* World.point_lights (world.py:47-49, lights.py:25-39) */
+  int32_t n_lights;
+  const double *light_pos;    /* [3][n_lights] */
+  const double *light_color;  /* [3][n_lights] */
+  const double *light_radius; /* [n_lights] linear_radius */
+  /* ImagePigment textures (materials.py:62-82): row-major RGB fp64, row 0 first */
+  int32_t n_textures;
+  const int32_t *tex_w;      /* [n_textures] */
+  const int32_t *tex_h;      /* [n_textures] */
+  const int64_t *tex_offset; /* [n_textures] offset (in doubles) into tex_data */
+  const double *tex_data;
+} pt_scene_desc;
+
+/* Replaces: OrthogonalCamera / PerspectiveCamera fields (camera.py:48-57, 87-101). */
+typedef struct pt_camera {
+  int32_t kind; /* PT_CAMERA_* */
+  int32_t _pad;
+  double m[12]; /* rows 0..2 of camera.transformation.m, row-major */
+  double screen_distance;
+  double aspect_ratio;
+} pt_camera;
+
+/* Replaces: the arguments main.py:164-198 passes to ImageTracer(...) and the Renderer ctor. */
+typedef struct pt_params {
+  int32_t width, height;    /* HdrImage size (hdrimages.py:59-70)                        */
+  int32_t samples_per_side; /* ImageTracer.samples_per_side (imagetracer.py:45); 0 = pixel centre */
+  int32_t renderer;         /* PT_RENDERER_*                                             */
+  double background[3];     /* Renderer.background_color (render.py:33)                  */
+  double onoff_color[3];    /* OnOffRenderer.color (render.py:50)                        */
+  double ambient[3];        /* PointLightRenderer.ambient_color (render.py:155)          */
+  int32_t num_of_rays;      /* PathTracer.num_of_rays (render.py:95)                     */
+  int32_t max_depth;        /* PathTracer.max_depth (render.py:96)                       */
+  int32_t rr_limit;         /* PathTracer.russian_roulette_limit (render.py:97)          */
+  int32_t pcg_mode;         /* PT_PCG_*                                                  */
+  uint64_t jitter_state, jitter_seq; /* ImageTracer.pcg seeds (SEQ mode only)            */
+  uint64_t path_state, path_seq;     /* PathTracer.pcg seeds (SEQ) / S0,Q0 (PIXEL, SAMPLE) */
+  /* Pixel partition for multi-GPU: rows are cut in blocks of `row_block` rows, block b belongs
+   * to rank b % n_ranks; a rank's output holds its rows compactly in ascending global order.
+   * n_ranks = 1 renders the whole frame. */
+  int32_t row_block, n_ranks, rank;
+  int32_t out_format; /* PT_OUT_* */
+} pt_params;
+
+typedef struct pt_stats {
+  uint64_t n_rays;      /* rays handed to a world query (primary + scattered + shadow) */
+  uint64_t n_pixels;    /* pixels written by this call                                   */
+  double kernel_ms;     /* hipEvent time of the render kernel(s) only                    */
+  double total_ms;      /* hipEvent time incl. D2H copy when the call copies             */
+  int32_t vgprs, lds_bytes, grid, block; /* launch geometry of the render kernel        */
+} pt_stats;
+
+typedef struct pt_scene pt_scene; /* opaque: device-resident scene + workspace */
+
+/* ---- entry points --------------------------------------------------------------------------*/
+int pt_device_count(void);
+/* Copy the flattened scene to the HBM of `device` (packed into the kernel's record layout). */
+int pt_scene_upload(const pt_scene_desc *desc, int device, pt_scene **out);
+void pt_scene_free(pt_scene *scene);
+/* Number of image rows rank `p->rank` owns under p's partition. */
+int pt_rows_for_rank(const pt_params *p);
+/* Bytes the output of one call needs: rows_for_rank * W * 3 * sizeof(out_format). */
+size_t pt_output_bytes(const pt_params *p);
+/* Render into a caller-owned HOST buffer (kernel + D2H); row 0 = top of the image,
+ * pixel (col,row) at out[(row*W+col)*3 + k]  (hdrimages.py:78-80). */
+int pt_render(pt_scene *scene, const pt_camera *cam, const pt_params *p, void *out_host,
+              size_t out_bytes);
+/* Render into a caller-owned DEVICE buffer on `stream` (a hipStream_t, NULL = the library's own
+ * stream); asynchronous when a stream is given. Nothing is copied to the host. */
+int pt_render_device(pt_scene *scene, const pt_camera *cam, const pt_params *p, void *out_dev,
+                     size_t out_bytes, void *stream);
+/* Statistics of the last completed pt_render / synchronised pt_render_device on this scene. */
+int pt_get_stats(pt_scene *scene, pt_stats *out);
+/* Enable (1) / disable (0) the in-kernel ray counter (default on). */
+int pt_set_count_rays(pt_scene *scene, int enable);
+/* Block until the scene's last asynchronous render has finished and fold its statistics. */
+int pt_sync(pt_scene *scene);
+/* Copy the last error message of the calling thread (NUL-terminated) into buf; returns its length. */
+int pt_last_error(char *buf, size_t n);
+/* Library/ABI version: (major<<16)|minor. */
+int pt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTRACE_H */
