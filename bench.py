@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the MI355X ray-trace/shade path.
+
+Workload (BASELINE.json configs[1], "C2"): 1280x720, 32 spheres + 1 checkered plane, FlatRenderer,
+pixel-centre rays (S=0), synthetic scene of SURVEY.md §8(d).  One *step* = one frame through the C-ABI
+(`pt_render_device`: hoist prep + render kernel) with the scene already resident in HBM and the output
+left in HBM (fp32 RGB, the reference's PFM precision: 12 B/pixel).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): weak scaling — the frame grows with
+N (same scene and view, area x N), rows are cut in interleaved 8-row blocks, every rank renders its
+blocks and the image is gathered to rank 0 with one RCCL gather per frame on a side stream, overlapped
+with the next frame's render (double-buffered); all gathers complete inside the timed region.
+
+Prints ONE JSON line (rank 0).  `value` = rays handed to a world query by all ranks / wall time.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from pytracer_amd import abi, flatten, scenes  # noqa: E402
+from pytracer_amd.device import DeviceScene  # noqa: E402
+
+PEAK_FP64_VECTOR_TFLOPS = 78.6  # MI355X vector fp64 (vendor spec; an FMA counts 2), SURVEY.md §8(d)
+PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FLOP_PER_SPHERE_TEST = 54       # 33 transform + 5 a + 6 b + 6 c + 4 delta
+FLOP_PER_PLANE_TEST = 36
+
+
+def frame_size(n_gpus: int):
+    """Weak scaling: area x N at the 16:9 view of the 1280x720 base frame."""
+    s = math.sqrt(n_gpus)
+    w = int(round(1280 * s / 2)) * 2
+    h = int(round(720 * s / 2)) * 2
+    return w, h
+
+
+def cpu_baseline(scene, cam_for, seconds_budget=20.0):
+    """Time the CPU oracle (a C restatement of the reference path: kind "port") on this host's cores,
+    on the same C2 frame.  Test infrastructure used only as a reported baseline."""
+    from oracle import oracle as orc
+
+    orc.build()
+    par = abi.make_params(1280, 720, abi.RENDERER_FLAT, out_format=abi.OUT_F32)
+    cam = cam_for(1280, 720)
+    threads = orc.max_threads()
+    t0 = time.perf_counter()
+    _, rays = orc.render(scene, cam, par, n_threads=threads, sqr_mode=orc.SQR_MUL)
+    first = time.perf_counter() - t0
+    reps = max(1, min(20, int(seconds_budget / max(first, 1e-3)) - 1))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        orc.render(scene, cam, par, n_threads=threads, sqr_mode=orc.SQR_MUL)
+    dt = (time.perf_counter() - t0) / reps
+    # one core, bounded: a 1/8 crop of the rows of the same frame
+    par1 = abi.copy_params(par, n_ranks=8, rank=3, row_block=8)
+    t0 = time.perf_counter()
+    _, rays1 = orc.render(scene, cam, par1, n_threads=1, sqr_mode=orc.SQR_MUL)
+    dt1 = time.perf_counter() - t0
+    orc.set_sqr_mode(orc.SQR_POW)
+    return {
+        "value": rays / dt / 1e6, "unit": "Mray/s", "cores": threads, "kind": "port",
+        "sample": f"full 1280x720 C2 frame x{reps} on {threads} threads (OpenMP rows), C oracle, x*x arithmetic",
+        "ms_per_frame": dt * 1e3,
+        "one_core_Mray_s": rays1 / dt1 / 1e6,
+        "one_core_sample": "rows of rank 3/8 (90 rows) of the same frame, 1 thread",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true")
+    args = ap.parse_args()
+
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    n = args.gpus
+    if world_size != n and world_size > 1:
+        n = world_size
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world_size > 1:
+        import torch.distributed as dist  # noqa: F811
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world_size,
+                                device_id=torch.device("cuda", local_rank))
+
+    W, H = frame_size(n)
+    world = scenes.synthetic_world(32, with_plane=True)
+    flat = flatten.flatten_world(world)
+    cam_for = lambda w, h: flatten.flatten_camera(scenes.synthetic_camera(w, h))  # noqa: E731
+    cam = cam_for(W, H)
+    ds = DeviceScene(flat, device=local_rank)
+    par = abi.make_params(W, H, abi.RENDERER_FLAT, out_format=abi.OUT_F32, row_block=8, n_ranks=world_size,
+                          rank=rank)
+    rows = len(abi.rows_for_rank(H, 8, world_size, rank))
+    max_rows = max(len(abi.rows_for_rank(H, 8, world_size, r)) for r in range(world_size))
+    # double-buffered output in HBM (fp32 RGB); padded to the largest shard so gathers are uniform
+    bufs = [torch.zeros((max_rows, W, 3), dtype=torch.float32, device="cuda") for _ in range(2)]
+    gathered = None
+    comm_stream = None
+    if dist is not None:
+        comm_stream = torch.cuda.Stream()
+        if rank == 0:
+            gathered = [[torch.empty_like(bufs[0]) for _ in range(world_size)] for _ in range(2)]
+    stream = torch.cuda.current_stream()
+    nbytes = rows * W * 3 * 4
+    ev_pairs = []
+    done_events = [None, None]
+
+    def step(i, timed):
+        b = i & 1
+        if done_events[b] is not None:
+            stream.wait_event(done_events[b])  # the gather that last read this buffer has finished
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+        ds.render_into(cam, par, bufs[b].data_ptr(), nbytes, stream.cuda_stream)
+        if timed:
+            e1.record(stream)
+            ev_pairs.append((e0, e1))
+        if dist is not None:
+            rendered = torch.cuda.Event()
+            rendered.record(stream)
+            with torch.cuda.stream(comm_stream):
+                comm_stream.wait_event(rendered)
+                dist.gather(bufs[b], gathered[b] if rank == 0 else None, dst=0)
+                ev = torch.cuda.Event()
+                ev.record(comm_stream)
+                done_events[b] = ev
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    ds.set_count_rays(True)
+    for i in range(args.warmup):
+        step(i, False)
+    fence()
+    ds.sync()
+    # rays per frame are counted (in-kernel counter) during warm-up; the workload is deterministic, so
+    # the timed steps run without the counter: one step == exactly one render-kernel launch
+    rays_per_step_local = int(ds.stats().n_rays) if args.warmup > 0 else rows * W
+    ds.set_count_rays(False)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i, True)
+    fence()
+    elapsed = time.perf_counter() - t0
+
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        r = torch.tensor([rays_per_step_local], dtype=torch.int64, device="cuda")
+        dist.all_reduce(r, op=dist.ReduceOp.SUM)
+        rays_per_step = int(r.item())
+    else:
+        rays_per_step = rays_per_step_local
+
+    kernel_ms = [a.elapsed_time(b) for a, b in ev_pairs]
+    avg_kernel_s = float(np.mean(kernel_ms)) * 1e-3 if kernel_ms else float("nan")
+
+    if rank == 0:
+        n_sph = int((flat.kind == abi.SHAPE_SPHERE).sum())
+        n_pl = int((flat.kind == abi.SHAPE_PLANE).sum())
+        rays_local = rows * W
+        flops = rays_local * (n_sph * FLOP_PER_SPHERE_TEST + n_pl * FLOP_PER_PLANE_TEST)
+        n_wg = ds.stats().grid
+        alg_bytes = rays_local * 12 + n_wg * flat.n_shapes * 104
+        tflops = flops / avg_kernel_s / 1e12
+        result = {
+            "metric": "Mray/s (primary+shadow) at 1280x720 per GPU, C2: 32 spheres + 1 plane, FlatRenderer",
+            "value": rays_per_step * args.steps / elapsed / 1e6,
+            "unit": "Mray/s",
+            "n_gpus": n,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"C2 flat {W}x{H}, 32 spheres + 1 plane, S=0, fp32 RGB output",
+                       "width": W, "height": H, "n_shapes": flat.n_shapes, "renderer": "FlatRenderer",
+                       "partition": f"interleaved 8-row blocks over {n} rank(s)" + (" + RCCL gather to rank 0" if n > 1 else "")},
+            "ray_shape_tests_per_s": rays_per_step * flat.n_shapes * args.steps / elapsed,
+            "roofline": {
+                "bound": "valu_fp64",
+                "achieved": tflops, "peak": PEAK_FP64_VECTOR_TFLOPS, "unit": "TFLOP/s",
+                "frac": tflops / PEAK_FP64_VECTOR_TFLOPS,
+                "traffic": None,
+                "kernel": "pt_simple_kernel<FLAT, hoisted> (+ pt_prep_hoist)",
+                "avg_kernel_ms": avg_kernel_s * 1e3,
+                "algorithmic_flop_per_launch": flops,
+                "note": "no dense contraction: MFMA unused; fp64 VALU issue binds (SURVEY.md 8d). "
+                        "peak counts an FMA as 2 flop; the parity kernel may not fuse, so its own ceiling is peak/2",
+                "hbm": {"achieved": alg_bytes / avg_kernel_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": alg_bytes / avg_kernel_s / 1e9 / PEAK_HBM_GBS,
+                        "algorithmic_bytes_per_launch": alg_bytes},
+            },
+        }
+        if n == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(flat, cam_for)
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    ds.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,75 @@
+"""Loader for libptrace.so (the HIP product library).  Fails loudly: there is no CPU fallback."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import abi
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libptrace.so")
+_lib = None
+
+# every symbol include/ptrace.h declares
+EXPORTS = ("pt_device_count", "pt_scene_upload", "pt_scene_free", "pt_rows_for_rank", "pt_output_bytes",
+           "pt_render", "pt_render_device", "pt_get_stats", "pt_set_count_rays", "pt_sync", "pt_last_error",
+           "pt_version")
+
+
+class PtraceError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"{abi.ERROR_NAMES.get(code, code)}: {message}")
+        self.code = code
+
+
+def lib_path() -> str:
+    return _LIB_PATH
+
+
+def lib():
+    """The loaded C-ABI library; raises if it has not been built (``python -m pytracer_amd.build``)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise ImportError(
+                f"{_LIB_PATH} is missing: the HIP extension has not been built. "
+                "Run `python -m pytracer_amd.build` (needs hipcc); there is no CPU fallback.")
+        L = C.CDLL(_LIB_PATH)
+        P = C.POINTER
+        L.pt_device_count.restype = C.c_int
+        L.pt_scene_upload.restype = C.c_int
+        L.pt_scene_upload.argtypes = [P(abi.SceneDesc), C.c_int, P(C.c_void_p)]
+        L.pt_scene_free.restype = None
+        L.pt_scene_free.argtypes = [C.c_void_p]
+        L.pt_rows_for_rank.restype = C.c_int
+        L.pt_rows_for_rank.argtypes = [P(abi.Params)]
+        L.pt_output_bytes.restype = C.c_size_t
+        L.pt_output_bytes.argtypes = [P(abi.Params)]
+        L.pt_render.restype = C.c_int
+        L.pt_render.argtypes = [C.c_void_p, P(abi.Camera), P(abi.Params), C.c_void_p, C.c_size_t]
+        L.pt_render_device.restype = C.c_int
+        L.pt_render_device.argtypes = [C.c_void_p, P(abi.Camera), P(abi.Params), C.c_void_p, C.c_size_t,
+                                       C.c_void_p]
+        L.pt_get_stats.restype = C.c_int
+        L.pt_get_stats.argtypes = [C.c_void_p, P(abi.Stats)]
+        L.pt_set_count_rays.restype = C.c_int
+        L.pt_set_count_rays.argtypes = [C.c_void_p, C.c_int]
+        L.pt_sync.restype = C.c_int
+        L.pt_sync.argtypes = [C.c_void_p]
+        L.pt_last_error.restype = C.c_int
+        L.pt_last_error.argtypes = [C.c_char_p, C.c_size_t]
+        L.pt_version.restype = C.c_int
+        L.pt_debug_probe.restype = C.c_int
+        L.pt_debug_probe.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        _lib = L
+    return _lib
+
+
+def last_error() -> str:
+    buf = C.create_string_buffer(512)
+    lib().pt_last_error(buf, 512)
+    return buf.value.decode("utf-8", "replace")
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise PtraceError(rc, last_error())

@@ -1,0 +1,80 @@
+// pt_layout.h — device-side (HBM) layout of a flattened scene and the kernel argument block.
+//
+// The C-ABI hands over structure-of-arrays host arrays (include/ptrace.h); pt_scene_upload packs
+// them into two array-of-records tables sized for how the kernels touch them:
+//
+//   PtShapeRec (128 B)  — what the per-ray shape loop reads for EVERY shape: the 3x4 inverse
+//                         transform + kind.  The loop index is wave-uniform, so a record is
+//                         fetched once per wave through the scalar cache (s_load_dwordx8/x16)
+//                         into SGPRs, or staged in LDS for tiles of big scenes.
+//   PtShapeAux (256 B)  — what only the CLOSEST hit needs: the forward transform and materials.
+//                         Gathered per lane after the loop.
+#pragma once
+#include <stdint.h>
+
+struct alignas(128) PtShapeRec {
+  double invm[12];  // rows 0..2 of transformation.invm, row-major
+  int32_t kind;     // PT_SHAPE_*
+  int32_t index;    // position in World.shapes (records are grouped spheres-first; ties between
+                    // equal t go to the lower index, world.py:62)
+  double _pad[3];
+};
+static_assert(sizeof(PtShapeRec) == 128, "PtShapeRec must be 128 B");
+
+struct alignas(256) PtShapeAux {
+  double m[12];  // rows 0..2 of transformation.m
+  double pig_c1[3], pig_c2[3];
+  double emi_c1[3], emi_c2[3];
+  double pig_steps, emi_steps, brdf_param;
+  int32_t brdf_kind, pig_kind, emi_kind, pig_tex, emi_tex, needs_uv;
+  double _pad[2];
+};
+static_assert(sizeof(PtShapeAux) == 256, "PtShapeAux must be 256 B");
+
+struct alignas(64) PtLight {
+  double pos[3];
+  double color[3];
+  double radius;
+  double _pad;
+};
+
+struct PtTex {
+  int32_t w, h;
+  int64_t offset;  // in doubles into tex_data
+};
+
+// Per-shape constants of the primary rays of a perspective camera (all share one origin):
+// o' = invm * origin and c = |o'|^2 - 1, computed in the reference's operation order by
+// pt_prep_hoist so the hoisted loop reproduces the per-ray arithmetic bit for bit.
+struct alignas(32) PtHoist {
+  double ox, oy, oz, c;
+};
+
+struct PtKArgs {
+  const PtShapeRec *recs;
+  const PtShapeAux *aux;
+  const PtHoist *hoist;
+  const PtLight *lights;
+  const PtTex *tex;
+  const double *tex_data;
+  void *out;                       // this rank's rows, compact
+  double *ws;                      // path-tracer frame stack: [slot][field][thread]
+  unsigned long long *ray_counter; // may be null
+  long long npix;                  // pixels this launch covers (rows_local * W)
+  int n_shapes, n_lights;
+  int n_spheres;                   // recs[0..n_spheres) are spheres, recs[n_spheres..n_shapes) planes
+  int nthreads;                    // grid * block
+  int frame_doubles;               // fields per stack frame
+  // camera (camera.py)
+  int cam_kind;
+  double cam_m[12];
+  double cam_dist, cam_aspect;
+  // image / renderer parameters (pt_params)
+  int W, H, S;
+  int N, D, rr;
+  int pcg_mode;
+  unsigned long long s0, q0;
+  int row_block, n_ranks, rank;
+  int out_f32;
+  double bg[3], onoff[3], ambient[3];
+};

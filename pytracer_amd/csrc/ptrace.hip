@@ -1,0 +1,527 @@
+// ptrace.hip — libptrace.so: the C-ABI of include/ptrace.h over the HIP kernels of pt_kernels.h.
+//
+// Boundary replaced: ImageTracer.fire_all_rays(renderer) — src/pytracer/imagetracer.py:60-110 with
+// the solvers of src/pytracer/render.py:42-193.  No torch types, no exceptions across the ABI, every
+// failure is a negative return code plus a thread-local message (pt_last_error).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/ptrace.h"
+#include "pt_kernels.h"
+#include "pt_layout.h"
+
+#define PT_VERSION ((1 << 16) | 0)
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                        \
+  do {                                                                                       \
+    hipError_t _e = (expr);                                                                  \
+    if (_e != hipSuccess)                                                                    \
+      return fail(PT_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                  __LINE__);                                                                 \
+  } while (0)
+
+struct pt_scene {
+  int device = 0;
+  int n_shapes = 0, n_spheres = 0, n_lights = 0, n_textures = 0;
+  PtShapeRec *recs = nullptr;
+  PtShapeAux *aux = nullptr;
+  PtHoist *hoist = nullptr;
+  PtLight *lights = nullptr;
+  PtTex *tex = nullptr;
+  double *tex_data = nullptr;
+  double *ws = nullptr;  // path-tracer frame stack, grown on demand
+  size_t ws_bytes = 0;
+  void *out_dev = nullptr;  // staging for pt_render (host output)
+  size_t out_dev_bytes = 0;
+  unsigned long long *ray_counter = nullptr;
+  unsigned long long *ray_counter_host = nullptr;  // pinned
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
+  bool count_rays = true;
+  bool pending = false;  // an async render whose stats are not folded yet
+  bool pending_copy = false;
+  bool hoist_valid = false;  // s->hoist holds the constants of hoist_cam
+  pt_camera hoist_cam = {};
+  hipStream_t hoist_stream = nullptr;  // the stream the constants were produced on
+  int n_cu = 256;
+  pt_stats stats = {};
+};
+
+extern "C" int pt_version(void) { return PT_VERSION; }
+
+extern "C" int pt_last_error(char *buf, size_t n) {
+  const size_t len = strlen(g_err);
+  if (buf && n) {
+    const size_t c = std::min(len, n - 1);
+    memcpy(buf, g_err, c);
+    buf[c] = 0;
+  }
+  return (int)len;
+}
+
+extern "C" int pt_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+extern "C" int pt_rows_for_rank(const pt_params *p) {
+  if (!p || p->height <= 0) return 0;
+  const int rb = p->row_block > 0 ? p->row_block : 1;
+  const int nr = p->n_ranks > 0 ? p->n_ranks : 1;
+  int rows = 0;
+  for (int b = 0; b * rb < p->height; ++b)
+    if (b % nr == p->rank) rows += std::min(rb, p->height - b * rb);
+  return rows;
+}
+
+extern "C" size_t pt_output_bytes(const pt_params *p) {
+  if (!p) return 0;
+  return (size_t)pt_rows_for_rank(p) * (size_t)p->width * 3 * (p->out_format == PT_OUT_F32 ? 4 : 8);
+}
+
+static int check_desc(const pt_scene_desc *d) {
+  if (!d) return fail(PT_ERR_INVALID, "null scene descriptor");
+  if (d->n_shapes < 0 || d->n_lights < 0 || d->n_textures < 0)
+    return fail(PT_ERR_INVALID, "negative count in scene descriptor");
+  if (d->n_shapes > 0 &&
+      (!d->kind || !d->invm || !d->m || !d->brdf_kind || !d->brdf_param || !d->pig_kind ||
+       !d->pig_c1 || !d->pig_c2 || !d->pig_steps || !d->pig_tex || !d->emi_kind || !d->emi_c1 ||
+       !d->emi_c2 || !d->emi_steps || !d->emi_tex))
+    return fail(PT_ERR_INVALID, "null array in scene descriptor");
+  if (d->n_lights > 0 && (!d->light_pos || !d->light_color || !d->light_radius))
+    return fail(PT_ERR_INVALID, "null light array in scene descriptor");
+  if (d->n_textures > 0 && (!d->tex_w || !d->tex_h || !d->tex_offset || !d->tex_data))
+    return fail(PT_ERR_INVALID, "null texture array in scene descriptor");
+  for (int i = 0; i < d->n_shapes; ++i) {
+    if (d->kind[i] != PT_SHAPE_SPHERE && d->kind[i] != PT_SHAPE_PLANE)
+      return fail(PT_ERR_INVALID, "shape %d: unknown kind %d", i, d->kind[i]);
+    if (d->brdf_kind[i] != PT_BRDF_DIFFUSE && d->brdf_kind[i] != PT_BRDF_SPECULAR)
+      return fail(PT_ERR_INVALID, "shape %d: unknown BRDF kind %d", i, d->brdf_kind[i]);
+    const int pk[2] = {d->pig_kind[i], d->emi_kind[i]};
+    const int pt[2] = {d->pig_tex[i], d->emi_tex[i]};
+    for (int k = 0; k < 2; ++k) {
+      if (pk[k] < PT_PIGMENT_UNIFORM || pk[k] > PT_PIGMENT_IMAGE)
+        return fail(PT_ERR_INVALID, "shape %d: unknown pigment kind %d", i, pk[k]);
+      if (pk[k] == PT_PIGMENT_IMAGE && (pt[k] < 0 || pt[k] >= d->n_textures))
+        return fail(PT_ERR_INVALID, "shape %d: texture index %d out of range", i, pt[k]);
+    }
+  }
+  for (int t = 0; t < d->n_textures; ++t)
+    if (d->tex_w[t] <= 0 || d->tex_h[t] <= 0 || d->tex_offset[t] < 0)
+      return fail(PT_ERR_INVALID, "texture %d: bad size/offset", t);
+  return PT_OK;
+}
+
+extern "C" void pt_scene_free(pt_scene *s) {
+  if (!s) return;
+  (void)hipSetDevice(s->device);
+  if (s->stream) (void)hipStreamSynchronize(s->stream);
+  (void)hipFree(s->recs);
+  (void)hipFree(s->aux);
+  (void)hipFree(s->hoist);
+  (void)hipFree(s->lights);
+  (void)hipFree(s->tex);
+  (void)hipFree(s->tex_data);
+  (void)hipFree(s->ws);
+  (void)hipFree(s->out_dev);
+  (void)hipFree(s->ray_counter);
+  if (s->ray_counter_host) (void)hipHostFree(s->ray_counter_host);
+  if (s->ev0) (void)hipEventDestroy(s->ev0);
+  if (s->ev1) (void)hipEventDestroy(s->ev1);
+  if (s->ev2) (void)hipEventDestroy(s->ev2);
+  if (s->stream) (void)hipStreamDestroy(s->stream);
+  delete s;
+}
+
+template <typename T>
+static int upload(T **dst, const std::vector<T> &src) {
+  const size_t bytes = std::max<size_t>(src.size(), 1) * sizeof(T);
+  HIP_TRY(hipMalloc((void **)dst, bytes));
+  if (!src.empty()) HIP_TRY(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+  return PT_OK;
+}
+
+extern "C" int pt_scene_upload(const pt_scene_desc *d, int device, pt_scene **out) {
+  if (!out) return fail(PT_ERR_INVALID, "null output handle");
+  *out = nullptr;
+  int rc = check_desc(d);
+  if (rc) return rc;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(PT_ERR_NODEVICE, "no HIP device visible");
+  if (device < 0 || device >= ndev) return fail(PT_ERR_INVALID, "device %d out of range [0,%d)", device, ndev);
+  HIP_TRY(hipSetDevice(device));
+
+  pt_scene *s = new (std::nothrow) pt_scene();
+  if (!s) return fail(PT_ERR_NOMEM, "out of host memory");
+  s->device = device;
+  s->n_shapes = d->n_shapes;
+  s->n_lights = d->n_lights;
+  s->n_textures = d->n_textures;
+  const int n = d->n_shapes;
+
+  // group the records: spheres first, then planes, each group in World.shapes order
+  std::vector<int> order;
+  order.reserve(n);
+  for (int i = 0; i < n; ++i)
+    if (d->kind[i] == PT_SHAPE_SPHERE) order.push_back(i);
+  s->n_spheres = (int)order.size();
+  for (int i = 0; i < n; ++i)
+    if (d->kind[i] != PT_SHAPE_SPHERE) order.push_back(i);
+  std::vector<PtShapeRec> recs(n);
+  std::vector<PtShapeAux> aux(n);
+  for (int slot = 0; slot < n; ++slot) {
+    const int i = order[slot];
+    PtShapeRec &r = recs[slot];
+    PtShapeAux &x = aux[slot];
+    memset(&r, 0, sizeof r);
+    memset(&x, 0, sizeof x);
+    for (int k = 0; k < 12; ++k) {
+      r.invm[k] = d->invm[(size_t)k * n + i];
+      x.m[k] = d->m[(size_t)k * n + i];
+    }
+    r.kind = d->kind[i];
+    for (int k = 0; k < 3; ++k) {
+      x.pig_c1[k] = d->pig_c1[(size_t)k * n + i];
+      x.pig_c2[k] = d->pig_c2[(size_t)k * n + i];
+      x.emi_c1[k] = d->emi_c1[(size_t)k * n + i];
+      x.emi_c2[k] = d->emi_c2[(size_t)k * n + i];
+    }
+    x.pig_steps = d->pig_steps[i];
+    x.emi_steps = d->emi_steps[i];
+    x.brdf_param = d->brdf_param[i];
+    x.brdf_kind = d->brdf_kind[i];
+    x.pig_kind = d->pig_kind[i];
+    x.emi_kind = d->emi_kind[i];
+    x.pig_tex = d->pig_tex[i];
+    x.emi_tex = d->emi_tex[i];
+    x.needs_uv = (d->pig_kind[i] != PT_PIGMENT_UNIFORM || d->emi_kind[i] != PT_PIGMENT_UNIFORM) ? 1 : 0;
+    r.index = i;
+  }
+  std::vector<PtLight> lights(d->n_lights);
+  for (int l = 0; l < d->n_lights; ++l) {
+    memset(&lights[l], 0, sizeof(PtLight));
+    for (int k = 0; k < 3; ++k) {
+      lights[l].pos[k] = d->light_pos[(size_t)k * d->n_lights + l];
+      lights[l].color[k] = d->light_color[(size_t)k * d->n_lights + l];
+    }
+    lights[l].radius = d->light_radius[l];
+  }
+  std::vector<PtTex> tex(d->n_textures);
+  size_t tex_doubles = 0;
+  for (int t = 0; t < d->n_textures; ++t) {
+    tex[t].w = d->tex_w[t];
+    tex[t].h = d->tex_h[t];
+    tex[t].offset = d->tex_offset[t];
+    tex_doubles = std::max(tex_doubles, (size_t)d->tex_offset[t] + (size_t)d->tex_w[t] * d->tex_h[t] * 3);
+  }
+  std::vector<double> tex_data(d->tex_data, d->tex_data + tex_doubles);
+
+#define UP(call)            \
+  do {                      \
+    rc = (call);            \
+    if (rc) {               \
+      pt_scene_free(s);     \
+      return rc;            \
+    }                       \
+  } while (0)
+  UP(upload(&s->recs, recs));
+  UP(upload(&s->aux, aux));
+  UP(upload(&s->lights, lights));
+  UP(upload(&s->tex, tex));
+  UP(upload(&s->tex_data, tex_data));
+  {
+    std::vector<PtHoist> h(std::max(n, 1));
+    UP(upload(&s->hoist, h));
+  }
+#undef UP
+  auto hip_or_free = [&](hipError_t e, const char *what) -> int {
+    if (e == hipSuccess) return PT_OK;
+    int code = fail(PT_ERR_HIP, "%s failed: %s", what, hipGetErrorString(e));
+    pt_scene_free(s);
+    return code;
+  };
+  if ((rc = hip_or_free(hipMalloc((void **)&s->ray_counter, sizeof(unsigned long long)), "hipMalloc(counter)"))) return rc;
+  if ((rc = hip_or_free(hipHostMalloc((void **)&s->ray_counter_host, sizeof(unsigned long long)), "hipHostMalloc"))) return rc;
+  *s->ray_counter_host = 0;
+  if ((rc = hip_or_free(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking), "hipStreamCreate"))) return rc;
+  if ((rc = hip_or_free(hipEventCreate(&s->ev0), "hipEventCreate"))) return rc;
+  if ((rc = hip_or_free(hipEventCreate(&s->ev1), "hipEventCreate"))) return rc;
+  if ((rc = hip_or_free(hipEventCreate(&s->ev2), "hipEventCreate"))) return rc;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) s->n_cu = prop.multiProcessorCount;
+  *out = s;
+  return PT_OK;
+}
+
+extern "C" int pt_set_count_rays(pt_scene *s, int enable) {
+  if (!s) return fail(PT_ERR_INVALID, "null scene");
+  s->count_rays = enable != 0;
+  return PT_OK;
+}
+
+static int check_params(const pt_scene *s, const pt_camera *cam, const pt_params *p) {
+  if (!s || !cam || !p) return fail(PT_ERR_INVALID, "null argument");
+  if (p->width <= 0 || p->height <= 0) return fail(PT_ERR_INVALID, "bad image size %dx%d", p->width, p->height);
+  if (p->samples_per_side < 0 || p->samples_per_side > 1024)
+    return fail(PT_ERR_INVALID, "bad samples_per_side %d", p->samples_per_side);
+  if (p->renderer < PT_RENDERER_ONOFF || p->renderer > PT_RENDERER_POINTLIGHT)
+    return fail(PT_ERR_INVALID, "unknown renderer %d", p->renderer);
+  if (cam->kind != PT_CAMERA_ORTHOGONAL && cam->kind != PT_CAMERA_PERSPECTIVE)
+    return fail(PT_ERR_INVALID, "unknown camera kind %d", cam->kind);
+  if (p->out_format != PT_OUT_F64 && p->out_format != PT_OUT_F32)
+    return fail(PT_ERR_INVALID, "unknown output format %d", p->out_format);
+  const int nr = p->n_ranks > 0 ? p->n_ranks : 1;
+  if (p->rank < 0 || p->rank >= nr) return fail(PT_ERR_INVALID, "rank %d outside [0,%d)", p->rank, nr);
+  if (p->pcg_mode == PT_PCG_SEQ && (p->samples_per_side > 0 || p->renderer == PT_RENDERER_PATHTRACER))
+    return fail(PT_ERR_UNSUPPORTED,
+                "PT_PCG_SEQ (two global sequential streams) is inherently serial; the device path "
+                "implements PT_PCG_PIXEL and PT_PCG_SAMPLE");
+  if (p->pcg_mode < PT_PCG_SEQ || p->pcg_mode > PT_PCG_SAMPLE)
+    return fail(PT_ERR_INVALID, "unknown pcg_mode %d", p->pcg_mode);
+  if (p->renderer == PT_RENDERER_PATHTRACER) {
+    if (p->num_of_rays < 1)
+      return fail(PT_ERR_INVALID, "num_of_rays must be >= 1 (the reference divides by it, render.py:139)");
+    if (p->max_depth > 4096) return fail(PT_ERR_INVALID, "max_depth %d too large", p->max_depth);
+  }
+  if ((long long)p->width * p->height > (1LL << 40)) return fail(PT_ERR_INVALID, "image too large");
+  return PT_OK;
+}
+
+static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *out_dev, hipStream_t st) {
+  PtKArgs a;
+  memset(&a, 0, sizeof a);
+  a.recs = s->recs;
+  a.aux = s->aux;
+  a.hoist = s->hoist;
+  a.lights = s->lights;
+  a.tex = s->tex;
+  a.tex_data = s->tex_data;
+  a.out = out_dev;
+  a.ray_counter = s->count_rays ? s->ray_counter : nullptr;
+  a.n_shapes = s->n_shapes;
+  a.n_spheres = s->n_spheres;
+  a.n_lights = s->n_lights;
+  a.cam_kind = cam->kind;
+  memcpy(a.cam_m, cam->m, sizeof a.cam_m);
+  a.cam_dist = cam->screen_distance;
+  a.cam_aspect = cam->aspect_ratio;
+  a.W = p->width;
+  a.H = p->height;
+  a.S = p->samples_per_side;
+  a.N = p->num_of_rays;
+  a.D = p->max_depth;
+  a.rr = p->rr_limit;
+  a.pcg_mode = p->pcg_mode == PT_PCG_SEQ ? PT_PCG_PIXEL : p->pcg_mode;
+  a.s0 = p->path_state;
+  a.q0 = p->path_seq;
+  a.row_block = p->row_block > 0 ? p->row_block : 1;
+  a.n_ranks = p->n_ranks > 0 ? p->n_ranks : 1;
+  a.rank = p->rank;
+  a.out_f32 = p->out_format == PT_OUT_F32;
+  for (int k = 0; k < 3; ++k) {
+    a.bg[k] = p->background[k];
+    a.onoff[k] = p->onoff_color[k];
+    a.ambient[k] = p->ambient[k];
+  }
+  const int rows = pt_rows_for_rank(p);
+  a.npix = (long long)rows * p->width;
+  s->stats.n_pixels = (uint64_t)a.npix;
+  if (a.npix == 0) return PT_OK;
+
+  // grid: one lane per pixel up to the resident capacity of the chip, grid-stride beyond
+  const long long want = (a.npix + PT_BLOCK - 1) / PT_BLOCK;
+  const long long cap = (long long)s->n_cu * 8;  // 8 x 256-thread workgroups per CU = 32 waves/CU
+  const int grid = (int)std::max<long long>(1, std::min(want, cap));
+  a.nthreads = grid * PT_BLOCK;
+  s->stats.grid = grid;
+  s->stats.block = PT_BLOCK;
+
+  if (s->count_rays) HIP_TRY(hipMemsetAsync(s->ray_counter, 0, sizeof(unsigned long long), st));
+
+  const bool hoist = cam->kind == PT_CAMERA_PERSPECTIVE && p->renderer != PT_RENDERER_PATHTRACER && s->n_shapes > 0;
+  if (hoist && !(s->hoist_valid && s->hoist_stream == st && memcmp(&s->hoist_cam, cam, sizeof(pt_camera)) == 0)) {
+    V3 o = {-cam->screen_distance, 0.0, 0.0};
+    // camera.py:116-124: origin (-d, 0, 0) through the camera transformation, reference order
+    V3 w;
+    w.x = o.x * cam->m[0] + o.y * cam->m[1] + o.z * cam->m[2] + cam->m[3];
+    w.y = o.x * cam->m[4] + o.y * cam->m[5] + o.z * cam->m[6] + cam->m[7];
+    w.z = o.x * cam->m[8] + o.y * cam->m[9] + o.z * cam->m[10] + cam->m[11];
+    hipLaunchKernelGGL(pt_prep_hoist, dim3((s->n_shapes + 255) / 256), dim3(256), 0, st, s->recs, s->hoist,
+                       s->n_shapes, w);
+    s->hoist_cam = *cam;
+    s->hoist_valid = true;
+    s->hoist_stream = st;
+  }
+
+  if (p->renderer == PT_RENDERER_PATHTRACER) {
+    a.frame_doubles = p->num_of_rays > 1 ? 20 : 6;
+    const size_t slots = (size_t)std::max(p->max_depth, 0) + 1;
+    const size_t need = slots * a.frame_doubles * (size_t)a.nthreads * sizeof(double);
+    if (need > s->ws_bytes) {
+      HIP_TRY(hipStreamSynchronize(st));
+      if (s->ws) HIP_TRY(hipFree(s->ws));
+      s->ws = nullptr;
+      s->ws_bytes = 0;
+      HIP_TRY(hipMalloc((void **)&s->ws, need));
+      s->ws_bytes = need;
+    }
+    a.ws = s->ws;
+  }
+
+  HIP_TRY(hipEventRecord(s->ev0, st));
+  switch (p->renderer) {
+    case PT_RENDERER_ONOFF:
+      if (hoist)
+        hipLaunchKernelGGL((pt_simple_kernel<PT_RENDERER_ONOFF, true>), dim3(grid), dim3(PT_BLOCK), 0, st, a);
+      else
+        hipLaunchKernelGGL((pt_simple_kernel<PT_RENDERER_ONOFF, false>), dim3(grid), dim3(PT_BLOCK), 0, st, a);
+      break;
+    case PT_RENDERER_FLAT:
+      if (hoist)
+        hipLaunchKernelGGL((pt_simple_kernel<PT_RENDERER_FLAT, true>), dim3(grid), dim3(PT_BLOCK), 0, st, a);
+      else
+        hipLaunchKernelGGL((pt_simple_kernel<PT_RENDERER_FLAT, false>), dim3(grid), dim3(PT_BLOCK), 0, st, a);
+      break;
+    case PT_RENDERER_POINTLIGHT:
+      if (hoist)
+        hipLaunchKernelGGL((pt_simple_kernel<PT_RENDERER_POINTLIGHT, true>), dim3(grid), dim3(PT_BLOCK), 0, st, a);
+      else
+        hipLaunchKernelGGL((pt_simple_kernel<PT_RENDERER_POINTLIGHT, false>), dim3(grid), dim3(PT_BLOCK), 0, st, a);
+      break;
+    default:
+      hipLaunchKernelGGL(pt_path_kernel, dim3(grid), dim3(PT_BLOCK), 0, st, a);
+      break;
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(s->ev1, st));
+  if (s->count_rays)
+    HIP_TRY(hipMemcpyAsync(s->ray_counter_host, s->ray_counter, sizeof(unsigned long long),
+                           hipMemcpyDeviceToHost, st));
+  return PT_OK;
+}
+
+static int fold_stats(pt_scene *s) {
+  if (!s->pending) return PT_OK;
+  float ms = 0.f;
+  HIP_TRY(hipEventSynchronize(s->pending_copy ? s->ev2 : s->ev1));
+  if (s->stats.n_pixels > 0) {
+    HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+    s->stats.kernel_ms = ms;
+    if (s->pending_copy) {
+      HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev2));
+    }
+    s->stats.total_ms = ms;
+  } else {
+    s->stats.kernel_ms = s->stats.total_ms = 0.0;
+  }
+  s->stats.n_rays = s->count_rays ? *s->ray_counter_host : 0;
+  s->pending = false;
+  s->pending_copy = false;
+  return PT_OK;
+}
+
+extern "C" int pt_render_device(pt_scene *s, const pt_camera *cam, const pt_params *p, void *out_dev,
+                                size_t out_bytes, void *stream) {
+  int rc = check_params(s, cam, p);
+  if (rc) return rc;
+  const size_t need = pt_output_bytes(p);
+  if (out_bytes < need) return fail(PT_ERR_SIZE, "output buffer too small: %zu < %zu bytes", out_bytes, need);
+  if (need > 0 && !out_dev) return fail(PT_ERR_INVALID, "null output buffer");
+  HIP_TRY(hipSetDevice(s->device));
+  // an earlier asynchronous render that was never synchronised simply loses its statistics:
+  // folding them here would block the host on the device every frame
+  s->pending = false;
+  hipStream_t st = stream ? (hipStream_t)stream : s->stream;
+  rc = launch(s, cam, p, out_dev, st);
+  if (rc) return rc;
+  if (s->stats.n_pixels > 0) {
+    s->pending = true;
+    s->pending_copy = false;
+  }
+  if (!stream) return pt_sync(s);
+  return PT_OK;
+}
+
+extern "C" int pt_sync(pt_scene *s) {
+  if (!s) return fail(PT_ERR_INVALID, "null scene");
+  HIP_TRY(hipSetDevice(s->device));
+  return fold_stats(s);
+}
+
+extern "C" int pt_render(pt_scene *s, const pt_camera *cam, const pt_params *p, void *out_host,
+                         size_t out_bytes) {
+  int rc = check_params(s, cam, p);
+  if (rc) return rc;
+  const size_t need = pt_output_bytes(p);
+  if (out_bytes < need) return fail(PT_ERR_SIZE, "output buffer too small: %zu < %zu bytes", out_bytes, need);
+  if (need > 0 && !out_host) return fail(PT_ERR_INVALID, "null output buffer");
+  HIP_TRY(hipSetDevice(s->device));
+  if (s->pending) {
+    rc = fold_stats(s);
+    if (rc) return rc;
+  }
+  if (need > s->out_dev_bytes) {
+    if (s->out_dev) HIP_TRY(hipFree(s->out_dev));
+    s->out_dev = nullptr;
+    s->out_dev_bytes = 0;
+    HIP_TRY(hipMalloc(&s->out_dev, need));
+    s->out_dev_bytes = need;
+  }
+  rc = launch(s, cam, p, s->out_dev, s->stream);
+  if (rc) return rc;
+  if (need > 0) {
+    HIP_TRY(hipMemcpyAsync(out_host, s->out_dev, need, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipEventRecord(s->ev2, s->stream));
+    s->pending = true;
+    s->pending_copy = true;
+  }
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  return fold_stats(s);
+}
+
+extern "C" int pt_get_stats(pt_scene *s, pt_stats *out) {
+  if (!s || !out) return fail(PT_ERR_INVALID, "null argument");
+  if (s->pending) {
+    int rc = pt_sync(s);
+    if (rc) return rc;
+  }
+  *out = s->stats;
+  return PT_OK;
+}
+
+// ---- diagnostics (not part of the reference seam): device primitive probe used by the tests -------------
+extern "C" int pt_debug_probe(int op, const double *x, const double *y, double *out, int n) {
+  if (n <= 0 || !x || !out) return fail(PT_ERR_INVALID, "bad probe arguments");
+  double *dx = nullptr, *dy = nullptr, *dout = nullptr;
+  const size_t bytes = (size_t)n * sizeof(double);
+  HIP_TRY(hipMalloc((void **)&dx, bytes));
+  HIP_TRY(hipMalloc((void **)&dy, bytes));
+  HIP_TRY(hipMalloc((void **)&dout, bytes));
+  HIP_TRY(hipMemcpy(dx, x, bytes, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(dy, y ? y : x, bytes, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(pt_probe_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, op, dx, dy, dout, n);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost));
+  (void)hipFree(dx);
+  (void)hipFree(dy);
+  (void)hipFree(dout);
+  return PT_OK;
+}

@@ -1,0 +1,82 @@
+"""DeviceScene: a scene resident in the HBM of one MI355X, rendered through the C-ABI."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import _lib, abi
+
+
+class DeviceScene:
+    """Owns a ``pt_scene`` handle (``pt_scene_upload`` / ``pt_scene_free``)."""
+
+    def __init__(self, scene: abi.FlatScene, device: int = 0):
+        self._h = C.c_void_p()
+        self.flat = scene
+        self.device = device
+        d = scene.desc()
+        _lib.check(_lib.lib().pt_scene_upload(C.byref(d), int(device), C.byref(self._h)))
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h.value:
+            _lib.lib().pt_scene_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # ------------------------------------------------------------------------------------------
+    @staticmethod
+    def output_shape(params: abi.Params) -> Tuple[int, int, int]:
+        return int(_lib.lib().pt_rows_for_rank(C.byref(params))), int(params.width), 3
+
+    def render(self, cam: abi.Camera, params: abi.Params) -> np.ndarray:
+        """Kernel + device->host copy; returns ``[rows_for_rank, W, 3]`` (fp64 or fp32)."""
+        dt = np.float64 if params.out_format == abi.OUT_F64 else np.float32
+        out = np.empty(self.output_shape(params), dtype=dt)
+        _lib.check(_lib.lib().pt_render(self._h, C.byref(cam), C.byref(params),
+                                        out.ctypes.data_as(C.c_void_p), out.nbytes))
+        return out
+
+    def render_into(self, cam: abi.Camera, params: abi.Params, dev_ptr: int, nbytes: int,
+                    stream: Optional[int] = None) -> None:
+        """Render into caller-owned device memory (e.g. a torch tensor's ``data_ptr()``) on ``stream``
+        (a ``hipStream_t`` value; ``None`` = the library's stream, synchronous)."""
+        _lib.check(_lib.lib().pt_render_device(self._h, C.byref(cam), C.byref(params), C.c_void_p(dev_ptr),
+                                               nbytes, C.c_void_p(stream) if stream else None))
+
+    def sync(self) -> None:
+        _lib.check(_lib.lib().pt_sync(self._h))
+
+    def set_count_rays(self, enable: bool) -> None:
+        _lib.check(_lib.lib().pt_set_count_rays(self._h, int(bool(enable))))
+
+    def stats(self) -> abi.Stats:
+        st = abi.Stats()
+        _lib.check(_lib.lib().pt_get_stats(self._h, C.byref(st)))
+        return st
+
+
+def device_count() -> int:
+    return int(_lib.lib().pt_device_count())
+
+
+def probe(op: int, x, y=None) -> np.ndarray:
+    """Evaluate a device primitive elementwise (tests: IEEE exactness / ulp distance to libm)."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = x if y is None else np.ascontiguousarray(y, dtype=np.float64)
+    out = np.empty_like(x)
+    _lib.check(_lib.lib().pt_debug_probe(op, x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p),
+                                         out.ctypes.data_as(C.c_void_p), x.size))
+    return out

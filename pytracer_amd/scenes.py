@@ -8,8 +8,8 @@ from __future__ import annotations
 from typing import Tuple
 
 from .hostmodel import (PCG, CheckeredPigment, Color, DiffuseBRDF, Material, PerspectiveCamera, Plane,
-                        PointLight, SpecularBRDF, Sphere, UniformPigment, Vec, World, rotation_y,
-                        rotation_z, scaling, translation)
+                        PointLight, SpecularBRDF, Sphere, Transformation, UniformPigment, Vec, World,
+                        rotation_y, rotation_z, scaling, translation)
 
 BLACK = Color(0.0, 0.0, 0.0)
 
@@ -52,6 +52,16 @@ def synthetic_camera(width: int, height: int) -> PerspectiveCamera:
                              transformation=translation(Vec(-1.0, 0.0, 1.0)))
 
 
+def _as_parsed(*factors) -> Transformation:
+    """Compose factors the way the reference's scene parser does (scene_file.py:505-560): it starts
+    from the identity and multiplies every factor in, so even a single ``translation(...)`` has gone
+    through one matrix product (which e.g. turns the -0.0 entries of an inverse into +0.0)."""
+    result = Transformation()
+    for f in factors:
+        result = result * f
+    return result
+
+
 def demo_world(clock: float = 150.0) -> Tuple[World, PerspectiveCamera]:
     """The scene described by the reference's examples/demo.txt:1-28 (pure data: two planes, one
     sphere, three materials, one point light, a perspective camera)."""
@@ -61,9 +71,9 @@ def demo_world(clock: float = 150.0) -> Tuple[World, PerspectiveCamera]:
     mirror = Material(SpecularBRDF(UniformPigment(Color(0.5, 0.5, 0.5))), UniformPigment(BLACK))
     world = World()
     world.add_light(PointLight(Vec(10.0, 10.0, 10.0), Color(1.0, 1.0, 1.0), 1.0))
-    world.add_shape(Plane(translation(Vec(0.0, 0.0, 100.0)) * rotation_y(clock), sky))
-    world.add_shape(Plane(material=ground))
-    world.add_shape(Sphere(translation(Vec(0.0, 0.0, 1.0)), mirror))
+    world.add_shape(Plane(_as_parsed(translation(Vec(0.0, 0.0, 100.0)), rotation_y(clock)), sky))
+    world.add_shape(Plane(_as_parsed(), ground))
+    world.add_shape(Sphere(_as_parsed(translation(Vec(0.0, 0.0, 1.0))), mirror))
     camera = PerspectiveCamera(screen_distance=1.0, aspect_ratio=1.0,
-                               transformation=rotation_z(30.0) * translation(Vec(-4.0, 0.0, 1.0)))
+                               transformation=_as_parsed(rotation_z(30.0), translation(Vec(-4.0, 0.0, 1.0))))
     return world, camera

@@ -1,0 +1,276 @@
+"""GPU parity tests (run with ``-m gpu`` on an MI355X): the HIP path, called through the C-ABI, against
+
+* the golden fixtures (outputs of the reference itself),
+* the CPU oracle on the same seeded inputs (sqr mode ``x*x`` = the device arithmetic),
+* size-independent properties at BASELINE.json's full sizes.
+
+Bars (BASELINE.json north_star): bit-exact for the on/off renderer; <= 1e-5 relative per channel
+elsewhere (fp64 output, so the floor is libm-vs-ocml last-ulp differences).  Where no
+libm transcendental is involved the device must equal the oracle's ``x*x`` mode bit for bit.
+"""
+import math
+
+import numpy as np
+import pytest
+
+from pytracer_amd import abi
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from pytracer_amd import device
+
+    assert device.device_count() >= 1, "no HIP device visible"
+    return device
+
+
+def _device_ok(par: abi.Params) -> bool:
+    """SEQ fixtures that draw no random number are mode-independent and run on the device."""
+    return not (par.pcg_mode == abi.PCG_SEQ and (par.samples_per_side > 0 or par.renderer == abi.RENDERER_PATHTRACER))
+
+
+def _uses_libm(scene: abi.FlatScene, par: abi.Params) -> bool:
+    """True when the frame can depend on sin/cos/atan2/acos (the only non-bit-exact operations)."""
+    sphere_uv = bool(np.any((scene.kind == abi.SHAPE_SPHERE) &
+                            ((scene.pig_kind != abi.PIGMENT_UNIFORM) | (scene.emi_kind != abi.PIGMENT_UNIFORM))))
+    if par.renderer == abi.RENDERER_PATHTRACER:
+        return True  # diffuse scattering uses sin/cos
+    if par.renderer == abi.RENDERER_POINTLIGHT:
+        return sphere_uv or bool(np.any(scene.brdf_kind == abi.BRDF_SPECULAR))  # specular eval: acos
+    if par.renderer == abi.RENDERER_FLAT:
+        return sphere_uv
+    return False
+
+
+# ---- device primitives --------------------------------------------------------------------------------
+def test_sqrt_div_are_ieee_exact(dev):
+    rng = np.random.default_rng(1)
+    x = np.concatenate([rng.uniform(0, 1e3, 200000), 10.0 ** rng.uniform(-300, 300, 200000),
+                        np.array([0.0, 1.0, 2.0, 4.0, 1e-310, 5e-324])])
+    assert util.bits_equal(dev.probe(0, x), np.sqrt(x))
+    a = rng.normal(size=400000) * 10.0 ** rng.integers(-20, 20, 400000)
+    b = rng.normal(size=400000) * 10.0 ** rng.integers(-20, 20, 400000)
+    assert util.bits_equal(dev.probe(1, a, b), a / b)
+    # PCG floats: integer / 0xFFFFFFFF
+    n = rng.integers(0, 2 ** 32, 200000).astype(np.float64)
+    assert util.bits_equal(dev.probe(1, n, np.full_like(n, 4294967295.0)), n / 4294967295.0)
+    assert util.bits_equal(dev.probe(6, a), np.floor(a))
+
+
+def test_no_fma_contraction(dev):
+    rng = np.random.default_rng(2)
+    a, b = rng.normal(size=100000), rng.normal(size=100000)
+    got = dev.probe(7, a, b)
+    assert util.bits_equal(got, (a * b) + a), "a*b+c was fused: build without -ffp-contract=off?"
+
+
+def test_transcendental_ulp_distance(dev):
+    """ocml vs glibc: report and bound the distance (not bit-exact by construction)."""
+    rng = np.random.default_rng(3)
+    x = rng.uniform(0, 2 * math.pi, 20000)
+    ref_sin = np.array([math.sin(v) for v in x])
+    ref_cos = np.array([math.cos(v) for v in x])
+    for op, ref in ((2, ref_sin), (3, ref_cos)):
+        got = dev.probe(op, x)
+        assert np.max(np.abs(got - ref)) <= 4 * np.finfo(np.float64).eps
+    y, xx = rng.uniform(-1, 1, 20000), rng.uniform(-1, 1, 20000)
+    got = dev.probe(4, y, xx)
+    ref = np.array([math.atan2(a, b) for a, b in zip(y, xx)])
+    assert np.max(np.abs(got - ref)) <= 8 * np.finfo(np.float64).eps
+    z = rng.uniform(-1, 1, 20000)
+    got = dev.probe(5, z)
+    ref = np.array([math.acos(v) for v in z])
+    assert np.max(np.abs(got - ref)) <= 8 * np.finfo(np.float64).eps
+
+
+# ---- golden frames ----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", util.FRAME_FIXTURES)
+def test_frame_vs_reference_golden(dev, oracle, name):
+    scene, cam, par, pixels = util.load_frame(name)
+    if not _device_ok(par):
+        pytest.skip("fixture uses the reference's two global sequential PCG streams (serial by construction)")
+    with dev.DeviceScene(scene) as ds:
+        out = ds.render(cam, par)
+        st = ds.stats()
+    assert out.shape == pixels.shape
+    # (1) against the oracle in the device's own arithmetic (x*x): exact unless libm is involved
+    par_o = abi.copy_params(par, pcg_mode=abi.PCG_PIXEL if par.pcg_mode == abi.PCG_SEQ else par.pcg_mode)
+    ora, n_rays = oracle.render(scene, cam, par_o, sqr_mode=oracle.SQR_MUL)
+    oracle.set_sqr_mode(oracle.SQR_POW)
+    if not _uses_libm(scene, par):
+        assert util.bits_equal(out, ora), f"device != oracle(x*x): max rel {util.rel_err(out, ora).max()}"
+    # (2) against the reference's own output
+    if par.renderer == abi.RENDERER_ONOFF:
+        assert util.bits_equal(out, pixels), "OnOff must be bit-exact"
+    err = util.rel_err(out, pixels)
+    bad = int((err > TOL).any(axis=-1).sum())
+    print(f"{name}: max rel err {err.max():.3e}, pixels over {TOL:g}: {bad}/{err.shape[0] * err.shape[1]}")
+    assert bad == 0, f"{bad} pixels differ from the reference by more than {TOL}"
+    # ray accounting equals the oracle's count of world queries
+    if not _uses_libm(scene, par) or par.renderer != abi.RENDERER_PATHTRACER:
+        assert st.n_rays == n_rays
+    assert st.n_pixels == par.width * par.height
+
+
+def test_f32_output_is_rounded_f64(dev):
+    scene, cam, par, _ = util.load_frame("g5_c2_flat_160x90")
+    with dev.DeviceScene(scene) as ds:
+        o64 = ds.render(cam, par)
+        o32 = ds.render(cam, abi.copy_params(par, out_format=abi.OUT_F32))
+    assert o32.dtype == np.float32 and np.array_equal(o32, o64.astype(np.float32))
+
+
+# ---- the synthetic benchmark scenes against the oracle, at sizes the oracle finishes in seconds ------------
+def _synthetic(n_spheres, with_plane, wide, w, h):
+    from pytracer_amd import flatten, scenes
+
+    world = scenes.synthetic_world(n_spheres, with_plane=with_plane, wide=wide)
+    return flatten.flatten_world(world), flatten.flatten_camera(scenes.synthetic_camera(w, h))
+
+
+def test_c2_flat_320x180_bit_exact_vs_oracle(dev, oracle):
+    scene, cam = _synthetic(32, True, False, 320, 180)
+    par = abi.make_params(320, 180, abi.RENDERER_FLAT)
+    with dev.DeviceScene(scene) as ds:
+        out = ds.render(cam, par)
+    ora, _ = oracle.render(scene, cam, par, sqr_mode=oracle.SQR_MUL)
+    oracle.set_sqr_mode(oracle.SQR_POW)
+    assert util.bits_equal(out, ora)
+
+
+def test_c5_many_spheres_flat_vs_oracle(dev, oracle):
+    # 10 k spheres (config 5) at a reduced frame: 96x54 x 10 000 shapes = 52 M tests for the oracle
+    scene, cam = _synthetic(10000, False, True, 96, 54)
+    par = abi.make_params(96, 54, abi.RENDERER_FLAT)
+    with dev.DeviceScene(scene) as ds:
+        out = ds.render(cam, par)
+    ora, _ = oracle.render(scene, cam, par, sqr_mode=oracle.SQR_MUL)
+    oracle.set_sqr_mode(oracle.SQR_POW)
+    assert util.bits_equal(out, ora)
+
+
+@pytest.mark.parametrize("n_rays,depth,S,mode", [(1, 3, 4, abi.PCG_PIXEL), (2, 2, 2, abi.PCG_PIXEL),
+                                                 (1, 5, 2, abi.PCG_SAMPLE), (3, 3, 0, abi.PCG_PIXEL)])
+def test_c3_pathtracer_vs_oracle(dev, oracle, n_rays, depth, S, mode):
+    scene, cam = _synthetic(32, False, False, 160, 90)
+    par = abi.make_params(160, 90, abi.RENDERER_PATHTRACER, samples_per_side=S, num_of_rays=n_rays,
+                          max_depth=depth, rr_limit=3, pcg_mode=mode, path_state=45, path_seq=54)
+    with dev.DeviceScene(scene) as ds:
+        out = ds.render(cam, par)
+        st = ds.stats()
+    ora, n = oracle.render(scene, cam, par, sqr_mode=oracle.SQR_MUL)
+    oracle.set_sqr_mode(oracle.SQR_POW)
+    err = util.rel_err(out, ora)
+    bad = int((err > TOL).any(axis=-1).sum())
+    print(f"path N={n_rays} D={depth} S={S}: max rel {err.max():.3e}, outliers {bad}, rays {st.n_rays} vs {n}")
+    # sin/cos last-ulp differences can flip a silhouette/checker decision after a bounce: allow a
+    # handful of outlier pixels, never a systematic difference
+    assert bad <= 3
+    assert abs(int(st.n_rays) - n) <= 8
+
+
+def test_furnace(dev):
+    """test_all.py:1015-1051 on the device: closed diffuse sphere, N=1, D=100, rr_limit=101."""
+    g = util.load("g9_furnace")
+    eye = [1.0, 0, 0, 0, 0, 1.0, 0, 0, 0, 0, 1.0, 0]
+    cam = abi.make_camera(abi.CAMERA_PERSPECTIVE, eye, 1.0, 1.0)
+    for i, row in enumerate(g["rows"]):
+        scene = abi.FlatScene.from_dict(g, prefix=f"f{i}_scene_")
+        par = abi.make_params(8, 8, abi.RENDERER_PATHTRACER, num_of_rays=1, max_depth=100, rr_limit=101,
+                              path_state=7, path_seq=100 * i)
+        with dev.DeviceScene(scene) as ds:
+            out = ds.render(cam, par)
+            st = ds.stats()
+        assert st.n_rays == 64 * 101
+        assert np.allclose(out, row[5], rtol=1e-3)
+
+
+# ---- properties at full size (1280x720) -------------------------------------------------------------------------
+def test_full_size_partition_invariance_and_determinism(dev):
+    scene, cam = _synthetic(32, True, False, 1280, 720)
+    par = abi.make_params(1280, 720, abi.RENDERER_FLAT)
+    with dev.DeviceScene(scene) as ds:
+        full = ds.render(cam, par)
+        again = ds.render(cam, par)
+        assert util.bits_equal(full, again)
+        assert ds.stats().n_rays == 1280 * 720
+        for n_ranks, rb in ((2, 8), (8, 16), (3, 7)):
+            got = np.zeros_like(full)
+            for rank in range(n_ranks):
+                p = abi.copy_params(par, n_ranks=n_ranks, rank=rank, row_block=rb)
+                part = ds.render(cam, p)
+                rows = abi.rows_for_rank(720, rb, n_ranks, rank)
+                assert part.shape[0] == len(rows)
+                got[rows] = part
+            assert util.bits_equal(got, full)
+        # OnOff == "Flat hit something": the sky sphere encloses the camera, so every pixel is lit
+        onoff = ds.render(cam, abi.copy_params(par, renderer=abi.RENDERER_ONOFF))
+        assert np.all(onoff == 1.0)
+    assert math.isfinite(float(full.sum())) and float(full.min()) >= 0.0
+
+
+def test_full_size_pathtracer_partition_invariance(dev):
+    scene, cam = _synthetic(32, False, False, 1280, 720)
+    par = abi.make_params(1280, 720, abi.RENDERER_PATHTRACER, samples_per_side=2, num_of_rays=1, max_depth=3,
+                          rr_limit=3, path_state=45, path_seq=54)
+    with dev.DeviceScene(scene) as ds:
+        full = ds.render(cam, par)
+        n_full = ds.stats().n_rays
+        got = np.zeros_like(full)
+        n_parts = 0
+        for rank in range(4):
+            p = abi.copy_params(par, n_ranks=4, rank=rank, row_block=8)
+            got[abi.rows_for_rank(720, 8, 4, rank)] = ds.render(cam, p)
+            n_parts += ds.stats().n_rays
+    assert util.bits_equal(got, full), "per-pixel seeds must make the image independent of the partition"
+    assert n_parts == n_full
+
+
+# ---- error behaviour of the C-ABI ----------------------------------------------------------------------------------
+def test_errors(dev):
+    from pytracer_amd._lib import PtraceError
+
+    scene, cam = _synthetic(4, False, False, 16, 9)
+    with dev.DeviceScene(scene) as ds:
+        with pytest.raises(PtraceError) as e:
+            ds.render(cam, abi.make_params(16, 9, abi.RENDERER_PATHTRACER, pcg_mode=abi.PCG_SEQ))
+        assert e.value.code == -3
+        with pytest.raises(PtraceError):
+            ds.render(cam, abi.make_params(0, 9, abi.RENDERER_FLAT))
+        with pytest.raises(PtraceError):
+            ds.render(cam, abi.make_params(16, 9, abi.RENDERER_PATHTRACER, num_of_rays=0))
+        with pytest.raises(PtraceError):
+            ds.render(cam, abi.make_params(16, 9, 7))
+
+
+# ---- the Python drop-in surface ----------------------------------------------------------------------------------------
+def test_gpu_image_tracer_dropin(dev, oracle):
+    from pytracer_amd import flatten, hostmodel as hm, scenes
+    from pytracer_amd.tracer import GpuImageTracer
+
+    world, camera = scenes.demo_world()
+    image = hm.HdrImage(160, 120)
+    calls = []
+    tracer = GpuImageTracer(image, camera)
+    assert tracer.fire_all_rays(hm.OnOffRenderer(world), callback=lambda col, row, **kw: calls.append((col, row, kw)),
+                                tag=1) is None
+    assert calls[0] == (0, 0, {"tag": 1}) and len(calls) >= 1
+    gold = util.load("g5_demo_onoff_160x120")["pixels"]
+    assert util.bits_equal(image.array, gold)
+    assert image.get_pixel(3, 2).r == gold[2, 3, 0] and len(image.pixels) == 160 * 120
+    tracer.fire_all_rays(hm.FlatRenderer(world))
+    gold = util.load("g5_demo_flat_160x120")["pixels"]
+    assert util.rel_err(image.array, gold).max() <= TOL
+    # path tracer through the object interface == C-ABI with the same seeds
+    pt = hm.PathTracer(world, pcg=hm.PCG(45, 54), num_of_rays=2, max_depth=2)
+    small = hm.HdrImage(40, 30)
+    GpuImageTracer(small, camera).fire_all_rays(pt)
+    gold = util.load("g5_demo_path_40x30_n2d2_pixel")["pixels"]
+    assert util.rel_err(small.array, gold).max() <= TOL
+    with pytest.raises(flatten.UnsupportedSceneError):
+        GpuImageTracer(small, camera).fire_all_rays(lambda ray: hm.Color(1.0, 2.0, 3.0))
