@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Kernel micro-benchmark: times the render kernel alone (hipEvents inside the library) for the
+BASELINE.json configurations, several rounds in ONE process (cdna_hip_programming.md rule 24).
+
+    python tools/kbench.py [c2 c3 c5 c2onoff c3n10 ...] [--rounds 20]
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402,F401  (device memory for the output buffer)
+
+from pytracer_amd import abi, flatten, scenes  # noqa: E402
+from pytracer_amd.device import DeviceScene  # noqa: E402
+
+CONFIGS = {
+    # name: (n_spheres, plane, wide, W, H, params kwargs)
+    "c2": (32, True, False, 1280, 720, dict(renderer=abi.RENDERER_FLAT)),
+    "c2onoff": (32, True, False, 1280, 720, dict(renderer=abi.RENDERER_ONOFF)),
+    "c2s2": (32, True, False, 1280, 720, dict(renderer=abi.RENDERER_FLAT, samples_per_side=2)),
+    "c3": (32, False, False, 1280, 720, dict(renderer=abi.RENDERER_PATHTRACER, samples_per_side=4, num_of_rays=1,
+                                             max_depth=3, rr_limit=3, path_state=45, path_seq=54)),
+    "c3n10": (32, False, False, 1280, 720, dict(renderer=abi.RENDERER_PATHTRACER, samples_per_side=1, num_of_rays=10,
+                                                max_depth=3, rr_limit=3, path_state=45, path_seq=54)),
+    "c4crop": (256, False, True, 960, 540, dict(renderer=abi.RENDERER_PATHTRACER, samples_per_side=4, num_of_rays=1,
+                                                max_depth=5, rr_limit=3, path_state=45, path_seq=54)),
+    "c5": (10000, False, True, 1280, 720, dict(renderer=abi.RENDERER_FLAT)),
+    "c5small": (10000, False, True, 320, 180, dict(renderer=abi.RENDERER_FLAT)),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("names", nargs="*", default=["c2", "c3", "c5"])
+    ap.add_argument("--rounds", type=int, default=20)
+    ap.add_argument("--f64", action="store_true")
+    args = ap.parse_args()
+    for name in args.names:
+        ns, plane, wide, W, H, kw = CONFIGS[name]
+        flat = flatten.flatten_world(scenes.synthetic_world(ns, with_plane=plane, wide=wide))
+        cam = flatten.flatten_camera(scenes.synthetic_camera(W, H))
+        par = abi.make_params(W, H, out_format=abi.OUT_F64 if args.f64 else abi.OUT_F32, **kw)
+        ds = DeviceScene(flat)
+        out = torch.empty((H, W, 3), dtype=torch.float64 if args.f64 else torch.float32, device="cuda")
+        nbytes = out.numel() * out.element_size()
+        ms = []
+        rays = 0
+        for r in range(args.rounds + 2):
+            ds.render_into(cam, par, out.data_ptr(), nbytes, None)
+            st = ds.stats()
+            rays = st.n_rays
+            if r >= 2:
+                ms.append(st.kernel_ms)
+        ms = np.array(ms)
+        n_sph = int((flat.kind == 0).sum())
+        n_pl = int((flat.kind == 1).sum())
+        flop = rays * (n_sph * 54 + n_pl * 36)
+        t = float(np.median(ms)) * 1e-3
+        print(f"{name:8s} {W}x{H} shapes={flat.n_shapes:5d} rays={rays:9d}  kernel ms: min {ms.min():.4f} "
+              f"med {np.median(ms):.4f} max {ms.max():.4f} | {rays / t / 1e6:9.1f} Mray/s "
+              f"{rays * flat.n_shapes / t:.3e} tests/s {flop / t / 1e12:6.2f} TFLOP/s(alg) grid={st.grid}", flush=True)
+        ds.close()
+
+
+if __name__ == "__main__":
+    main()
