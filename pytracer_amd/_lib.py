@@ -6,7 +6,8 @@ import os
 
 from . import abi
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libptrace.so")
+# PTRACE_LIB lets kernel A/B experiments load an alternative build of the same C-ABI library
+_LIB_PATH = os.environ.get("PTRACE_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libptrace.so")
 _lib = None
 
 # every symbol include/ptrace.h declares

@@ -31,6 +31,12 @@
 #define PT_DEV static __device__ __forceinline__
 #define PT_PI 3.141592653589793
 #define PT_BLOCK 256
+#ifndef PT_WAVES_SIMPLE
+#define PT_WAVES_SIMPLE 4
+#endif
+#ifndef PT_WAVES_PATH
+#define PT_WAVES_PATH 3
+#endif
 
 // Uniform (wave-invariant) reads go through the constant address space so the backend emits
 // s_load_* (scalar cache -> SGPRs) instead of per-lane global loads.
@@ -38,6 +44,17 @@ typedef const __attribute__((address_space(4))) double *pt_kdouble;
 typedef const __attribute__((address_space(4))) int32_t *pt_kint;
 #define PT_KD(p) ((pt_kdouble)(const void *)(p))
 #define PT_KI(p) ((pt_kint)(const void *)(p))
+
+// Register budget: the argument block is ~90 dwords.  Only the fields the shape loop needs are read
+// as ordinary by-value kernel arguments (they stay in SGPRs); everything else is re-read from the
+// kernarg segment (scalar cache) at its point of use through a laundered pointer, so the compiler
+// cannot hoist those loads to the kernel entry and then spill them inside the hot loop.
+typedef const __attribute__((address_space(4))) PtKArgs *pt_kargs;
+PT_DEV pt_kargs cold_args() {
+  unsigned long long p = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+  return (pt_kargs)p;
+}
 
 struct V3 {
   double x, y, z;
@@ -108,21 +125,142 @@ PT_DEV double max2(double a, double b) { return (b > a) ? b : a; }  // Python ma
 
 // ---- the shape loop: World.ray_intersection (world.py:51-69) ---------------------------------------
 // Returns the record slot of the closest shape hit in (r.tmin, best_t) or -1; best_t is updated.
-// Records are grouped (spheres first, then planes) so each loop body is branch-free on the shape
-// kind; a tie in t between a plane and an earlier winner is resolved by the original list index,
-// which reproduces "first shape in list order wins" (world.py:62, strict <).
+//
+// Records are grouped [scale+translate spheres | other spheres | planes] so each loop body is
+// branch-free on the shape kind; a tie in t between a plane and an earlier winner is resolved by the
+// original list index, which reproduces "first shape in list order wins" (world.py:62, strict <).
 // ANYHIT: leave as soon as every active lane has some hit (OnOff, shadow rays) — the hit/miss
-// answer is identical, only `which` shape is unspecified.
+//   answer is identical, only `which` shape is unspecified.
 // HOIST: primary rays of a perspective camera share their origin, so invm*origin and c=|o'|^2-1
-// are per-shape constants (a.hoist), computed in the same operation order by pt_prep_hoist.
+//   are per-shape constants, computed in the same operation order by pt_prep_hoist.
+//
+// Scale+translate fast path: with invm = diag(s) | t the reference's full product is
+//   d'_x = (d.x*s0 + d.y*0) + d.z*0,   o'_x = ((o.x*s0 + o.y*0) + o.z*0) + t0.
+// Adding a signed zero changes a value only if that value is itself a zero, so the short forms
+// d.x*s0 and o.x*s0 + t0 are bit-identical unless a product is +-0 (or non-finite).  WaveGuard
+// proves per wave, per ray, that no lane can be in that case; otherwise the full product runs.
+struct WaveGuard {
+  bool fast;        // every active lane: 1e-100 <= |d.c| <= 1e100 (and |o.c| <= 1e100)
+  unsigned ozmask;  // bit c: some active lane has |o.c| < 1e-100 (its product may be a zero)
+};
+
+template <bool HOIST>
+PT_DEV WaveGuard wave_guard(const Ray &r, bool active) {
+  const double lo = 1e-100, hi = 1e100;
+  const double ax = fabs(r.d.x), ay = fabs(r.d.y), az = fabs(r.d.z);
+  bool bad = !(ax >= lo && ax <= hi && ay >= lo && ay <= hi && az >= lo && az <= hi);
+  WaveGuard g;
+  g.ozmask = 0;
+  if (!HOIST) {
+    const double px = fabs(r.o.x), py = fabs(r.o.y), pz = fabs(r.o.z);
+    bad = bad || !(px <= hi && py <= hi && pz <= hi);
+    g.ozmask = (__ballot(active && px < lo) ? 1u : 0u) | (__ballot(active && py < lo) ? 2u : 0u) |
+               (__ballot(active && pz < lo) ? 4u : 0u);
+  }
+  g.fast = __ballot(active && bad) == 0ULL;
+  return g;
+}
+
+// shapes.py:103-121 given the object-space ray; updates (best_t, best) for the lanes that hit
+#define PT_SPHERE_ROOTS(SLOT)                                                     \
+  do {                                                                            \
+    const double bb = 2.0 * (ox * dx + oy * dy + oz * dz);                        \
+    const double delta = bb * bb - 4.0 * aa * cc;                                 \
+    if (active && delta > 0.0) {                                                  \
+      /* first root inside (tmin, tmax); the roots are ordered (a > 0), so the */ \
+      /* running best_t as upper limit selects the same winner as world.py:62 */  \
+      const double sd = sqrt(delta);                                              \
+      const double den = 2.0 * aa;                                                \
+      double t = (-bb - sd) / den;                                                \
+      bool ok = (t > tmin) && (t < best_t);                                       \
+      if (!ok) {                                                                  \
+        t = (-bb + sd) / den;                                                     \
+        ok = (t > tmin) && (t < best_t);                                          \
+      }                                                                           \
+      if (ok) {                                                                   \
+        best_t = t;                                                               \
+        best = (SLOT);                                                            \
+      }                                                                           \
+    }                                                                             \
+    if (ANYHIT) {                                                                 \
+      if (__ballot(active && best < 0) == 0ULL) return best;                      \
+    }                                                                             \
+  } while (0)
+
 template <bool ANYHIT, bool HOIST>
 PT_DEV int world_query(const PtKArgs &a, const Ray &r, double &best_t, bool active) {
   int best = -1;
   const double tmin = r.tmin;
+  const int nd = a.n_diag;
   const int ns = a.n_spheres;
   const int n = a.n_shapes;
-  // ---- spheres: shapes.py:102-121 (54 flop generic, 30 hoisted, + sqrt and 1-2 div on a hit) ----
-  for (int i = 0; i < ns; ++i) {
+  int first_general = 0;
+
+  // ---- scale+translate spheres: 30 flop per test (18 hoisted) instead of 54 (30) ----
+  if (nd > 0) {
+    const WaveGuard g = wave_guard<HOIST>(r, active);
+    if (g.fast) {
+      first_general = nd;
+      if (HOIST) {
+        // software pipeline: the record of shape i+1 is requested (s_load) before shape i is evaluated
+        pt_kdouble base = PT_KD(a.hoist_diag);
+        double n0 = base[0], n1 = base[1], n2 = base[2], n3 = base[3], n4 = base[4], n5 = base[5], n6 = base[6];
+        for (int i = 0; i < nd; ++i) {
+          const double s0 = n0, s1 = n1, s2 = n2, ox = n3, oy = n4, oz = n5, cc = n6;
+          pt_kdouble h = base + (size_t)((i + 1 < nd) ? i + 1 : i) * 8;
+          n0 = h[0];
+          n1 = h[1];
+          n2 = h[2];
+          n3 = h[3];
+          n4 = h[4];
+          n5 = h[5];
+          n6 = h[6];
+          const double dx = r.d.x * s0, dy = r.d.y * s1, dz = r.d.z * s2;
+          const double aa = dx * dx + dy * dy + dz * dz;
+          PT_SPHERE_ROOTS(i);
+        }
+      } else {
+        pt_kdouble base = PT_KD(a.diag);
+        double n0 = base[0], n1 = base[1], n2 = base[2], n3 = base[3], n4 = base[4], n5 = base[5];
+        int ntnz = *PT_KI(&a.diag[0].tnz);
+        for (int i = 0; i < nd; ++i) {
+          const double s0 = n0, s1 = n1, s2 = n2, t0 = n3, t1 = n4, t2 = n5;
+          const int tnz = ntnz;
+          const int nx = (i + 1 < nd) ? i + 1 : i;
+          pt_kdouble h = base + (size_t)nx * 8;
+          n0 = h[0];
+          n1 = h[1];
+          n2 = h[2];
+          n3 = h[3];
+          n4 = h[4];
+          n5 = h[5];
+          ntnz = *PT_KI(&a.diag[nx].tnz);
+          double dx, dy, dz, ox, oy, oz;
+          if ((g.ozmask & ~(unsigned)tnz) == 0u) {
+            dx = r.d.x * s0;
+            dy = r.d.y * s1;
+            dz = r.d.z * s2;
+            ox = r.o.x * s0 + t0;
+            oy = r.o.y * s1 + t1;
+            oz = r.o.z * s2 + t2;
+          } else {  // a zero product could meet a zero translation: full product for this shape
+            pt_kdouble m = PT_KD(a.recs[i].invm);
+            dx = r.d.x * m[0] + r.d.y * m[1] + r.d.z * m[2];
+            dy = r.d.x * m[4] + r.d.y * m[5] + r.d.z * m[6];
+            dz = r.d.x * m[8] + r.d.y * m[9] + r.d.z * m[10];
+            ox = r.o.x * m[0] + r.o.y * m[1] + r.o.z * m[2] + m[3];
+            oy = r.o.x * m[4] + r.o.y * m[5] + r.o.z * m[6] + m[7];
+            oz = r.o.x * m[8] + r.o.y * m[9] + r.o.z * m[10] + m[11];
+          }
+          const double aa = dx * dx + dy * dy + dz * dz;
+          const double cc = (ox * ox + oy * oy + oz * oz) - 1.0;
+          PT_SPHERE_ROOTS(i);
+        }
+      }
+    }
+  }
+  // ---- spheres, full 3x4 product: shapes.py:102-121 (54 flop generic, 30 hoisted) ----
+  for (int i = first_general; i < ns; ++i) {
     pt_kdouble m = PT_KD(a.recs[i].invm);
     const double dx = r.d.x * m[0] + r.d.y * m[1] + r.d.z * m[2];
     const double dy = r.d.x * m[4] + r.d.y * m[5] + r.d.z * m[6];
@@ -141,27 +279,7 @@ PT_DEV int world_query(const PtKArgs &a, const Ray &r, double &best_t, bool acti
       oz = r.o.x * m[8] + r.o.y * m[9] + r.o.z * m[10] + m[11];
       cc = (ox * ox + oy * oy + oz * oz) - 1.0;
     }
-    const double bb = 2.0 * (ox * dx + oy * dy + oz * dz);
-    const double delta = bb * bb - 4.0 * aa * cc;
-    if (active && delta > 0.0) {
-      // first root inside (tmin, tmax); the roots are ordered (a > 0), so using the running
-      // best_t as the upper limit selects the same winner as world.py:62
-      const double sd = sqrt(delta);
-      const double den = 2.0 * aa;
-      double t = (-bb - sd) / den;
-      bool ok = (t > tmin) && (t < best_t);
-      if (!ok) {
-        t = (-bb + sd) / den;
-        ok = (t > tmin) && (t < best_t);
-      }
-      if (ok) {
-        best_t = t;
-        best = i;
-      }
-    }
-    if (ANYHIT) {
-      if (__ballot(active && best < 0) == 0ULL) return best;
-    }
+    PT_SPHERE_ROOTS(i);
   }
   // ---- planes: shapes.py:168-175, only the z row of the object-space ray decides ----
   for (int i = ns; i < n; ++i) {
@@ -199,7 +317,7 @@ PT_DEV int world_query(const PtKArgs &a, const Ray &r, double &best_t, bool acti
 // it equals what the reference computed for that candidate.
 PT_DEV void hit_details(const PtKArgs &a, const Ray &r, double t, int i, Hit &h, bool need_uv) {
   const PtShapeRec *rec = a.recs + i;
-  const PtShapeAux *ax = a.aux + i;  // same (grouped) slot order as recs
+  const PtShapeAux *ax = cold_args()->aux + i;  // same (grouped) slot order as recs
   double im[12];
 #pragma unroll
   for (int k = 0; k < 12; ++k) im[k] = rec->invm[k];
@@ -247,12 +365,14 @@ PT_DEV V3 pigment_color(const PtKArgs &a, int kind, const double *c1, const doub
     // Python's % 2 is non-negative; (x & 1) is the same parity for negative x in two's complement
     c = ((iu & 1LL) == (iv & 1LL)) ? c1 : c2;
   } else if (kind == PT_PIGMENT_IMAGE) {
-    const int w = a.tex[tex].w, hh = a.tex[tex].h;
+    pt_kargs ca = cold_args();
+    const PtTex *tx = ca->tex + tex;
+    const int w = tx->w, hh = tx->h;
     long long col = (long long)(u * (double)w);  // int() truncates toward zero
     long long row = (long long)(v * (double)hh);
     if (col >= w) col = w - 1;
     if (row >= hh) row = hh - 1;
-    c = a.tex_data + a.tex[tex].offset + (row * w + col) * 3;
+    c = ca->tex_data + tx->offset + (row * w + col) * 3;
   }
   V3 r = {c[0], c[1], c[2]};
   return r;
@@ -295,64 +415,92 @@ PT_DEV Ray scatter_ray(int brdf_kind, Pcg &pcg, V3 incoming, V3 point, V3 n) {
 }
 
 // ---- ImageTracer.fire_ray + Camera.fire_ray (imagetracer.py:48-58; camera.py:59-78, 103-124) -----
-PT_DEV Ray primary_ray(const PtKArgs &a, int col, int row, double up, double vp) {
-  const double u = ((double)col + up) / (double)a.W;
-  const double v = 1.0 - ((double)row + vp) / (double)a.H;
+PT_DEV Ray primary_ray(int col, int row, double up, double vp) {
+  pt_kargs c = cold_args();
+  const double u = ((double)col + up) / (double)c->W;
+  const double v = 1.0 - ((double)row + vp) / (double)c->H;
   V3 o, d;
-  if (a.cam_kind == PT_CAMERA_PERSPECTIVE) {
-    o.x = -a.cam_dist;
+  const double dist = c->cam_dist, aspect = c->cam_aspect;
+  if (c->cam_kind == PT_CAMERA_PERSPECTIVE) {
+    o.x = -dist;
     o.y = 0.0;
     o.z = 0.0;
-    d.x = a.cam_dist;
-    d.y = (1.0 - 2.0 * u) * a.cam_aspect;
+    d.x = dist;
+    d.y = (1.0 - 2.0 * u) * aspect;
     d.z = 2.0 * v - 1.0;
   } else {
     o.x = -1.0;
-    o.y = (1.0 - 2.0 * u) * a.cam_aspect;
+    o.y = (1.0 - 2.0 * u) * aspect;
     o.z = 2.0 * v - 1.0;
     d.x = 1.0;
     d.y = 0.0;
     d.z = 0.0;
   }
   Ray r;
-  r.o = xf_point(a.cam_m, o);
-  r.d = xf_vec(a.cam_m, d);
+  r.o = xf_point(c->cam_m, o);
+  r.d = xf_vec(c->cam_m, d);
   r.tmin = 1.0e-5;
   return r;
 }
 
 // local (rank-compact) pixel index -> column and GLOBAL row (pt_params partition)
-PT_DEV void pixel_coords(const PtKArgs &a, long long pix, int &col, int &grow) {
-  const int lr = (int)(pix / a.W);
-  col = (int)(pix - (long long)lr * a.W);
-  const int blk = lr / a.row_block;
-  grow = (blk * a.n_ranks + a.rank) * a.row_block + (lr - blk * a.row_block);
+PT_DEV void pixel_coords(long long pix, int &col, int &grow) {
+  pt_kargs c = cold_args();
+  const int W = c->W, rb = c->row_block;
+  const int lr = (int)(pix / W);
+  col = (int)(pix - (long long)lr * W);
+  const int blk = lr / rb;
+  grow = (blk * c->n_ranks + c->rank) * rb + (lr - blk * rb);
 }
 
-PT_DEV void store_pixel(const PtKArgs &a, long long pix, V3 c) {
-  if (a.out_f32) {
-    float *o = (float *)a.out + pix * 3;
-    o[0] = (float)c.x;
-    o[1] = (float)c.y;
-    o[2] = (float)c.z;
+PT_DEV void store_pixel(long long pix, V3 v) {
+  pt_kargs c = cold_args();
+  if (c->out_f32) {
+    float *o = (float *)c->out + pix * 3;
+    o[0] = (float)v.x;
+    o[1] = (float)v.y;
+    o[2] = (float)v.z;
   } else {
-    double *o = (double *)a.out + pix * 3;
-    o[0] = c.x;
-    o[1] = c.y;
-    o[2] = c.z;
+    double *o = (double *)c->out + pix * 3;
+    o[0] = v.x;
+    o[1] = v.y;
+    o[2] = v.z;
   }
 }
 
-PT_DEV void add_ray_count(const PtKArgs &a, unsigned long long n) {
-  if (a.ray_counter) {
-    // wave reduction, then one atomic per wave
+// Ray accounting without a contended atomic: wave reduction -> LDS -> one plain store per workgroup
+// into a.ray_counter[blockIdx.x]; pt_sum_counts folds the per-workgroup partials afterwards.
+PT_DEV void add_ray_count(unsigned long long n) {
+  unsigned long long *counter = cold_args()->ray_counter;
+  if (counter) {
+    __shared__ unsigned long long partial[PT_BLOCK / 64];
     for (int off = 32; off > 0; off >>= 1) n += __shfl_down(n, off, 64);
-    if ((threadIdx.x & 63) == 0) atomicAdd(a.ray_counter, n);
+    if ((threadIdx.x & 63) == 0) partial[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned long long t = 0;
+      for (int w = 0; w < PT_BLOCK / 64; ++w) t += partial[w];
+      counter[blockIdx.x] = t;
+    }
   }
+}
+
+__global__ void pt_sum_counts(const unsigned long long *partials, int n, unsigned long long *total) {
+  __shared__ unsigned long long acc[256];
+  unsigned long long t = 0;
+  for (int i = threadIdx.x; i < n; i += 256) t += partials[i];
+  acc[threadIdx.x] = t;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) acc[threadIdx.x] += acc[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total = acc[0];
 }
 
 // ---- pt_prep_hoist: per-shape constants of the primary rays (perspective camera) ----------------------
-__global__ void pt_prep_hoist(const PtShapeRec *recs, PtHoist *hoist, int n, V3 origin) {
+__global__ void pt_prep_hoist(const PtShapeRec *recs, PtHoist *hoist, PtHoistDiag *hoist_diag, int n,
+                              int n_diag, V3 origin) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const V3 o = xf_point(recs[i].invm, origin);
@@ -362,46 +510,69 @@ __global__ void pt_prep_hoist(const PtShapeRec *recs, PtHoist *hoist, int n, V3 
   h.oz = o.z;
   h.c = (o.x * o.x + o.y * o.y + o.z * o.z) - 1.0;
   hoist[i] = h;
+  if (i < n_diag) {
+    PtHoistDiag d;
+    d.s[0] = recs[i].invm[0];
+    d.s[1] = recs[i].invm[5];
+    d.s[2] = recs[i].invm[10];
+    d.o[0] = o.x;
+    d.o[1] = o.y;
+    d.o[2] = o.z;
+    d.c = h.c;
+    d._pad = 0.0;
+    hoist_diag[i] = d;
+  }
 }
 
 // ---- OnOff / Flat / PointLight: one world query per sample (+ shadow rays) ----------------------------
 template <int RENDERER, bool HOIST>
-__global__ __launch_bounds__(PT_BLOCK) void pt_simple_kernel(const PtKArgs a) {
-  const int S = a.S;
+__global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAVES_SIMPLE, 8))) void pt_simple_kernel(const PtKArgs a) {
+  const int S = cold_args()->S;
   const int nsamp = S > 0 ? S * S : 1;
-  const V3 bg = {a.bg[0], a.bg[1], a.bg[2]};
   unsigned long long nrays = 0;
   for (long long base = (long long)blockIdx.x * PT_BLOCK; base < a.npix; base += a.nthreads) {
     const long long pix = base + threadIdx.x;
     const bool active = pix < a.npix;
     int col = 0, grow = 0;
-    if (active) pixel_coords(a, pix, col, grow);
-    const unsigned long long gpix = (unsigned long long)grow * a.W + col;
+    if (active) pixel_coords(pix, col, grow);
     Pcg pcg;
-    if (S > 0 && a.pcg_mode == PT_PCG_PIXEL) pcg_seed(pcg, a.s0, a.q0 + gpix);
+    unsigned long long gpix = 0;
+    if (S > 0) {
+      pt_kargs c = cold_args();
+      gpix = (unsigned long long)grow * c->W + col;
+      if (c->pcg_mode == PT_PCG_PIXEL) pcg_seed(pcg, c->s0, c->q0 + gpix);
+    }
     V3 cum = {0.0, 0.0, 0.0};
     for (int s = 0; s < nsamp; ++s) {
       double up = 0.5, vp = 0.5;
       if (S > 0) {  // imagetracer.py:86-93: u drawn first, then v; sub_row outer, sub_col inner
-        if (a.pcg_mode == PT_PCG_SAMPLE) pcg_seed(pcg, a.s0, a.q0 + gpix * (unsigned)nsamp + (unsigned)s);
+        pt_kargs c = cold_args();
+        if (c->pcg_mode == PT_PCG_SAMPLE) pcg_seed(pcg, c->s0, c->q0 + gpix * (unsigned)nsamp + (unsigned)s);
         const int sr = s / S, sc = s - sr * S;
         up = ((double)sc + pcg_float(pcg)) / (double)S;
         vp = ((double)sr + pcg_float(pcg)) / (double)S;
       }
-      const Ray ray = primary_ray(a, col, grow, up, vp);
+      const Ray ray = primary_ray(col, grow, up, vp);
       double best_t = INFINITY;
       const int hit = world_query<RENDERER == PT_RENDERER_ONOFF, HOIST>(a, ray, best_t, active);
       if (active) nrays++;
-      V3 c = bg;
+      V3 c;
+      {
+        pt_kargs ca = cold_args();
+        c.x = ca->bg[0];
+        c.y = ca->bg[1];
+        c.z = ca->bg[2];
+      }
       if (RENDERER == PT_RENDERER_ONOFF) {  // render.py:52-53
         if (hit >= 0) {
-          c.x = a.onoff[0];
-          c.y = a.onoff[1];
-          c.z = a.onoff[2];
+          pt_kargs ca = cold_args();
+          c.x = ca->onoff[0];
+          c.y = ca->onoff[1];
+          c.z = ca->onoff[2];
         }
       } else if (RENDERER == PT_RENDERER_FLAT) {  // render.py:65-74
         if (hit >= 0) {
-          const PtShapeAux *ax = a.aux + hit;
+          const PtShapeAux *ax = cold_args()->aux + hit;
           Hit h;
           h.u = 0.0;
           h.v = 0.0;
@@ -416,17 +587,24 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_simple_kernel(const PtKArgs a) {
       } else {  // PointLight, render.py:157-193
         const bool lit = active && hit >= 0;
         Hit h;
-        const PtShapeAux *ax = a.aux + (hit >= 0 ? hit : 0);
-        V3 res = bg;
+        h.wp = {0.0, 0.0, 0.0};
+        h.n = {0.0, 0.0, 1.0};
+        h.u = 0.0;
+        h.v = 0.0;
+        pt_kargs ca = cold_args();
+        const PtShapeAux *ax = ca->aux + (hit >= 0 ? hit : 0);
+        V3 res = c;
         if (lit) {
           hit_details(a, ray, best_t, hit, h, ax->needs_uv != 0);
           const V3 em = emitted_pigment(a, ax, h.u, h.v);
-          res.x = a.ambient[0] + em.x;
-          res.y = a.ambient[1] + em.y;
-          res.z = a.ambient[2] + em.z;
+          res.x = ca->ambient[0] + em.x;
+          res.y = ca->ambient[1] + em.y;
+          res.z = ca->ambient[2] + em.z;
         }
-        for (int l = 0; l < a.n_lights; ++l) {
-          pt_kdouble L = PT_KD(&a.lights[l]);
+        const int n_lights = ca->n_lights;
+        const PtLight *lights = ca->lights;
+        for (int l = 0; l < n_lights; ++l) {
+          pt_kdouble L = PT_KD(&lights[l]);
           const V3 lp = {L[0], L[1], L[2]};
           // world.py:71-80: shadow ray from the hit point towards the light, any-hit in (1e-2/|d|, 1)
           Ray sh;
@@ -483,30 +661,64 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_simple_kernel(const PtKArgs a) {
       cum.y = cum.y * k;
       cum.z = cum.z * k;
     }
-    if (active) store_pixel(a, pix, cum);
+    if (active) store_pixel(pix, cum);
   }
-  add_ray_count(a, nrays);
+  add_ray_count(nrays);
 }
 
 // ---- PathTracer (render.py:99-139) as a per-lane state machine ----------------------------------------
 // The reference recursion is depth-first; frame `k` of the explicit stack is the call at depth k.
-// Frame fields (in a.ws, [slot][field][thread] so a wave's accesses are contiguous):
+// Frame fields (in ws, [slot][field][thread] so a wave's accesses are contiguous):
 //   0..2 hit_color (after Russian roulette)   3..5 emitted
 //   N > 1 only: 6..8 cum_radiance, 9 children done, 10..12 hit point, 13..15 normal,
 //               16..18 incoming direction, 19 brdf kind
-PT_DEV double &ws_at(const PtKArgs &a, int slot, int field, int gtid) {
-  return a.ws[((size_t)slot * a.frame_doubles + field) * (size_t)a.nthreads + gtid];
+// Pixels are handed out dynamically (one wave-aggregated atomic per refill): a lane that finishes
+// a cheap pixel (sky) immediately takes the next one, so a few expensive pixels (deep recursion,
+// num_of_rays > 1) do not hold 63 idle lanes hostage.  Per-pixel seeds make the image independent
+// of which lane renders which pixel.
+struct PathCtx {
+  double *ws;
+  size_t stride;  // frame_doubles * nthreads
+  size_t nthreads;
+  int gtid;
+};
+PT_DEV double &ws_at(const PathCtx &w, int slot, int field) {
+  return w.ws[(size_t)slot * w.stride + (size_t)field * w.nthreads + w.gtid];
 }
 
-__global__ __launch_bounds__(PT_BLOCK) void pt_path_kernel(const PtKArgs a) {
-  const int gtid = blockIdx.x * PT_BLOCK + threadIdx.x;
-  const int S = a.S;
-  const int nsamp = S > 0 ? S * S : 1;
-  const int N = a.N;
+// next pixel for every lane with `need` set; returns -1 when the frame is exhausted
+PT_DEV long long next_pixel(bool need, long long npix) {
+  const unsigned long long mask = __ballot(need);
+  long long pix = -1;
+  if (need) {
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)mask) - 1;
+    const int rank = __popcll(mask & ((1ULL << lane) - 1ULL));
+    unsigned long long base = 0;
+    if (lane == leader) base = atomicAdd(cold_args()->queue, (unsigned long long)__popcll(mask));
+    base = __shfl(base, leader, 64);
+    const long long p = (long long)(base + rank);
+    pix = p < npix ? p : -1;
+  }
+  return pix;
+}
+
+__global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAVES_PATH, 8))) void pt_path_kernel(const PtKArgs a) {
+  PathCtx w;
+  int S, nsamp, N;
+  {
+    pt_kargs c = cold_args();
+    w.ws = c->ws;
+    w.nthreads = (size_t)c->nthreads;
+    w.stride = (size_t)c->frame_doubles * w.nthreads;
+    w.gtid = blockIdx.x * PT_BLOCK + threadIdx.x;
+    S = c->S;
+    N = c->N;
+  }
+  nsamp = S > 0 ? S * S : 1;
   const double invN = 1.0 / (double)N;
-  const V3 bg = {a.bg[0], a.bg[1], a.bg[2]};
-  long long pix = gtid;
-  bool alive = pix < a.npix;
+  long long pix = next_pixel(true, a.npix);
+  bool alive = pix >= 0;
   unsigned long long nrays = 0;
 
   Pcg pcg;
@@ -518,51 +730,55 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_path_kernel(const PtKArgs a) {
   ray.o = {0.0, 0.0, 0.0};
   ray.d = {1.0, 0.0, 0.0};
   ray.tmin = 1e-5;
-  bool skip_query = false;  // max_depth < 0: the primary call returns black without a query
 
   // (re)start: pixel coordinates + seeds + the sample's primary ray
   auto start_sample = [&]() {
+    pt_kargs c = cold_args();
     if (samp == 0) {
-      pixel_coords(a, pix, col, grow);
-      if (a.pcg_mode == PT_PCG_PIXEL)
-        pcg_seed(pcg, a.s0, a.q0 + ((unsigned long long)grow * a.W + col));
+      pixel_coords(pix, col, grow);
+      if (c->pcg_mode == PT_PCG_PIXEL) pcg_seed(pcg, c->s0, c->q0 + ((unsigned long long)grow * c->W + col));
     }
-    if (a.pcg_mode == PT_PCG_SAMPLE)
-      pcg_seed(pcg, a.s0, a.q0 + ((unsigned long long)grow * a.W + col) * (unsigned)nsamp + (unsigned)samp);
+    if (c->pcg_mode == PT_PCG_SAMPLE)
+      pcg_seed(pcg, c->s0, c->q0 + ((unsigned long long)grow * c->W + col) * (unsigned)nsamp + (unsigned)samp);
     double up = 0.5, vp = 0.5;
     if (S > 0) {
       const int sr = samp / S, sc = samp - sr * S;
       up = ((double)sc + pcg_float(pcg)) / (double)S;
       vp = ((double)sr + pcg_float(pcg)) / (double)S;
     }
-    ray = primary_ray(a, col, grow, up, vp);
-    skip_query = a.D < 0;
+    ray = primary_ray(col, grow, up, vp);
   };
   if (alive) start_sample();
 
-  while (alive) {
+  while (__any(alive)) {
     V3 ret = {0.0, 0.0, 0.0};
     bool spawn = false;
     // registers describing the frame just pushed (child 0 is spawned from them)
     V3 f_wp = {0.0, 0.0, 0.0}, f_n = {0.0, 0.0, 1.0}, f_in = ray.d;
     int f_brdf = 0;
+    bool need_pixel = false;
 
-    if (!skip_query) {
-      // ---- the convergent hot loop: one world query for this lane's current ray (depth = sp) ----
-      double best_t = INFINITY;
-      const int hit = world_query<false, false>(a, ray, best_t, true);
+    // ---- the convergent hot loop: one world query for this lane's current ray (depth = sp) ----
+    // (max_depth < 0 never reaches the device: the frame is black, the host clears it)
+    const bool query = alive;
+    double best_t = INFINITY;
+    const int hit = world_query<false, false>(a, ray, best_t, query);
+    if (query) {
       nrays++;
-      if (hit < 0) {
-        ret = bg;  // render.py:103-105
+      if (hit < 0) {  // render.py:103-105
+        pt_kargs c = cold_args();
+        ret.x = c->bg[0];
+        ret.y = c->bg[1];
+        ret.z = c->bg[2];
       } else {
-        const PtShapeAux *ax = a.aux + hit;
+        const PtShapeAux *ax = cold_args()->aux + hit;
         Hit h;
         hit_details(a, ray, best_t, hit, h, ax->needs_uv != 0);
         V3 hc = brdf_pigment(a, ax, h.u, h.v);
         const V3 em = emitted_pigment(a, ax, h.u, h.v);
         const double lum = max2(max2(hc.x, hc.y), hc.z);
         bool go_on = true;
-        if (sp >= a.rr) {  // render.py:116-123
+        if (sp >= cold_args()->rr) {  // render.py:116-123
           const double q = max2(0.05, 1.0 - lum);
           if (pcg_float(pcg) > q) {
             const double k = 1.0 / (1.0 - q);
@@ -576,27 +792,27 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_path_kernel(const PtKArgs a) {
         }
         if (go_on) {
           if (lum > 0.0) {  // render.py:126-137: push the frame, spawn child 0
-            ws_at(a, sp, 0, gtid) = hc.x;
-            ws_at(a, sp, 1, gtid) = hc.y;
-            ws_at(a, sp, 2, gtid) = hc.z;
-            ws_at(a, sp, 3, gtid) = em.x;
-            ws_at(a, sp, 4, gtid) = em.y;
-            ws_at(a, sp, 5, gtid) = em.z;
+            ws_at(w, sp, 0) = hc.x;
+            ws_at(w, sp, 1) = hc.y;
+            ws_at(w, sp, 2) = hc.z;
+            ws_at(w, sp, 3) = em.x;
+            ws_at(w, sp, 4) = em.y;
+            ws_at(w, sp, 5) = em.z;
             if (N > 1) {
-              ws_at(a, sp, 6, gtid) = 0.0;
-              ws_at(a, sp, 7, gtid) = 0.0;
-              ws_at(a, sp, 8, gtid) = 0.0;
-              ws_at(a, sp, 9, gtid) = 0.0;
-              ws_at(a, sp, 10, gtid) = h.wp.x;
-              ws_at(a, sp, 11, gtid) = h.wp.y;
-              ws_at(a, sp, 12, gtid) = h.wp.z;
-              ws_at(a, sp, 13, gtid) = h.n.x;
-              ws_at(a, sp, 14, gtid) = h.n.y;
-              ws_at(a, sp, 15, gtid) = h.n.z;
-              ws_at(a, sp, 16, gtid) = ray.d.x;
-              ws_at(a, sp, 17, gtid) = ray.d.y;
-              ws_at(a, sp, 18, gtid) = ray.d.z;
-              ws_at(a, sp, 19, gtid) = (double)ax->brdf_kind;
+              ws_at(w, sp, 6) = 0.0;
+              ws_at(w, sp, 7) = 0.0;
+              ws_at(w, sp, 8) = 0.0;
+              ws_at(w, sp, 9) = 0.0;
+              ws_at(w, sp, 10) = h.wp.x;
+              ws_at(w, sp, 11) = h.wp.y;
+              ws_at(w, sp, 12) = h.wp.z;
+              ws_at(w, sp, 13) = h.n.x;
+              ws_at(w, sp, 14) = h.n.y;
+              ws_at(w, sp, 15) = h.n.z;
+              ws_at(w, sp, 16) = ray.d.x;
+              ws_at(w, sp, 17) = ray.d.y;
+              ws_at(w, sp, 18) = ray.d.z;
+              ws_at(w, sp, 19) = (double)ax->brdf_kind;
             }
             f_wp = h.wp;
             f_n = h.n;
@@ -612,15 +828,15 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_path_kernel(const PtKArgs a) {
         }
       }
     }
-    skip_query = false;
 
     // ---- unwind: deliver `ret` up the stack / spawn the next child, until a ray needs a query ----
-    for (;;) {
+    bool unwinding = alive;
+    while (unwinding) {
       if (spawn) {
         // scatter_ray consumes its draws even when the child is beyond max_depth
         ray = scatter_ray(f_brdf, pcg, f_in, f_wp, f_n);
         spawn = false;
-        if (sp > a.D) {  // render.py:100-101: the child returns black without a world query
+        if (sp > cold_args()->D) {  // render.py:100-101: the child returns black without a world query
           ret.x = 0.0;
           ret.y = 0.0;
           ret.z = 0.0;
@@ -643,62 +859,62 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_path_kernel(const PtKArgs a) {
             cum.y = cum.y * k;
             cum.z = cum.z * k;
           }
-          store_pixel(a, pix, cum);
+          store_pixel(pix, cum);
           cum.x = 0.0;
           cum.y = 0.0;
           cum.z = 0.0;
           samp = 0;
-          pix += a.nthreads;
-          if (pix >= a.npix) {
-            alive = false;
-            break;
-          }
+          need_pixel = true;  // refilled below, wave-aggregated
+          break;
         }
         start_sample();
-        if (skip_query) {
-          skip_query = false;
-          ret.x = 0.0;
-          ret.y = 0.0;
-          ret.z = 0.0;
-          continue;
-        }
         break;
       }
       // a child of frame sp-1 returned `ret` (render.py:135-137)
       const int fs = sp - 1;
-      const V3 hc = {ws_at(a, fs, 0, gtid), ws_at(a, fs, 1, gtid), ws_at(a, fs, 2, gtid)};
+      const V3 hc = {ws_at(w, fs, 0), ws_at(w, fs, 1), ws_at(w, fs, 2)};
       V3 fc = {0.0, 0.0, 0.0};
       int done = 0;
       if (N > 1) {
-        fc.x = ws_at(a, fs, 6, gtid);
-        fc.y = ws_at(a, fs, 7, gtid);
-        fc.z = ws_at(a, fs, 8, gtid);
-        done = (int)ws_at(a, fs, 9, gtid);
+        fc.x = ws_at(w, fs, 6);
+        fc.y = ws_at(w, fs, 7);
+        fc.z = ws_at(w, fs, 8);
+        done = (int)ws_at(w, fs, 9);
       }
       fc.x = fc.x + hc.x * ret.x;
       fc.y = fc.y + hc.y * ret.y;
       fc.z = fc.z + hc.z * ret.z;
       done++;
       if (done < N) {
-        ws_at(a, fs, 6, gtid) = fc.x;
-        ws_at(a, fs, 7, gtid) = fc.y;
-        ws_at(a, fs, 8, gtid) = fc.z;
-        ws_at(a, fs, 9, gtid) = (double)done;
-        f_wp = {ws_at(a, fs, 10, gtid), ws_at(a, fs, 11, gtid), ws_at(a, fs, 12, gtid)};
-        f_n = {ws_at(a, fs, 13, gtid), ws_at(a, fs, 14, gtid), ws_at(a, fs, 15, gtid)};
-        f_in = {ws_at(a, fs, 16, gtid), ws_at(a, fs, 17, gtid), ws_at(a, fs, 18, gtid)};
-        f_brdf = (int)ws_at(a, fs, 19, gtid);
+        ws_at(w, fs, 6) = fc.x;
+        ws_at(w, fs, 7) = fc.y;
+        ws_at(w, fs, 8) = fc.z;
+        ws_at(w, fs, 9) = (double)done;
+        f_wp = {ws_at(w, fs, 10), ws_at(w, fs, 11), ws_at(w, fs, 12)};
+        f_n = {ws_at(w, fs, 13), ws_at(w, fs, 14), ws_at(w, fs, 15)};
+        f_in = {ws_at(w, fs, 16), ws_at(w, fs, 17), ws_at(w, fs, 18)};
+        f_brdf = (int)ws_at(w, fs, 19);
         spawn = true;
         continue;
       }
       // render.py:139
-      ret.x = ws_at(a, fs, 3, gtid) + fc.x * invN;
-      ret.y = ws_at(a, fs, 4, gtid) + fc.y * invN;
-      ret.z = ws_at(a, fs, 5, gtid) + fc.z * invN;
+      ret.x = ws_at(w, fs, 3) + fc.x * invN;
+      ret.y = ws_at(w, fs, 4) + fc.y * invN;
+      ret.z = ws_at(w, fs, 5) + fc.z * invN;
       sp = fs;
     }
+
+    // ---- refill: lanes whose pixel is complete take the next one from the queue ----
+    if (__any(need_pixel)) {
+      const long long np = next_pixel(need_pixel, a.npix);
+      if (need_pixel) {
+        pix = np;
+        alive = np >= 0;
+        if (alive) start_sample();
+      }
+    }
   }
-  add_ray_count(a, nrays);
+  add_ray_count(nrays);
 }
 
 // ---- primitive probe: lets the tests check IEEE exactness of device sqrt / div and measure the ulp

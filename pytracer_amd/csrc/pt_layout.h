@@ -43,6 +43,27 @@ struct PtTex {
   int64_t offset;  // in doubles into tex_data
 };
 
+// Spheres whose inverse transform is "scale + translate" (the 3x3 block of invm is diagonal): the
+// common case (translation * scaling).  For them x*0.0 terms only ever add a signed zero, so when no
+// product can be a zero itself (wave-level guard in world_query) the object-space ray is
+//   o' = o * s + t,  d' = d * s        (9 flop instead of 33) — bit-identical to the full product.
+struct alignas(64) PtDiagRec {
+  double s[3];     // invm[0], invm[5], invm[10]
+  double t[3];     // invm[3], invm[7], invm[11]
+  int32_t tnz;     // bit c set: t[c] != 0 (a zero o[c]*s[c] is then absorbed exactly)
+  int32_t _pad[3];
+};
+static_assert(sizeof(PtDiagRec) == 64, "PtDiagRec must be 64 B");
+
+// ... and their per-camera constants for hoisted primary rays
+struct alignas(64) PtHoistDiag {
+  double s[3];
+  double o[3];  // invm * origin, full-product arithmetic (pt_prep_hoist)
+  double c;     // |o'|^2 - 1
+  double _pad;
+};
+static_assert(sizeof(PtHoistDiag) == 64, "PtHoistDiag must be 64 B");
+
 // Per-shape constants of the primary rays of a perspective camera (all share one origin):
 // o' = invm * origin and c = |o'|^2 - 1, computed in the reference's operation order by
 // pt_prep_hoist so the hoisted loop reproduces the per-ray arithmetic bit for bit.
@@ -54,15 +75,19 @@ struct PtKArgs {
   const PtShapeRec *recs;
   const PtShapeAux *aux;
   const PtHoist *hoist;
+  const PtDiagRec *diag;            // [n_diag], parallel to recs[0..n_diag)
+  const PtHoistDiag *hoist_diag;    // [n_diag]
   const PtLight *lights;
   const PtTex *tex;
   const double *tex_data;
   void *out;                       // this rank's rows, compact
   double *ws;                      // path-tracer frame stack: [slot][field][thread]
-  unsigned long long *ray_counter; // may be null
+  unsigned long long *ray_counter; // per-workgroup partial counts; may be null
+  unsigned long long *queue;       // path tracer: next unassigned pixel (zeroed per launch)
   long long npix;                  // pixels this launch covers (rows_local * W)
   int n_shapes, n_lights;
   int n_spheres;                   // recs[0..n_spheres) are spheres, recs[n_spheres..n_shapes) planes
+  int n_diag;                      // recs[0..n_diag) are the scale+translate spheres
   int nthreads;                    // grid * block
   int frame_doubles;               // fields per stack frame
   // camera (camera.py)

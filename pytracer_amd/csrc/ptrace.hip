@@ -6,8 +6,10 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -42,6 +44,9 @@ struct pt_scene {
   PtShapeRec *recs = nullptr;
   PtShapeAux *aux = nullptr;
   PtHoist *hoist = nullptr;
+  PtDiagRec *diag = nullptr;
+  PtHoistDiag *hoist_diag = nullptr;
+  int n_diag = 0;
   PtLight *lights = nullptr;
   PtTex *tex = nullptr;
   double *tex_data = nullptr;
@@ -49,7 +54,10 @@ struct pt_scene {
   size_t ws_bytes = 0;
   void *out_dev = nullptr;  // staging for pt_render (host output)
   size_t out_dev_bytes = 0;
-  unsigned long long *ray_counter = nullptr;
+  unsigned long long *ray_counter = nullptr;   // total (1 word)
+  unsigned long long *ray_partials = nullptr;  // one word per workgroup
+  int ray_partials_n = 0;
+  unsigned long long *queue = nullptr;  // path-tracer pixel queue head
   unsigned long long *ray_counter_host = nullptr;  // pinned
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
@@ -136,12 +144,16 @@ extern "C" void pt_scene_free(pt_scene *s) {
   (void)hipFree(s->recs);
   (void)hipFree(s->aux);
   (void)hipFree(s->hoist);
+  (void)hipFree(s->diag);
+  (void)hipFree(s->hoist_diag);
   (void)hipFree(s->lights);
   (void)hipFree(s->tex);
   (void)hipFree(s->tex_data);
   (void)hipFree(s->ws);
   (void)hipFree(s->out_dev);
   (void)hipFree(s->ray_counter);
+  (void)hipFree(s->ray_partials);
+  (void)hipFree(s->queue);
   if (s->ray_counter_host) (void)hipHostFree(s->ray_counter_host);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
@@ -177,11 +189,28 @@ extern "C" int pt_scene_upload(const pt_scene_desc *d, int device, pt_scene **ou
   s->n_textures = d->n_textures;
   const int n = d->n_shapes;
 
-  // group the records: spheres first, then planes, each group in World.shapes order
+  // group the records: scale+translate spheres, other spheres, planes — each group in World.shapes order
+  auto is_diag = [&](int i) {
+    if (d->kind[i] != PT_SHAPE_SPHERE) return false;
+    const int off[6] = {1, 2, 4, 6, 8, 9};
+    for (int k : off)
+      if (d->invm[(size_t)k * n + i] != 0.0) return false;
+    const int dia[3] = {0, 5, 10};
+    for (int k : dia) {
+      const double v = std::fabs(d->invm[(size_t)k * n + i]);
+      if (!(v >= 1e-100 && v <= 1e100)) return false;
+    }
+    for (int k : {3, 7, 11})
+      if (!std::isfinite(d->invm[(size_t)k * n + i])) return false;
+    return true;
+  };
   std::vector<int> order;
   order.reserve(n);
   for (int i = 0; i < n; ++i)
-    if (d->kind[i] == PT_SHAPE_SPHERE) order.push_back(i);
+    if (is_diag(i)) order.push_back(i);
+  s->n_diag = (int)order.size();
+  for (int i = 0; i < n; ++i)
+    if (d->kind[i] == PT_SHAPE_SPHERE && !is_diag(i)) order.push_back(i);
   s->n_spheres = (int)order.size();
   for (int i = 0; i < n; ++i)
     if (d->kind[i] != PT_SHAPE_SPHERE) order.push_back(i);
@@ -242,7 +271,25 @@ extern "C" int pt_scene_upload(const pt_scene_desc *d, int device, pt_scene **ou
       return rc;            \
     }                       \
   } while (0)
+  std::vector<PtDiagRec> diag(s->n_diag);
+  for (int slot = 0; slot < s->n_diag; ++slot) {
+    PtDiagRec &g = diag[slot];
+    memset(&g, 0, sizeof g);
+    const double *im = recs[slot].invm;
+    g.s[0] = im[0];
+    g.s[1] = im[5];
+    g.s[2] = im[10];
+    g.t[0] = im[3];
+    g.t[1] = im[7];
+    g.t[2] = im[11];
+    g.tnz = (im[3] != 0.0 ? 1 : 0) | (im[7] != 0.0 ? 2 : 0) | (im[11] != 0.0 ? 4 : 0);
+  }
   UP(upload(&s->recs, recs));
+  UP(upload(&s->diag, diag));
+  {
+    std::vector<PtHoistDiag> hd(std::max(s->n_diag, 1));
+    UP(upload(&s->hoist_diag, hd));
+  }
   UP(upload(&s->aux, aux));
   UP(upload(&s->lights, lights));
   UP(upload(&s->tex, tex));
@@ -259,6 +306,7 @@ extern "C" int pt_scene_upload(const pt_scene_desc *d, int device, pt_scene **ou
     return code;
   };
   if ((rc = hip_or_free(hipMalloc((void **)&s->ray_counter, sizeof(unsigned long long)), "hipMalloc(counter)"))) return rc;
+  if ((rc = hip_or_free(hipMalloc((void **)&s->queue, sizeof(unsigned long long)), "hipMalloc(queue)"))) return rc;
   if ((rc = hip_or_free(hipHostMalloc((void **)&s->ray_counter_host, sizeof(unsigned long long)), "hipHostMalloc"))) return rc;
   *s->ray_counter_host = 0;
   if ((rc = hip_or_free(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking), "hipStreamCreate"))) return rc;
@@ -311,11 +359,13 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
   a.recs = s->recs;
   a.aux = s->aux;
   a.hoist = s->hoist;
+  a.diag = s->diag;
+  a.hoist_diag = s->hoist_diag;
+  a.n_diag = s->n_diag;
   a.lights = s->lights;
   a.tex = s->tex;
   a.tex_data = s->tex_data;
   a.out = out_dev;
-  a.ray_counter = s->count_rays ? s->ray_counter : nullptr;
   a.n_shapes = s->n_shapes;
   a.n_spheres = s->n_spheres;
   a.n_lights = s->n_lights;
@@ -348,13 +398,30 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
 
   // grid: one lane per pixel up to the resident capacity of the chip, grid-stride beyond
   const long long want = (a.npix + PT_BLOCK - 1) / PT_BLOCK;
-  const long long cap = (long long)s->n_cu * 8;  // 8 x 256-thread workgroups per CU = 32 waves/CU
+  long long cap = (long long)s->n_cu * 8;  // 8 x 256-thread workgroups per CU = 32 waves/CU
+  if (p->renderer == PT_RENDERER_PATHTRACER) {
+    // The path tracer hands pixels out dynamically; fewer resident lanes than pixels lets a lane
+    // that drew a cheap pixel take several more while its neighbours finish an expensive one.
+    static const int env_wg = getenv("PTRACE_PATH_WG_PER_CU") ? atoi(getenv("PTRACE_PATH_WG_PER_CU")) : 0;
+    const int wg_per_cu = env_wg > 0 ? env_wg : 3;
+    cap = (long long)s->n_cu * wg_per_cu;
+  }
   const int grid = (int)std::max<long long>(1, std::min(want, cap));
   a.nthreads = grid * PT_BLOCK;
   s->stats.grid = grid;
   s->stats.block = PT_BLOCK;
 
-  if (s->count_rays) HIP_TRY(hipMemsetAsync(s->ray_counter, 0, sizeof(unsigned long long), st));
+  if (s->count_rays) {
+    if (grid > s->ray_partials_n) {
+      HIP_TRY(hipStreamSynchronize(st));
+      if (s->ray_partials) HIP_TRY(hipFree(s->ray_partials));
+      s->ray_partials = nullptr;
+      s->ray_partials_n = 0;
+      HIP_TRY(hipMalloc((void **)&s->ray_partials, (size_t)grid * sizeof(unsigned long long)));
+      s->ray_partials_n = grid;
+    }
+    a.ray_counter = s->ray_partials;
+  }
 
   const bool hoist = cam->kind == PT_CAMERA_PERSPECTIVE && p->renderer != PT_RENDERER_PATHTRACER && s->n_shapes > 0;
   if (hoist && !(s->hoist_valid && s->hoist_stream == st && memcmp(&s->hoist_cam, cam, sizeof(pt_camera)) == 0)) {
@@ -365,13 +432,28 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
     w.y = o.x * cam->m[4] + o.y * cam->m[5] + o.z * cam->m[6] + cam->m[7];
     w.z = o.x * cam->m[8] + o.y * cam->m[9] + o.z * cam->m[10] + cam->m[11];
     hipLaunchKernelGGL(pt_prep_hoist, dim3((s->n_shapes + 255) / 256), dim3(256), 0, st, s->recs, s->hoist,
-                       s->n_shapes, w);
+                       s->hoist_diag, s->n_shapes, s->n_diag, w);
     s->hoist_cam = *cam;
     s->hoist_valid = true;
     s->hoist_stream = st;
   }
 
+  if (p->renderer == PT_RENDERER_PATHTRACER && p->max_depth < 0) {
+    // render.py:100-101: every primary call returns Color(0, 0, 0) without a world query
+    HIP_TRY(hipEventRecord(s->ev0, st));
+    HIP_TRY(hipMemsetAsync(out_dev, 0, pt_output_bytes(p), st));
+    HIP_TRY(hipEventRecord(s->ev1, st));
+    if (s->count_rays) {
+      *s->ray_counter_host = 0;
+      HIP_TRY(hipMemsetAsync(s->ray_counter, 0, sizeof(unsigned long long), st));
+      HIP_TRY(hipMemcpyAsync(s->ray_counter_host, s->ray_counter, sizeof(unsigned long long),
+                             hipMemcpyDeviceToHost, st));
+    }
+    return PT_OK;
+  }
   if (p->renderer == PT_RENDERER_PATHTRACER) {
+    a.queue = s->queue;
+    HIP_TRY(hipMemsetAsync(s->queue, 0, sizeof(unsigned long long), st));
     a.frame_doubles = p->num_of_rays > 1 ? 20 : 6;
     const size_t slots = (size_t)std::max(p->max_depth, 0) + 1;
     const size_t need = slots * a.frame_doubles * (size_t)a.nthreads * sizeof(double);
@@ -412,9 +494,11 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
   }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(s->ev1, st));
-  if (s->count_rays)
+  if (s->count_rays) {
+    hipLaunchKernelGGL(pt_sum_counts, dim3(1), dim3(256), 0, st, s->ray_partials, grid, s->ray_counter);
     HIP_TRY(hipMemcpyAsync(s->ray_counter_host, s->ray_counter, sizeof(unsigned long long),
                            hipMemcpyDeviceToHost, st));
+  }
   return PT_OK;
 }
 
