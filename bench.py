@@ -30,6 +30,7 @@ import torch  # noqa: E402
 
 from pytracer_amd import abi, flatten, scenes  # noqa: E402
 from pytracer_amd.device import DeviceScene  # noqa: E402
+from pytracer_amd.dist import ShardedFrameLoop  # noqa: E402
 
 PEAK_FP64_VECTOR_TFLOPS = 78.6  # MI355X vector fp64 (vendor spec; an FMA counts 2), SURVEY.md §8(d)
 PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
@@ -53,7 +54,8 @@ def cpu_baseline(scene, cam_for, seconds_budget=20.0):
     orc.build()
     par = abi.make_params(1280, 720, abi.RENDERER_FLAT, out_format=abi.OUT_F32)
     cam = cam_for(1280, 720)
-    threads = orc.max_threads()
+    # the GPU box gives this job a 16-core share of the host (more threads only oversubscribe it)
+    threads = int(os.environ.get("PT_CPU_THREADS", min(orc.max_threads(), 16)))
     t0 = time.perf_counter()
     _, rays = orc.render(scene, cam, par, n_threads=threads, sqr_mode=orc.SQR_MUL)
     first = time.perf_counter() - t0
@@ -75,6 +77,54 @@ def cpu_baseline(scene, cam_for, seconds_budget=20.0):
         "one_core_Mray_s": rays1 / dt1 / 1e6,
         "one_core_sample": "rows of rank 3/8 (90 rows) of the same frame, 1 thread",
     }
+
+
+def extra_rows(device: int):
+    """Secondary rows (not the headline): the other 1280x720 configurations of BASELINE.json on one GPU,
+    kernel time from the library's hipEvents, median of a few frames."""
+    rows = {}
+    cases = {
+        "C3_pathtracer_1280x720_32sph_D3_spp16_N1": (32, False, False, 1280, 720, 7, dict(
+            renderer=abi.RENDERER_PATHTRACER, samples_per_side=4, num_of_rays=1, max_depth=3, rr_limit=3,
+            path_state=45, path_seq=54)),
+        "C3_cli_default_N10_spp1": (32, False, False, 1280, 720, 3, dict(
+            renderer=abi.RENDERER_PATHTRACER, samples_per_side=1, num_of_rays=10, max_depth=3, rr_limit=3,
+            path_state=45, path_seq=54)),
+        "C5_flat_1280x720_10k_spheres": (10000, False, True, 1280, 720, 5, dict(renderer=abi.RENDERER_FLAT)),
+        "C4_crop_pathtracer_960x540_256sph_D5_spp16": (256, False, True, 960, 540, 3, dict(
+            renderer=abi.RENDERER_PATHTRACER, samples_per_side=4, num_of_rays=1, max_depth=5, rr_limit=3,
+            path_state=45, path_seq=54)),
+    }
+    for name, (ns, plane, wide, W, H, reps, kw) in cases.items():
+        flat = flatten.flatten_world(scenes.synthetic_world(ns, with_plane=plane, wide=wide))
+        cam = flatten.flatten_camera(scenes.synthetic_camera(W, H))
+        par = abi.make_params(W, H, out_format=abi.OUT_F32, **kw)
+        ds = DeviceScene(flat, device=device)
+        out = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+        ms = []
+        for r in range(reps + 1):
+            ds.render_into(cam, par, out.data_ptr(), out.numel() * 4, None)
+            st = ds.stats()
+            if r > 0:
+                ms.append(st.kernel_ms)
+        t = float(np.median(ms)) * 1e-3
+        n_sph = int((flat.kind == abi.SHAPE_SPHERE).sum())
+        n_pl = flat.n_shapes - n_sph
+        rows[name] = {"Mray_s": st.n_rays / t / 1e6, "ms_per_frame": t * 1e3, "rays_per_frame": int(st.n_rays),
+                      "ray_shape_tests_per_s": st.n_rays * flat.n_shapes / t,
+                      "algorithmic_TFLOP_s": st.n_rays * (n_sph * FLOP_PER_SPHERE_TEST + n_pl * FLOP_PER_PLANE_TEST) / t / 1e12}
+        ds.close()
+    return rows
+
+
+def measured_traffic():
+    """HBM bytes per launch of the headline kernel from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE;
+    collected separately, see profiles/): bench.py cannot read hardware counters itself."""
+    path = os.path.join(ROOT, "profiles", "traffic_c2.json")
+    if os.path.exists(path):
+        with open(path) as f:
+            return json.load(f)
+    return None
 
 
 def main():
@@ -109,43 +159,18 @@ def main():
     cam_for = lambda w, h: flatten.flatten_camera(scenes.synthetic_camera(w, h))  # noqa: E731
     cam = cam_for(W, H)
     ds = DeviceScene(flat, device=local_rank)
-    par = abi.make_params(W, H, abi.RENDERER_FLAT, out_format=abi.OUT_F32, row_block=8, n_ranks=world_size,
-                          rank=rank)
-    rows = len(abi.rows_for_rank(H, 8, world_size, rank))
-    max_rows = max(len(abi.rows_for_rank(H, 8, world_size, r)) for r in range(world_size))
-    # double-buffered output in HBM (fp32 RGB); padded to the largest shard so gathers are uniform
-    bufs = [torch.zeros((max_rows, W, 3), dtype=torch.float32, device="cuda") for _ in range(2)]
-    gathered = None
-    comm_stream = None
-    if dist is not None:
-        comm_stream = torch.cuda.Stream()
-        if rank == 0:
-            gathered = [[torch.empty_like(bufs[0]) for _ in range(world_size)] for _ in range(2)]
-    stream = torch.cuda.current_stream()
-    nbytes = rows * W * 3 * 4
+    par = abi.make_params(W, H, abi.RENDERER_FLAT, out_format=abi.OUT_F32)
+    loop = ShardedFrameLoop(ds, cam, par, row_block=8)
+    rows = loop.rows
+    stream = loop.stream
     ev_pairs = []
-    done_events = [None, None]
+
+    TIME_EVERY = 8  # bracket every 8th launch of the timed region with a hipEvent pair
 
     def step(i, timed):
-        b = i & 1
-        if done_events[b] is not None:
-            stream.wait_event(done_events[b])  # the gather that last read this buffer has finished
         if timed:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(stream)
-        ds.render_into(cam, par, bufs[b].data_ptr(), nbytes, stream.cuda_stream)
-        if timed:
-            e1.record(stream)
-            ev_pairs.append((e0, e1))
-        if dist is not None:
-            rendered = torch.cuda.Event()
-            rendered.record(stream)
-            with torch.cuda.stream(comm_stream):
-                comm_stream.wait_event(rendered)
-                dist.gather(bufs[b], gathered[b] if rank == 0 else None, dst=0)
-                ev = torch.cuda.Event()
-                ev.record(comm_stream)
-                done_events[b] = ev
+            ds.set_timing(i % TIME_EVERY == 0)
+        loop.step(i)
 
     def fence():
         torch.cuda.synchronize()
@@ -162,12 +187,20 @@ def main():
     # the timed steps run without the counter: one step == exactly one render-kernel launch
     rays_per_step_local = int(ds.stats().n_rays) if args.warmup > 0 else rows * W
     ds.set_count_rays(False)
+    ds.set_timing(False)
+    loop.step(0)  # one uncounted frame so the timed region starts from the steady state
     fence()
+    # every TIME_EVERY-th timed launch is bracketed by its own hipEvent pair on the launch stream (inside
+    # the library, directly around the render kernel): their mean is the kernel's average launch duration;
+    # the other launches carry no event so that frames run back to back
+    ds.profile_begin(args.steps)
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i, True)
     fence()
     elapsed = time.perf_counter() - t0
+    kernel_total_ms, kernel_launches = ds.profile_end()
+    ds.set_timing(True)
 
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -179,8 +212,7 @@ def main():
     else:
         rays_per_step = rays_per_step_local
 
-    kernel_ms = [a.elapsed_time(b) for a, b in ev_pairs]
-    avg_kernel_s = float(np.mean(kernel_ms)) * 1e-3 if kernel_ms else float("nan")
+    avg_kernel_s = kernel_total_ms / max(kernel_launches, 1) * 1e-3
 
     if rank == 0:
         n_sph = int((flat.kind == abi.SHAPE_SPHERE).sum())
@@ -222,6 +254,12 @@ def main():
                         "algorithmic_bytes_per_launch": alg_bytes},
             },
         }
+        tr = measured_traffic()
+        if tr is not None and n == 1:
+            result["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
+            result["roofline"]["traffic_source"] = tr["source"]
+        if n == 1 and not args.no_extras:
+            result["extra"] = extra_rows(local_rank)
         if n == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(flat, cam_for)
         print(json.dumps(result), flush=True)

@@ -163,6 +163,15 @@ int pt_get_stats(pt_scene *scene, pt_stats *out);
 int pt_set_count_rays(pt_scene *scene, int enable);
 /* Block until the scene's last asynchronous render has finished and fold its statistics. */
 int pt_sync(pt_scene *scene);
+/* Enable (1, default) / disable (0) the hipEvent pair around each render kernel.  An event record is a
+ * barrier packet on the stream: back-to-back frames run closer together without them. */
+int pt_set_timing(pt_scene *scene, int enable);
+/* Kernel-time accounting over many asynchronous launches (the reference only prints one
+ * process_time() delta around fire_all_rays, main.py:196-200).  Between begin and end every render
+ * on this scene brackets its render kernel with its own hipEvent pair, recorded on the stream the
+ * kernel is launched on; end synchronises and returns the summed kernel time and the launch count. */
+int pt_profile_begin(pt_scene *scene, int capacity);
+int pt_profile_end(pt_scene *scene, double *total_kernel_ms, int *launches);
 /* Copy the last error message of the calling thread (NUL-terminated) into buf; returns its length. */
 int pt_last_error(char *buf, size_t n);
 /* Library/ABI version: (major<<16)|minor. */

@@ -13,7 +13,7 @@ _lib = None
 # every symbol include/ptrace.h declares
 EXPORTS = ("pt_device_count", "pt_scene_upload", "pt_scene_free", "pt_rows_for_rank", "pt_output_bytes",
            "pt_render", "pt_render_device", "pt_get_stats", "pt_set_count_rays", "pt_sync", "pt_last_error",
-           "pt_version")
+           "pt_version", "pt_profile_begin", "pt_profile_end", "pt_set_timing")
 
 
 class PtraceError(RuntimeError):
@@ -59,6 +59,12 @@ def lib():
         L.pt_last_error.restype = C.c_int
         L.pt_last_error.argtypes = [C.c_char_p, C.c_size_t]
         L.pt_version.restype = C.c_int
+        L.pt_set_timing.restype = C.c_int
+        L.pt_set_timing.argtypes = [C.c_void_p, C.c_int]
+        L.pt_profile_begin.restype = C.c_int
+        L.pt_profile_begin.argtypes = [C.c_void_p, C.c_int]
+        L.pt_profile_end.restype = C.c_int
+        L.pt_profile_end.argtypes = [C.c_void_p, P(C.c_double), P(C.c_int)]
         L.pt_debug_probe.restype = C.c_int
         L.pt_debug_probe.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         _lib = L

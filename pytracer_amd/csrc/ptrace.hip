@@ -60,10 +60,16 @@ struct pt_scene {
   unsigned long long *queue = nullptr;  // path-tracer pixel queue head
   unsigned long long *ray_counter_host = nullptr;  // pinned
   hipStream_t stream = nullptr;
+  hipStream_t last_stream = nullptr;  // stream of the most recent launch
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
+  std::vector<hipEvent_t> prof;  // 2 * capacity events while profiling
+  int prof_used = 0;             // pairs recorded
+  bool profiling = false;
   bool count_rays = true;
+  bool timing = true;  // bracket render kernels with hipEvents
   bool pending = false;  // an async render whose stats are not folded yet
   bool pending_copy = false;
+  bool stats_valid = true;  // ev0/ev1 bracket the last launch (false while the profiling ring is used)
   bool hoist_valid = false;  // s->hoist holds the constants of hoist_cam
   pt_camera hoist_cam = {};
   hipStream_t hoist_stream = nullptr;  // the stream the constants were produced on
@@ -158,6 +164,7 @@ extern "C" void pt_scene_free(pt_scene *s) {
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
   if (s->ev2) (void)hipEventDestroy(s->ev2);
+  for (hipEvent_t e : s->prof) (void)hipEventDestroy(e);
   if (s->stream) (void)hipStreamDestroy(s->stream);
   delete s;
 }
@@ -391,6 +398,7 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
     a.onoff[k] = p->onoff_color[k];
     a.ambient[k] = p->ambient[k];
   }
+  s->last_stream = st;
   const int rows = pt_rows_for_rank(p);
   a.npix = (long long)rows * p->width;
   s->stats.n_pixels = (uint64_t)a.npix;
@@ -468,7 +476,8 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
     a.ws = s->ws;
   }
 
-  HIP_TRY(hipEventRecord(s->ev0, st));
+  const bool prof = s->timing && s->profiling && (size_t)(2 * s->prof_used + 1) < s->prof.size();
+  if (s->timing) HIP_TRY(hipEventRecord(prof ? s->prof[2 * s->prof_used] : s->ev0, st));
   switch (p->renderer) {
     case PT_RENDERER_ONOFF:
       if (hoist)
@@ -493,7 +502,16 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
       break;
   }
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipEventRecord(s->ev1, st));
+  if (prof) {
+    HIP_TRY(hipEventRecord(s->prof[2 * s->prof_used + 1], st));
+    s->prof_used++;
+    s->stats_valid = false;
+  } else if (s->timing) {
+    HIP_TRY(hipEventRecord(s->ev1, st));
+    s->stats_valid = true;
+  } else {
+    s->stats_valid = false;
+  }
   if (s->count_rays) {
     hipLaunchKernelGGL(pt_sum_counts, dim3(1), dim3(256), 0, st, s->ray_partials, grid, s->ray_counter);
     HIP_TRY(hipMemcpyAsync(s->ray_counter_host, s->ray_counter, sizeof(unsigned long long),
@@ -505,8 +523,11 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
 static int fold_stats(pt_scene *s) {
   if (!s->pending) return PT_OK;
   float ms = 0.f;
-  HIP_TRY(hipEventSynchronize(s->pending_copy ? s->ev2 : s->ev1));
-  if (s->stats.n_pixels > 0) {
+  if (s->stats_valid) HIP_TRY(hipEventSynchronize(s->pending_copy ? s->ev2 : s->ev1));
+  if (!s->stats_valid) {
+    HIP_TRY(hipStreamSynchronize(s->last_stream));
+    s->stats.kernel_ms = s->stats.total_ms = 0.0;
+  } else if (s->stats.n_pixels > 0) {
     HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
     s->stats.kernel_ms = ms;
     if (s->pending_copy) {
@@ -588,6 +609,42 @@ extern "C" int pt_get_stats(pt_scene *s, pt_stats *out) {
     if (rc) return rc;
   }
   *out = s->stats;
+  return PT_OK;
+}
+
+extern "C" int pt_set_timing(pt_scene *s, int enable) {
+  if (!s) return fail(PT_ERR_INVALID, "null scene");
+  s->timing = enable != 0;
+  return PT_OK;
+}
+
+extern "C" int pt_profile_begin(pt_scene *s, int capacity) {
+  if (!s || capacity <= 0 || capacity > (1 << 20)) return fail(PT_ERR_INVALID, "bad profiling capacity");
+  HIP_TRY(hipSetDevice(s->device));
+  while ((int)s->prof.size() < 2 * capacity) {
+    hipEvent_t e;
+    HIP_TRY(hipEventCreate(&e));
+    s->prof.push_back(e);
+  }
+  s->prof_used = 0;
+  s->profiling = true;
+  return PT_OK;
+}
+
+extern "C" int pt_profile_end(pt_scene *s, double *total_kernel_ms, int *launches) {
+  if (!s || !total_kernel_ms || !launches) return fail(PT_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(s->device));
+  double sum = 0.0;
+  for (int k = 0; k < s->prof_used; ++k) {
+    float ms = 0.f;
+    HIP_TRY(hipEventSynchronize(s->prof[2 * k + 1]));
+    HIP_TRY(hipEventElapsedTime(&ms, s->prof[2 * k], s->prof[2 * k + 1]));
+    sum += ms;
+  }
+  *total_kernel_ms = sum;
+  *launches = s->prof_used;
+  s->profiling = false;
+  s->prof_used = 0;
   return PT_OK;
 }
 

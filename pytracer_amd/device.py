@@ -62,6 +62,20 @@ class DeviceScene:
     def set_count_rays(self, enable: bool) -> None:
         _lib.check(_lib.lib().pt_set_count_rays(self._h, int(bool(enable))))
 
+    def set_timing(self, enable: bool) -> None:
+        """hipEvent pair around each render kernel on/off (off: frames run back to back)."""
+        _lib.check(_lib.lib().pt_set_timing(self._h, int(bool(enable))))
+
+    def profile_begin(self, capacity: int) -> None:
+        """Bracket every following render kernel with its own hipEvent pair (up to ``capacity``)."""
+        _lib.check(_lib.lib().pt_profile_begin(self._h, int(capacity)))
+
+    def profile_end(self) -> Tuple[float, int]:
+        """-> (summed kernel time in ms, launches) since ``profile_begin``; synchronises."""
+        total, n = C.c_double(0.0), C.c_int(0)
+        _lib.check(_lib.lib().pt_profile_end(self._h, C.byref(total), C.byref(n)))
+        return float(total.value), int(n.value)
+
     def stats(self) -> abi.Stats:
         st = abi.Stats()
         _lib.check(_lib.lib().pt_get_stats(self._h, C.byref(st)))
