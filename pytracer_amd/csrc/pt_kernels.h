@@ -161,35 +161,58 @@ PT_DEV WaveGuard wave_guard(const Ray &r, bool active) {
   return g;
 }
 
-// shapes.py:103-121 given the object-space ray; updates (best_t, best) for the lanes that hit
-#define PT_SPHERE_ROOTS(SLOT)                                                     \
-  do {                                                                            \
-    const double bb = 2.0 * (ox * dx + oy * dy + oz * dz);                        \
-    const double delta = bb * bb - 4.0 * aa * cc;                                 \
-    if (active && delta > 0.0) {                                                  \
-      /* first root inside (tmin, tmax); the roots are ordered (a > 0), so the */ \
-      /* running best_t as upper limit selects the same winner as world.py:62 */  \
-      const double sd = sqrt(delta);                                              \
-      const double den = 2.0 * aa;                                                \
-      double t = (-bb - sd) / den;                                                \
-      bool ok = (t > tmin) && (t < best_t);                                       \
-      if (!ok) {                                                                  \
-        t = (-bb + sd) / den;                                                     \
-        ok = (t > tmin) && (t < best_t);                                          \
-      }                                                                           \
-      if (ok) {                                                                   \
-        best_t = t;                                                               \
-        best = (SLOT);                                                            \
-      }                                                                           \
-    }                                                                             \
-    if (ANYHIT) {                                                                 \
-      if (__ballot(active && best < 0) == 0ULL) return best;                      \
-    }                                                                             \
+// Exact tie in t with the current winner: the shape that comes first in World.shapes wins
+// (world.py:62 replaces the closest hit only on a strict <).  Evaluated only when t == best_t.
+PT_DEV bool tie_wins(const PtKArgs &a, int slot, int best) {
+  return best >= 0 && *PT_KI(&a.recs[slot].index) < a.recs[best].index;
+}
+
+// shapes.py:103-121 given the object-space ray (ox..dz, aa = |d'|^2, cc = |o'|^2 - 1): the first root
+// inside (tmin, tmax) is this shape's hit; it replaces the winner if closer (world.py:62).
+#define PT_SPHERE_ROOTS(SLOT)                                                         \
+  do {                                                                                \
+    const double bb = 2.0 * (ox * dx + oy * dy + oz * dz);                            \
+    const double delta = bb * bb - 4.0 * aa * cc;                                     \
+    if (active && delta > 0.0) {                                                      \
+      const double sd = sqrt(delta);                                                  \
+      const double den = 2.0 * aa;                                                    \
+      double t = (-bb - sd) / den;                                                    \
+      bool ok = (t > tmin) && (t < tmax);                                             \
+      if (!ok) {                                                                      \
+        t = (-bb + sd) / den;                                                         \
+        ok = (t > tmin) && (t < tmax);                                                \
+      }                                                                               \
+      if (ok && (t < best_t || (!ANYHIT && t == best_t && tie_wins(a, (SLOT), best)))) { \
+        best_t = t;                                                                   \
+        best = (SLOT);                                                                \
+      }                                                                               \
+    }                                                                                 \
+  } while (0)
+
+// shapes.py:168-175 given the z row of the object-space ray
+#define PT_PLANE_HIT(SLOT)                                                            \
+  do {                                                                                \
+    if (active && !(fabs(dz) < 1e-5)) {                                               \
+      const double t = -oz / dz;                                                      \
+      if (!(t <= tmin) && !(t >= tmax) &&                                             \
+          (t < best_t || (!ANYHIT && t == best_t && tie_wins(a, (SLOT), best)))) {    \
+        best_t = t;                                                                   \
+        best = (SLOT);                                                                \
+      }                                                                               \
+    }                                                                                 \
+  } while (0)
+
+#define PT_ANYHIT_EXIT()                                             \
+  do {                                                               \
+    if (ANYHIT) {                                                    \
+      if (__ballot(active && best < 0) == 0ULL) return best;         \
+    }                                                                \
   } while (0)
 
 template <bool ANYHIT, bool HOIST>
-PT_DEV int world_query(const PtKArgs &a, const Ray &r, double &best_t, bool active) {
+PT_DEV int world_query(const PtKArgs &a, const Ray &r, double tmax, double &best_t, bool active) {
   int best = -1;
+  best_t = INFINITY;
   const double tmin = r.tmin;
   const int nd = a.n_diag;
   const int ns = a.n_spheres;
@@ -218,6 +241,7 @@ PT_DEV int world_query(const PtKArgs &a, const Ray &r, double &best_t, bool acti
           const double dx = r.d.x * s0, dy = r.d.y * s1, dz = r.d.z * s2;
           const double aa = dx * dx + dy * dy + dz * dz;
           PT_SPHERE_ROOTS(i);
+          PT_ANYHIT_EXIT();
         }
       } else {
         pt_kdouble base = PT_KD(a.diag);
@@ -255,6 +279,7 @@ PT_DEV int world_query(const PtKArgs &a, const Ray &r, double &best_t, bool acti
           const double aa = dx * dx + dy * dy + dz * dz;
           const double cc = (ox * ox + oy * oy + oz * oz) - 1.0;
           PT_SPHERE_ROOTS(i);
+          PT_ANYHIT_EXIT();
         }
       }
     }
@@ -280,6 +305,7 @@ PT_DEV int world_query(const PtKArgs &a, const Ray &r, double &best_t, bool acti
       cc = (ox * ox + oy * oy + oz * oz) - 1.0;
     }
     PT_SPHERE_ROOTS(i);
+    PT_ANYHIT_EXIT();
   }
   // ---- planes: shapes.py:168-175, only the z row of the object-space ray decides ----
   for (int i = ns; i < n; ++i) {
@@ -291,23 +317,8 @@ PT_DEV int world_query(const PtKArgs &a, const Ray &r, double &best_t, bool acti
     } else {
       oz = r.o.x * m[8] + r.o.y * m[9] + r.o.z * m[10] + m[11];
     }
-    if (active && !(fabs(dz) < 1e-5)) {
-      const double t = -oz / dz;
-      if (!(t <= tmin)) {
-        bool take = t < best_t;
-        if (!ANYHIT && t == best_t && best >= 0) {
-          // exact tie with an earlier winner: the lower World.shapes index wins
-          take = *PT_KI(&a.recs[i].index) < a.recs[best].index;
-        }
-        if (take) {
-          best_t = t;
-          best = i;
-        }
-      }
-    }
-    if (ANYHIT) {
-      if (__ballot(active && best < 0) == 0ULL) return best;
-    }
+    PT_PLANE_HIT(i);
+    PT_ANYHIT_EXIT();
   }
   return best;
 }
@@ -553,8 +564,8 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAV
         vp = ((double)sr + pcg_float(pcg)) / (double)S;
       }
       const Ray ray = primary_ray(col, grow, up, vp);
-      double best_t = INFINITY;
-      const int hit = world_query<RENDERER == PT_RENDERER_ONOFF, HOIST>(a, ray, best_t, active);
+      double best_t;
+      const int hit = world_query<RENDERER == PT_RENDERER_ONOFF, HOIST>(a, ray, INFINITY, best_t, active);
       if (active) nrays++;
       V3 c;
       {
@@ -614,8 +625,8 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAV
           sh.d.z = lp.z - sh.o.z;
           const double dn = sqrt(sh.d.x * sh.d.x + sh.d.y * sh.d.y + sh.d.z * sh.d.z);
           sh.tmin = 1e-2 / dn;
-          double tlim = 1.0;
-          const int blocked = world_query<true, false>(a, sh, tlim, lit);
+          double tlim;
+          const int blocked = world_query<true, false>(a, sh, 1.0, tlim, lit);
           if (lit) nrays++;
           if (lit && blocked < 0) {
             const V3 dv = {h.wp.x - lp.x, h.wp.y - lp.y, h.wp.z - lp.z};
@@ -662,6 +673,244 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAV
       cum.z = cum.z * k;
     }
     if (active) store_pixel(pix, cum);
+  }
+  add_ray_count(nrays);
+}
+
+// ---- tile culling for primary rays -------------------------------------------------------------------
+// A wave owns an 8x8-pixel tile.  All its primary rays (every jittered sample of every pixel) lie in
+// the convex cone spanned by the pixels' corner rays, so a shape whose bounding sphere misses that
+// cone (with a 1e-6 relative margin, ~1e9 times the rounding error of the fp64 test) cannot yield
+// delta > 0 for any lane: skipping it cannot change a single bit of the result.  Each lane tests one
+// bounding sphere per pass; the survivors come back as one 64-bit ballot per pass, staged in LDS
+// (wave-private slice) and replayed for every sample.  Survivors run the exact reference arithmetic
+// in ascending slot order; ties go to the lower World.shapes index as everywhere else.
+PT_DEV double wave_min(double v) {
+  for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off, 64));
+  return v;
+}
+PT_DEV double wave_sum(double v) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+PT_DEV V3 unit3(V3 v) {
+  const double n = sqrt(v.x * v.x + v.y * v.y + v.z * v.z);
+  V3 r = {v.x / n, v.y / n, v.z / n};
+  return r;
+}
+// direction of the primary ray through continuous image position (x, y) (perspective camera)
+PT_DEV V3 primary_dir_at(double x, double y) {
+  pt_kargs c = cold_args();
+  const double u = x / (double)c->W, v = 1.0 - y / (double)c->H;
+  V3 d = {c->cam_dist, (1.0 - 2.0 * u) * c->cam_aspect, 2.0 * v - 1.0};
+  return xf_vec(c->cam_m, d);
+}
+
+struct TileCone {
+  V3 apex, axis;
+  double cos_t, sin_t;  // half-angle
+  bool all;             // cone wider than 90 degrees: keep everything
+};
+
+PT_DEV TileCone tile_cone(int col, int grow, bool active) {
+  TileCone tc;
+  {
+    pt_kargs c = cold_args();
+    const V3 o = {-c->cam_dist, 0.0, 0.0};
+    tc.apex = xf_point(c->cam_m, o);
+  }
+  const V3 d00 = unit3(primary_dir_at((double)col, (double)grow));
+  const V3 d10 = unit3(primary_dir_at((double)col + 1.0, (double)grow));
+  const V3 d01 = unit3(primary_dir_at((double)col, (double)grow + 1.0));
+  const V3 d11 = unit3(primary_dir_at((double)col + 1.0, (double)grow + 1.0));
+  const double wgt = active ? 1.0 : 0.0;
+  V3 sum = {wave_sum(wgt * (d00.x + d11.x)), wave_sum(wgt * (d00.y + d11.y)), wave_sum(wgt * (d00.z + d11.z))};
+  tc.axis = unit3(sum);
+  double cmin = fmin(fmin(dot3(tc.axis, d00), dot3(tc.axis, d10)), fmin(dot3(tc.axis, d01), dot3(tc.axis, d11)));
+  cmin = wave_min(active ? cmin : 1.0);
+  tc.cos_t = cmin;
+  tc.all = !(cmin > 1e-3);  // also catches NaN
+  tc.sin_t = sqrt(fmax(0.0, 1.0 - cmin * cmin));
+  return tc;
+}
+
+// may the bounding sphere touch the cone?  (conservative: true when in doubt)
+PT_DEV bool cone_keeps(const TileCone &tc, const PtBound &b) {
+  if (tc.all || !(b.r >= 0.0)) return true;
+  const V3 v = {b.cx - tc.apex.x, b.cy - tc.apex.y, b.cz - tc.apex.z};
+  const double L2 = dot3(v, v);
+  const double L = sqrt(L2);
+  const double R = b.r * (1.0 + 1e-6);
+  if (!(L > R)) return true;  // apex inside the sphere (or NaN)
+  const double sin_a = R / L;
+  if (!(sin_a < tc.cos_t)) return true;  // theta + alpha >= 90 degrees
+  const double cos_a = sqrt(1.0 - sin_a * sin_a);
+  const double cos_sum = tc.cos_t * cos_a - tc.sin_t * sin_a;  // cos(theta + alpha), both < 90 degrees
+  return !(dot3(v, tc.axis) < L * (cos_sum - 1e-6));
+}
+
+// The survivor masks live in LDS and are always addressed through this array (never through a generic
+// pointer): DS reads and writes of one wave execute in order, FLAT accesses to the LDS aperture do not.
+extern __shared__ unsigned long long pt_lds_masks[];
+
+template <bool ANYHIT>
+PT_DEV int world_query_tile(const PtKArgs &a, const Ray &r, int mbase, int npass, double &best_t, bool active) {
+  int best = -1;
+  best_t = INFINITY;
+  const double tmin = r.tmin, tmax = INFINITY;
+  const int nd = a.n_diag, ns = a.n_spheres;
+  const WaveGuard g = wave_guard<true>(r, active);
+  for (int p = 0; p < npass; ++p) {
+    const unsigned long long mv = pt_lds_masks[mbase + p];
+    // readfirstlane returns a signed int: go through unsigned or bit 31 smears over the high half
+    const unsigned m_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(mv >> 32));
+    const unsigned m_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)mv);
+    unsigned long long mask = ((unsigned long long)m_hi << 32) | (unsigned long long)m_lo;
+    while (mask) {
+      const int slot = p * 64 + (__ffsll((long long)mask) - 1);
+      mask &= mask - 1;
+      if (slot < ns) {
+        double dx, dy, dz, ox, oy, oz, cc;
+        if (slot < nd && g.fast) {
+          pt_kdouble h = PT_KD(&a.hoist_diag[slot]);
+          dx = r.d.x * h[0];
+          dy = r.d.y * h[1];
+          dz = r.d.z * h[2];
+          ox = h[3];
+          oy = h[4];
+          oz = h[5];
+          cc = h[6];
+        } else {
+          pt_kdouble m = PT_KD(a.recs[slot].invm);
+          pt_kdouble h = PT_KD(&a.hoist[slot]);
+          dx = r.d.x * m[0] + r.d.y * m[1] + r.d.z * m[2];
+          dy = r.d.x * m[4] + r.d.y * m[5] + r.d.z * m[6];
+          dz = r.d.x * m[8] + r.d.y * m[9] + r.d.z * m[10];
+          ox = h[0];
+          oy = h[1];
+          oz = h[2];
+          cc = h[3];
+        }
+        const double aa = dx * dx + dy * dy + dz * dz;
+        PT_SPHERE_ROOTS(slot);
+      } else {
+        pt_kdouble m = PT_KD(a.recs[slot].invm);
+        const double dz = r.d.x * m[8] + r.d.y * m[9] + r.d.z * m[10];
+        const double oz = PT_KD(&a.hoist[slot])[2];
+        PT_PLANE_HIT(slot);
+      }
+      PT_ANYHIT_EXIT();
+    }
+  }
+  return best;
+}
+
+// OnOff / Flat / PointLight with a perspective camera: 8x8 tiles, culled shape lists.
+template <int RENDERER>
+__global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAVES_SIMPLE, 8))) void pt_tile_kernel(const PtKArgs a) {
+  int S, W, rows_local, npass;
+  {
+    pt_kargs c = cold_args();
+    S = c->S;
+    W = c->W;
+    rows_local = c->rows_local;
+    npass = c->npass;
+  }
+  const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+  const int mbase = wib * npass;  // this wave's slice of pt_lds_masks
+  const int nsamp = S > 0 ? S * S : 1;
+  const int tiles_x = (W + 7) >> 3, tiles_y = (rows_local + 7) >> 3;
+  const int ntiles = tiles_x * tiles_y;
+  const int nwaves = gridDim.x * (PT_BLOCK / 64);
+  unsigned long long nrays = 0;
+  for (int tile = blockIdx.x * (PT_BLOCK / 64) + wib; tile < ntiles; tile += nwaves) {
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int col = tx * 8 + (lane & 7), lrow = ty * 8 + (lane >> 3);
+    const bool active = col < W && lrow < rows_local;
+    // clamp so that idle lanes of edge tiles stand on a real pixel (they only widen nothing)
+    const int ccol = col < W ? col : W - 1, clrow = lrow < rows_local ? lrow : rows_local - 1;
+    const long long pix = (long long)clrow * W + ccol;
+    int pcol, grow;
+    pixel_coords(pix, pcol, grow);
+
+    // ---- cull: one bounding sphere per lane per pass -> ballot -> LDS ----
+    const TileCone tc = tile_cone(pcol, grow, active);
+    for (int p = 0; p < npass; ++p) {
+      const int slot = p * 64 + lane;
+      bool keep = false;
+      if (slot < a.n_shapes) keep = cone_keeps(tc, a.bounds[slot]);
+      const unsigned long long m = __ballot(keep);
+      if (lane == 0) pt_lds_masks[mbase + p] = m;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    Pcg pcg;
+    unsigned long long gpix = 0;
+    if (S > 0) {
+      pt_kargs c = cold_args();
+      gpix = (unsigned long long)grow * c->W + pcol;
+      if (c->pcg_mode == PT_PCG_PIXEL) pcg_seed(pcg, c->s0, c->q0 + gpix);
+    }
+    V3 cum = {0.0, 0.0, 0.0};
+    for (int s = 0; s < nsamp; ++s) {
+      double up = 0.5, vp = 0.5;
+      if (S > 0) {  // imagetracer.py:86-93
+        pt_kargs c = cold_args();
+        if (c->pcg_mode == PT_PCG_SAMPLE) pcg_seed(pcg, c->s0, c->q0 + gpix * (unsigned)nsamp + (unsigned)s);
+        const int sr = s / S, sc = s - sr * S;
+        up = ((double)sc + pcg_float(pcg)) / (double)S;
+        vp = ((double)sr + pcg_float(pcg)) / (double)S;
+      }
+      const Ray ray = primary_ray(pcol, grow, up, vp);
+      double best_t;
+      const int hit = world_query_tile<RENDERER == PT_RENDERER_ONOFF>(a, ray, mbase, npass, best_t, active);
+      if (active) nrays++;
+      V3 c;
+      {
+        pt_kargs ca = cold_args();
+        c.x = ca->bg[0];
+        c.y = ca->bg[1];
+        c.z = ca->bg[2];
+      }
+      if (RENDERER == PT_RENDERER_ONOFF) {  // render.py:52-53
+        if (hit >= 0) {
+          pt_kargs ca = cold_args();
+          c.x = ca->onoff[0];
+          c.y = ca->onoff[1];
+          c.z = ca->onoff[2];
+        }
+      } else {  // render.py:65-74
+        if (hit >= 0) {
+          const PtShapeAux *ax = cold_args()->aux + hit;
+          Hit h;
+          h.u = 0.0;
+          h.v = 0.0;
+          if (ax->needs_uv) hit_details(a, ray, best_t, hit, h, true);
+          const V3 p1 = brdf_pigment(a, ax, h.u, h.v);
+          const V3 p2 = emitted_pigment(a, ax, h.u, h.v);
+          c.x = p1.x + p2.x;
+          c.y = p1.y + p2.y;
+          c.z = p1.z + p2.z;
+        }
+      }
+      if (S > 0) {
+        cum.x = cum.x + c.x;
+        cum.y = cum.y + c.y;
+        cum.z = cum.z + c.z;
+      } else {
+        cum = c;
+      }
+    }
+    if (S > 0) {  // imagetracer.py:99-101
+      const double k = 1.0 / (double)(S * S);
+      cum.x = cum.x * k;
+      cum.y = cum.y * k;
+      cum.z = cum.z * k;
+    }
+    if (active) store_pixel(pix, cum);
+    __builtin_amdgcn_wave_barrier();  // the next tile overwrites this wave's mask slice
   }
   add_ray_count(nrays);
 }
@@ -761,8 +1010,8 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAV
     // ---- the convergent hot loop: one world query for this lane's current ray (depth = sp) ----
     // (max_depth < 0 never reaches the device: the frame is black, the host clears it)
     const bool query = alive;
-    double best_t = INFINITY;
-    const int hit = world_query<false, false>(a, ray, best_t, query);
+    double best_t;
+    const int hit = world_query<false, false>(a, ray, INFINITY, best_t, query);
     if (query) {
       nrays++;
       if (hit < 0) {  // render.py:103-105

@@ -64,6 +64,13 @@ struct alignas(64) PtHoistDiag {
 };
 static_assert(sizeof(PtHoistDiag) == 64, "PtHoistDiag must be 64 B");
 
+// World-space bounding sphere of a shape (centre = M*0, radius >= largest singular value of M's 3x3
+// block), used only to REJECT shapes a whole 8x8-pixel tile of primary rays cannot touch; every shape
+// that survives still goes through the exact reference arithmetic.  r < 0: never rejected (planes).
+struct alignas(32) PtBound {
+  double cx, cy, cz, r;
+};
+
 // Per-shape constants of the primary rays of a perspective camera (all share one origin):
 // o' = invm * origin and c = |o'|^2 - 1, computed in the reference's operation order by
 // pt_prep_hoist so the hoisted loop reproduces the per-ray arithmetic bit for bit.
@@ -77,6 +84,7 @@ struct PtKArgs {
   const PtHoist *hoist;
   const PtDiagRec *diag;            // [n_diag], parallel to recs[0..n_diag)
   const PtHoistDiag *hoist_diag;    // [n_diag]
+  const PtBound *bounds;            // [n_shapes], slot order
   const PtLight *lights;
   const PtTex *tex;
   const double *tex_data;
@@ -90,6 +98,8 @@ struct PtKArgs {
   int n_diag;                      // recs[0..n_diag) are the scale+translate spheres
   int nthreads;                    // grid * block
   int frame_doubles;               // fields per stack frame
+  int rows_local;                  // image rows this rank renders
+  int npass;                       // ceil(n_shapes / 64): culling passes per tile
   // camera (camera.py)
   int cam_kind;
   double cam_m[12];

@@ -46,6 +46,7 @@ struct pt_scene {
   PtHoist *hoist = nullptr;
   PtDiagRec *diag = nullptr;
   PtHoistDiag *hoist_diag = nullptr;
+  PtBound *bounds = nullptr;
   int n_diag = 0;
   PtLight *lights = nullptr;
   PtTex *tex = nullptr;
@@ -152,6 +153,7 @@ extern "C" void pt_scene_free(pt_scene *s) {
   (void)hipFree(s->hoist);
   (void)hipFree(s->diag);
   (void)hipFree(s->hoist_diag);
+  (void)hipFree(s->bounds);
   (void)hipFree(s->lights);
   (void)hipFree(s->tex);
   (void)hipFree(s->tex_data);
@@ -291,7 +293,48 @@ extern "C" int pt_scene_upload(const pt_scene_desc *d, int device, pt_scene **ou
     g.t[2] = im[11];
     g.tnz = (im[3] != 0.0 ? 1 : 0) | (im[7] != 0.0 ? 2 : 0) | (im[11] != 0.0 ? 4 : 0);
   }
+  // bounding spheres for tile culling: radius = a rigorous upper bound of the spectral norm of M's 3x3 block
+  std::vector<PtBound> bounds(n);
+  for (int slot = 0; slot < n; ++slot) {
+    PtBound &b = bounds[slot];
+    const double *m = aux[slot].m;
+    b.cx = m[3];
+    b.cy = m[7];
+    b.cz = m[11];
+    b.r = -1.0;
+    if (recs[slot].kind == PT_SHAPE_SPHERE) {
+      double A[3][3];
+      for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+          A[i][j] = 0.0;
+          for (int k = 0; k < 3; ++k) A[i][j] += m[k * 4 + i] * m[k * 4 + j];
+        }
+      // Gershgorin: lambda_max(M^T M) <= max_i sum_j |(M^T M)_ij|  (exact for scale/rotation blocks)
+      double lam = 0.0;
+      for (int i = 0; i < 3; ++i)
+        lam = std::max(lam, std::fabs(A[i][0]) + std::fabs(A[i][1]) + std::fabs(A[i][2]));
+      // The exact test uses invm, the bound uses m: check that m really inverts invm (the reference
+      // stores both, transformations.py:48-56) and widen the radius by the residual; else never cull.
+      const double *im = recs[slot].invm;
+      double resid = 0.0;
+      for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) {
+          double e = (i == j) ? -1.0 : 0.0;
+          for (int k = 0; k < 3; ++k) e += im[i * 4 + k] * m[k * 4 + j];
+          resid = std::max(resid, std::fabs(e));
+        }
+        double e = im[i * 4 + 3];
+        for (int k = 0; k < 3; ++k) e += im[i * 4 + k] * m[k * 4 + 3];
+        resid = std::max(resid, std::fabs(e));
+      }
+      const double r = std::sqrt(lam) * (1.0 + 1e-9 + 16.0 * resid);
+      const bool finite = std::isfinite(r) && std::isfinite(b.cx) && std::isfinite(b.cy) &&
+                          std::isfinite(b.cz) && resid < 1e-6;
+      b.r = finite ? r : -1.0;
+    }
+  }
   UP(upload(&s->recs, recs));
+  UP(upload(&s->bounds, bounds));
   UP(upload(&s->diag, diag));
   {
     std::vector<PtHoistDiag> hd(std::max(s->n_diag, 1));
@@ -368,6 +411,7 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
   a.hoist = s->hoist;
   a.diag = s->diag;
   a.hoist_diag = s->hoist_diag;
+  a.bounds = s->bounds;
   a.n_diag = s->n_diag;
   a.lights = s->lights;
   a.tex = s->tex;
@@ -400,6 +444,8 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
   }
   s->last_stream = st;
   const int rows = pt_rows_for_rank(p);
+  a.rows_local = rows;
+  a.npass = (s->n_shapes + 63) / 64;
   a.npix = (long long)rows * p->width;
   s->stats.n_pixels = (uint64_t)a.npix;
   if (a.npix == 0) return PT_OK;
@@ -414,10 +460,20 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
     const int wg_per_cu = env_wg > 0 ? env_wg : 3;
     cap = (long long)s->n_cu * wg_per_cu;
   }
-  const int grid = (int)std::max<long long>(1, std::min(want, cap));
+  const bool hoist = cam->kind == PT_CAMERA_PERSPECTIVE && p->renderer != PT_RENDERER_PATHTRACER && s->n_shapes > 0;
+  // 8x8 tiles with culled shape lists: primary rays of a perspective camera (OnOff, Flat)
+  static const int env_cull = getenv("PTRACE_CULL") ? atoi(getenv("PTRACE_CULL")) : 1;
+  const bool tile = hoist && env_cull != 0 && s->n_shapes >= 4 &&
+                    (p->renderer == PT_RENDERER_ONOFF || p->renderer == PT_RENDERER_FLAT);
+  int grid = (int)std::max<long long>(1, std::min(want, cap));
+  if (tile) {
+    const long long wave_tiles = (long long)((p->width + 7) / 8) * ((rows + 7) / 8);
+    grid = (int)std::max<long long>(1, std::min<long long>((wave_tiles + 3) / 4, cap));
+  }
   a.nthreads = grid * PT_BLOCK;
   s->stats.grid = grid;
   s->stats.block = PT_BLOCK;
+  s->stats.lds_bytes = 0;
 
   if (s->count_rays) {
     if (grid > s->ray_partials_n) {
@@ -431,7 +487,6 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
     a.ray_counter = s->ray_partials;
   }
 
-  const bool hoist = cam->kind == PT_CAMERA_PERSPECTIVE && p->renderer != PT_RENDERER_PATHTRACER && s->n_shapes > 0;
   if (hoist && !(s->hoist_valid && s->hoist_stream == st && memcmp(&s->hoist_cam, cam, sizeof(pt_camera)) == 0)) {
     V3 o = {-cam->screen_distance, 0.0, 0.0};
     // camera.py:116-124: origin (-d, 0, 0) through the camera transformation, reference order
@@ -478,6 +533,14 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
 
   const bool prof = s->timing && s->profiling && (size_t)(2 * s->prof_used + 1) < s->prof.size();
   if (s->timing) HIP_TRY(hipEventRecord(prof ? s->prof[2 * s->prof_used] : s->ev0, st));
+  if (tile) {
+    const size_t lds = (size_t)4 * a.npass * sizeof(unsigned long long);
+    s->stats.lds_bytes = (int)lds;
+    if (p->renderer == PT_RENDERER_ONOFF)
+      hipLaunchKernelGGL((pt_tile_kernel<PT_RENDERER_ONOFF>), dim3(grid), dim3(PT_BLOCK), lds, st, a);
+    else
+      hipLaunchKernelGGL((pt_tile_kernel<PT_RENDERER_FLAT>), dim3(grid), dim3(PT_BLOCK), lds, st, a);
+  } else
   switch (p->renderer) {
     case PT_RENDERER_ONOFF:
       if (hoist)
