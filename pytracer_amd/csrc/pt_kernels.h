@@ -706,47 +706,70 @@ PT_DEV V3 primary_dir_at(double x, double y) {
   return xf_vec(c->cam_m, d);
 }
 
+// The cone and the rejection test run in fp32 (sqrt/rcp are single instructions there) with explicit
+// conservative margins: every rounding error of the fp32 evaluation (<~1e-6 relative, plus the
+// absolute error of C - O for large coordinates) is covered by widening the cone by 2e-6 in cos and
+// the test by 1e-5*L + eps_abs.  The margin only ever KEEPS more shapes; it never touches the exact
+// fp64 arithmetic the survivors go through.
 struct TileCone {
-  V3 apex, axis;
-  double cos_t, sin_t;  // half-angle
-  bool all;             // cone wider than 90 degrees: keep everything
+  float ox, oy, oz;  // apex
+  float ax, ay, az;  // unit axis
+  float cos_t, sin_t;
+  float oabs;        // max |apex component| (error scale of C - O)
+  bool all;          // wide cone / degenerate: keep everything
 };
 
-PT_DEV TileCone tile_cone(int col, int grow, bool active) {
+// Rows of the tile are [grow0, grow1] (global image rows, inclusive), columns [x0, x1): the tile's
+// pixels (all jitter samples included) lie inside the rectangle [x0, x1] x [grow0, grow1 + 1] of the
+// image plane; primary directions are affine in image position, so the convex cone spanned by the
+// four corner rays contains every ray of the tile.
+PT_DEV TileCone tile_cone(int x0, int x1, int grow0, int grow1) {
   TileCone tc;
+  const int lane = threadIdx.x & 63;
   {
     pt_kargs c = cold_args();
     const V3 o = {-c->cam_dist, 0.0, 0.0};
-    tc.apex = xf_point(c->cam_m, o);
+    const V3 apex = xf_point(c->cam_m, o);
+    tc.ox = (float)apex.x;
+    tc.oy = (float)apex.y;
+    tc.oz = (float)apex.z;
+    tc.oabs = fmaxf(fmaxf(fabsf(tc.ox), fabsf(tc.oy)), fabsf(tc.oz));
   }
-  const V3 d00 = unit3(primary_dir_at((double)col, (double)grow));
-  const V3 d10 = unit3(primary_dir_at((double)col + 1.0, (double)grow));
-  const V3 d01 = unit3(primary_dir_at((double)col, (double)grow + 1.0));
-  const V3 d11 = unit3(primary_dir_at((double)col + 1.0, (double)grow + 1.0));
-  const double wgt = active ? 1.0 : 0.0;
-  V3 sum = {wave_sum(wgt * (d00.x + d11.x)), wave_sum(wgt * (d00.y + d11.y)), wave_sum(wgt * (d00.z + d11.z))};
-  tc.axis = unit3(sum);
-  double cmin = fmin(fmin(dot3(tc.axis, d00), dot3(tc.axis, d10)), fmin(dot3(tc.axis, d01), dot3(tc.axis, d11)));
-  cmin = wave_min(active ? cmin : 1.0);
-  tc.cos_t = cmin;
-  tc.all = !(cmin > 1e-3);  // also catches NaN
-  tc.sin_t = sqrt(fmax(0.0, 1.0 - cmin * cmin));
+  const double y0 = (double)grow0, y1 = (double)grow1 + 1.0;
+  const V3 dc = primary_dir_at(0.5 * ((double)x0 + (double)x1), 0.5 * (y0 + y1));
+  // lane k computes corner k & 3; the min over lanes 0..3 is the min over the whole wave
+  const V3 dk = primary_dir_at((lane & 1) ? (double)x1 : (double)x0, (lane & 2) ? y1 : y0);
+  const float cx = (float)dc.x, cy = (float)dc.y, cz = (float)dc.z;
+  const float rc = __frsqrt_rn(cx * cx + cy * cy + cz * cz);
+  tc.ax = cx * rc;
+  tc.ay = cy * rc;
+  tc.az = cz * rc;
+  const float kx = (float)dk.x, ky = (float)dk.y, kz = (float)dk.z;
+  const float rk = __frsqrt_rn(kx * kx + ky * ky + kz * kz);
+  float cs = (tc.ax * kx + tc.ay * ky + tc.az * kz) * rk;
+  cs = fminf(cs, __shfl_xor(cs, 1, 64));
+  cs = fminf(cs, __shfl_xor(cs, 2, 64));
+  cs -= 2e-6f;
+  tc.all = !(cs > 0.05f);  // also catches NaN
+  tc.cos_t = cs;
+  tc.sin_t = __fsqrt_rn(fmaxf(0.0f, 1.0f - cs * cs)) * (1.0f + 1e-5f) + 1e-7f;
   return tc;
 }
 
 // may the bounding sphere touch the cone?  (conservative: true when in doubt)
-PT_DEV bool cone_keeps(const TileCone &tc, const PtBound &b) {
-  if (tc.all || !(b.r >= 0.0)) return true;
-  const V3 v = {b.cx - tc.apex.x, b.cy - tc.apex.y, b.cz - tc.apex.z};
-  const double L2 = dot3(v, v);
-  const double L = sqrt(L2);
-  const double R = b.r * (1.0 + 1e-6);
+PT_DEV bool cone_keeps(const TileCone &tc, float4 b) {
+  if (tc.all || !(b.w >= 0.0f)) return true;
+  const float vx = b.x - tc.ox, vy = b.y - tc.oy, vz = b.z - tc.oz;
+  const float eps_abs = 1e-6f * (fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fabsf(b.z)) + tc.oabs);
+  const float L = __fsqrt_rn(vx * vx + vy * vy + vz * vz);
+  const float R = b.w * (1.0f + 1e-5f) + eps_abs;
   if (!(L > R)) return true;  // apex inside the sphere (or NaN)
-  const double sin_a = R / L;
+  const float sin_a = R / L;
   if (!(sin_a < tc.cos_t)) return true;  // theta + alpha >= 90 degrees
-  const double cos_a = sqrt(1.0 - sin_a * sin_a);
-  const double cos_sum = tc.cos_t * cos_a - tc.sin_t * sin_a;  // cos(theta + alpha), both < 90 degrees
-  return !(dot3(v, tc.axis) < L * (cos_sum - 1e-6));
+  const float cos_a = __fsqrt_rn(fmaxf(0.0f, 1.0f - sin_a * sin_a));
+  const float cos_sum = tc.cos_t * cos_a - tc.sin_t * sin_a;  // cos(theta + alpha), both < 90 degrees
+  const float lhs = vx * tc.ax + vy * tc.ay + vz * tc.az;
+  return !(lhs < L * cos_sum - (1e-5f * L + 2.0f * eps_abs));
 }
 
 // The survivor masks live in LDS and are always addressed through this array (never through a generic
@@ -834,11 +857,17 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAV
     pixel_coords(pix, pcol, grow);
 
     // ---- cull: one bounding sphere per lane per pass -> ballot -> LDS ----
-    const TileCone tc = tile_cone(pcol, grow, active);
+    int gx0, gr0, gx1, gr1;  // tile rectangle: columns [tx*8, ..), global rows of its first/last local row
+    pixel_coords((long long)(ty * 8) * W + tx * 8, gx0, gr0);
+    {
+      const int last_lrow = (ty * 8 + 7 < rows_local) ? ty * 8 + 7 : rows_local - 1;
+      pixel_coords((long long)last_lrow * W + tx * 8, gx1, gr1);
+    }
+    const TileCone tc = tile_cone(tx * 8, (tx * 8 + 8 < W) ? tx * 8 + 8 : W, gr0, gr1);
     for (int p = 0; p < npass; ++p) {
       const int slot = p * 64 + lane;
       bool keep = false;
-      if (slot < a.n_shapes) keep = cone_keeps(tc, a.bounds[slot]);
+      if (slot < a.n_shapes) keep = cone_keeps(tc, a.bounds[slot]);  // 16 B per lane, coalesced
       const unsigned long long m = __ballot(keep);
       if (lane == 0) pt_lds_masks[mbase + p] = m;
     }

@@ -10,6 +10,7 @@
 //   PtShapeAux (256 B)  — what only the CLOSEST hit needs: the forward transform and materials.
 //                         Gathered per lane after the loop.
 #pragma once
+#include <hip/hip_runtime.h>
 #include <stdint.h>
 
 struct alignas(128) PtShapeRec {
@@ -64,12 +65,10 @@ struct alignas(64) PtHoistDiag {
 };
 static_assert(sizeof(PtHoistDiag) == 64, "PtHoistDiag must be 64 B");
 
-// World-space bounding sphere of a shape (centre = M*0, radius >= largest singular value of M's 3x3
-// block), used only to REJECT shapes a whole 8x8-pixel tile of primary rays cannot touch; every shape
-// that survives still goes through the exact reference arithmetic.  r < 0: never rejected (planes).
-struct alignas(32) PtBound {
-  double cx, cy, cz, r;
-};
+// World-space bounding sphere of a shape as float4 (cx, cy, cz, r): centre = M*0, r >= largest singular
+// value of M's 3x3 block, inflated for the fp32 rounding of the centre.  Used only to REJECT shapes a
+// whole 8x8-pixel tile of primary rays cannot touch; every shape that survives still goes through the
+// exact reference arithmetic.  r < 0: never rejected (planes, non-finite or inconsistent transforms).
 
 // Per-shape constants of the primary rays of a perspective camera (all share one origin):
 // o' = invm * origin and c = |o'|^2 - 1, computed in the reference's operation order by
@@ -84,7 +83,7 @@ struct PtKArgs {
   const PtHoist *hoist;
   const PtDiagRec *diag;            // [n_diag], parallel to recs[0..n_diag)
   const PtHoistDiag *hoist_diag;    // [n_diag]
-  const PtBound *bounds;            // [n_shapes], slot order
+  const float4 *bounds;             // [n_shapes], slot order: (cx, cy, cz, r)
   const PtLight *lights;
   const PtTex *tex;
   const double *tex_data;

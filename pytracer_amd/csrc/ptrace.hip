@@ -46,7 +46,7 @@ struct pt_scene {
   PtHoist *hoist = nullptr;
   PtDiagRec *diag = nullptr;
   PtHoistDiag *hoist_diag = nullptr;
-  PtBound *bounds = nullptr;
+  float4 *bounds = nullptr;
   int n_diag = 0;
   PtLight *lights = nullptr;
   PtTex *tex = nullptr;
@@ -294,9 +294,12 @@ extern "C" int pt_scene_upload(const pt_scene_desc *d, int device, pt_scene **ou
     g.tnz = (im[3] != 0.0 ? 1 : 0) | (im[7] != 0.0 ? 2 : 0) | (im[11] != 0.0 ? 4 : 0);
   }
   // bounding spheres for tile culling: radius = a rigorous upper bound of the spectral norm of M's 3x3 block
-  std::vector<PtBound> bounds(n);
+  struct Bound64 {
+    double cx, cy, cz, r;
+  };
+  std::vector<float4> bounds(n);
   for (int slot = 0; slot < n; ++slot) {
-    PtBound &b = bounds[slot];
+    Bound64 b;
     const double *m = aux[slot].m;
     b.cx = m[3];
     b.cy = m[7];
@@ -332,6 +335,15 @@ extern "C" int pt_scene_upload(const pt_scene_desc *d, int device, pt_scene **ou
                           std::isfinite(b.cz) && resid < 1e-6;
       b.r = finite ? r : -1.0;
     }
+    // to fp32: widen r by the rounding of the centre (<= 2^-24 relative per component) and of r itself
+    float4 f;
+    f.x = (float)b.cx;
+    f.y = (float)b.cy;
+    f.z = (float)b.cz;
+    const double cabs = std::max(std::fabs(b.cx), std::max(std::fabs(b.cy), std::fabs(b.cz)));
+    const double rw = b.r * (1.0 + 1e-6) + 2e-7 * cabs;
+    f.w = (b.r >= 0.0 && std::isfinite(rw) && rw < 1e37 && cabs < 1e37) ? (float)rw * (1.0f + 1e-6f) : -1.0f;
+    bounds[slot] = f;
   }
   UP(upload(&s->recs, recs));
   UP(upload(&s->bounds, bounds));

@@ -154,6 +154,60 @@ def test_c5_many_spheres_flat_vs_oracle(dev, oracle):
     assert util.bits_equal(out, ora)
 
 
+def _cluster_world(n, spread, seed, rotated=False):
+    """n small spheres bunched around the view axis (many survivors per tile: exercises survivor-mask
+    bits >= 31 and several culling passes), optionally with non-diagonal transforms, plus duplicates."""
+    from pytracer_amd import hostmodel as hm
+
+    g = hm.PCG(seed, 3)
+    r = g.random_float
+    w = hm.World()
+    w.add_shape(hm.Sphere(hm.scaling(hm.Vec(60.0, 60.0, 60.0)),
+                          hm.Material(hm.DiffuseBRDF(hm.UniformPigment(hm.BLACK)), hm.UniformPigment(hm.Color(0.2, 0.3, 0.4)))))
+    for i in range(n):
+        rad = 0.03 + 0.1 * r()
+        t = hm.translation(hm.Vec(2.0 + 4.0 * r(), spread * (r() - 0.5), 1.0 + spread * (r() - 0.5)))
+        sc = hm.scaling(hm.Vec(rad, rad * (0.5 + r()), rad))
+        T = t * hm.rotation_z(360 * r()) * hm.rotation_x(360 * r()) * sc if (rotated and i % 3 == 0) else t * sc
+        mat = hm.Material(hm.DiffuseBRDF(hm.UniformPigment(hm.Color(r(), r(), r()))), hm.UniformPigment(hm.Color(r(), r(), r())))
+        w.add_shape(hm.Sphere(T, mat))
+        if i % 17 == 0:  # exact duplicate geometry, different material: the first one must win the tie
+            w.add_shape(hm.Sphere(T, hm.Material(hm.DiffuseBRDF(hm.UniformPigment(hm.Color(9.0, 9.0, 9.0))))))
+    w.add_shape(hm.Plane(hm.translation(hm.Vec(0.0, 0.0, -0.5)),
+                         hm.Material(hm.DiffuseBRDF(hm.CheckeredPigment(hm.Color(0.3, 0.5, 0.1), hm.Color(0.1, 0.2, 0.5), 2)))))
+    return w
+
+
+@pytest.mark.parametrize("n,spread,rotated,W,H,S,renderer", [
+    (120, 0.6, False, 203, 117, 0, abi.RENDERER_FLAT),    # sizes not multiples of 8
+    (120, 0.6, True, 203, 117, 0, abi.RENDERER_ONOFF),
+    (300, 1.5, True, 160, 96, 2, abi.RENDERER_FLAT),       # 5 culling passes, jittered samples
+    (40, 0.2, False, 64, 64, 3, abi.RENDERER_FLAT),
+])
+def test_tile_culling_is_invisible(dev, oracle, n, spread, rotated, W, H, S, renderer):
+    """The culled tile kernel must equal the oracle bit for bit (uniform pigments on the spheres,
+    checkered plane: no libm involved), including ties between duplicated shapes."""
+    from pytracer_amd import flatten, hostmodel as hm
+
+    world = _cluster_world(n, spread, seed=11 + n, rotated=rotated)
+    scene = flatten.flatten_world(world)
+    cam = flatten.flatten_camera(hm.PerspectiveCamera(1.0, W / H, hm.translation(hm.Vec(-1.0, 0.0, 1.0))))
+    par = abi.make_params(W, H, renderer, samples_per_side=S, path_state=5, path_seq=77)
+    ora, n_rays = oracle.render(scene, cam, par, sqr_mode=oracle.SQR_MUL)
+    oracle.set_sqr_mode(oracle.SQR_POW)
+    with dev.DeviceScene(scene) as ds:
+        out = ds.render(cam, par)
+        assert ds.stats().lds_bytes > 0, "expected the tile kernel"
+        assert util.bits_equal(out, ora), f"max rel {util.rel_err(out, ora).max()}"
+        assert ds.stats().n_rays == n_rays
+        # and under an awkward row partition (blocks of 7 rows over 3 ranks)
+        got = np.zeros_like(out)
+        for rank in range(3):
+            p = abi.copy_params(par, n_ranks=3, rank=rank, row_block=7)
+            got[abi.rows_for_rank(H, 7, 3, rank)] = ds.render(cam, p)
+        assert util.bits_equal(got, ora)
+
+
 @pytest.mark.parametrize("n_rays,depth,S,mode", [(1, 3, 4, abi.PCG_PIXEL), (2, 2, 2, abi.PCG_PIXEL),
                                                  (1, 5, 2, abi.PCG_SAMPLE), (3, 3, 0, abi.PCG_PIXEL)])
 def test_c3_pathtracer_vs_oracle(dev, oracle, n_rays, depth, S, mode):
