@@ -34,6 +34,9 @@
 #ifndef PT_WAVES_SIMPLE
 #define PT_WAVES_SIMPLE 4
 #endif
+#ifndef PT_REGION
+#define PT_REGION 8  // path tracer: a wave's region is PT_REGION x PT_REGION pixels
+#endif
 #ifndef PT_WAVES_PATH
 #define PT_WAVES_PATH 3
 #endif
@@ -46,12 +49,13 @@ typedef const __attribute__((address_space(4))) int32_t *pt_kint;
 #define PT_KI(p) ((pt_kint)(const void *)(p))
 
 // Register budget: the argument block is ~90 dwords.  Only the fields the shape loop needs are read
-// as ordinary by-value kernel arguments (they stay in SGPRs); everything else is re-read from the
-// kernarg segment (scalar cache) at its point of use through a laundered pointer, so the compiler
-// cannot hoist those loads to the kernel entry and then spill them inside the hot loop.
+// as ordinary by-value kernel arguments (they stay in SGPRs); everything else is re-read at its point
+// of use from a copy of the block in DEVICE memory (a.cold; scalar cache / L2) through a laundered
+// pointer, so the compiler cannot hoist those loads to the kernel entry and then spill them inside
+// the hot loop.  (Not from the kernarg segment itself: that lives in host memory, ~1.5 us per miss.)
 typedef const __attribute__((address_space(4))) PtKArgs *pt_kargs;
-PT_DEV pt_kargs cold_args() {
-  unsigned long long p = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+PT_DEV pt_kargs cold_args(const PtKArgs &a) {
+  unsigned long long p = (unsigned long long)a.cold;
   asm volatile("" : "+s"(p));
   return (pt_kargs)p;
 }
@@ -328,7 +332,7 @@ PT_DEV int world_query(const PtKArgs &a, const Ray &r, double tmax, double &best
 // it equals what the reference computed for that candidate.
 PT_DEV void hit_details(const PtKArgs &a, const Ray &r, double t, int i, Hit &h, bool need_uv) {
   const PtShapeRec *rec = a.recs + i;
-  const PtShapeAux *ax = cold_args()->aux + i;  // same (grouped) slot order as recs
+  const PtShapeAux *ax = cold_args(a)->aux + i;  // same (grouped) slot order as recs
   double im[12];
 #pragma unroll
   for (int k = 0; k < 12; ++k) im[k] = rec->invm[k];
@@ -376,7 +380,7 @@ PT_DEV V3 pigment_color(const PtKArgs &a, int kind, const double *c1, const doub
     // Python's % 2 is non-negative; (x & 1) is the same parity for negative x in two's complement
     c = ((iu & 1LL) == (iv & 1LL)) ? c1 : c2;
   } else if (kind == PT_PIGMENT_IMAGE) {
-    pt_kargs ca = cold_args();
+    pt_kargs ca = cold_args(a);
     const PtTex *tx = ca->tex + tex;
     const int w = tx->w, hh = tx->h;
     long long col = (long long)(u * (double)w);  // int() truncates toward zero
@@ -426,8 +430,8 @@ PT_DEV Ray scatter_ray(int brdf_kind, Pcg &pcg, V3 incoming, V3 point, V3 n) {
 }
 
 // ---- ImageTracer.fire_ray + Camera.fire_ray (imagetracer.py:48-58; camera.py:59-78, 103-124) -----
-PT_DEV Ray primary_ray(int col, int row, double up, double vp) {
-  pt_kargs c = cold_args();
+PT_DEV Ray primary_ray(const PtKArgs &a, int col, int row, double up, double vp) {
+  pt_kargs c = cold_args(a);
   const double u = ((double)col + up) / (double)c->W;
   const double v = 1.0 - ((double)row + vp) / (double)c->H;
   V3 o, d;
@@ -455,8 +459,8 @@ PT_DEV Ray primary_ray(int col, int row, double up, double vp) {
 }
 
 // local (rank-compact) pixel index -> column and GLOBAL row (pt_params partition)
-PT_DEV void pixel_coords(long long pix, int &col, int &grow) {
-  pt_kargs c = cold_args();
+PT_DEV void pixel_coords(const PtKArgs &a, long long pix, int &col, int &grow) {
+  pt_kargs c = cold_args(a);
   const int W = c->W, rb = c->row_block;
   const int lr = (int)(pix / W);
   col = (int)(pix - (long long)lr * W);
@@ -464,15 +468,15 @@ PT_DEV void pixel_coords(long long pix, int &col, int &grow) {
   grow = (blk * c->n_ranks + c->rank) * rb + (lr - blk * rb);
 }
 
-PT_DEV void store_pixel(long long pix, V3 v) {
-  pt_kargs c = cold_args();
+PT_DEV void store_pixel(const PtKArgs &a, long long pix, V3 v) {
+  pt_kargs c = cold_args(a);
   if (c->out_f32) {
-    float *o = (float *)c->out + pix * 3;
+    float *o = (float *)a.out + pix * 3;
     o[0] = (float)v.x;
     o[1] = (float)v.y;
     o[2] = (float)v.z;
   } else {
-    double *o = (double *)c->out + pix * 3;
+    double *o = (double *)a.out + pix * 3;
     o[0] = v.x;
     o[1] = v.y;
     o[2] = v.z;
@@ -481,8 +485,8 @@ PT_DEV void store_pixel(long long pix, V3 v) {
 
 // Ray accounting without a contended atomic: wave reduction -> LDS -> one plain store per workgroup
 // into a.ray_counter[blockIdx.x]; pt_sum_counts folds the per-workgroup partials afterwards.
-PT_DEV void add_ray_count(unsigned long long n) {
-  unsigned long long *counter = cold_args()->ray_counter;
+PT_DEV void add_ray_count(const PtKArgs &a, unsigned long long n) {
+  unsigned long long *counter = cold_args(a)->ray_counter;
   if (counter) {
     __shared__ unsigned long long partial[PT_BLOCK / 64];
     for (int off = 32; off > 0; off >>= 1) n += __shfl_down(n, off, 64);
@@ -538,18 +542,18 @@ __global__ void pt_prep_hoist(const PtShapeRec *recs, PtHoist *hoist, PtHoistDia
 // ---- OnOff / Flat / PointLight: one world query per sample (+ shadow rays) ----------------------------
 template <int RENDERER, bool HOIST>
 __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAVES_SIMPLE, 8))) void pt_simple_kernel(const PtKArgs a) {
-  const int S = cold_args()->S;
+  const int S = cold_args(a)->S;
   const int nsamp = S > 0 ? S * S : 1;
   unsigned long long nrays = 0;
   for (long long base = (long long)blockIdx.x * PT_BLOCK; base < a.npix; base += a.nthreads) {
     const long long pix = base + threadIdx.x;
     const bool active = pix < a.npix;
     int col = 0, grow = 0;
-    if (active) pixel_coords(pix, col, grow);
+    if (active) pixel_coords(a, pix, col, grow);
     Pcg pcg;
     unsigned long long gpix = 0;
     if (S > 0) {
-      pt_kargs c = cold_args();
+      pt_kargs c = cold_args(a);
       gpix = (unsigned long long)grow * c->W + col;
       if (c->pcg_mode == PT_PCG_PIXEL) pcg_seed(pcg, c->s0, c->q0 + gpix);
     }
@@ -557,33 +561,33 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAV
     for (int s = 0; s < nsamp; ++s) {
       double up = 0.5, vp = 0.5;
       if (S > 0) {  // imagetracer.py:86-93: u drawn first, then v; sub_row outer, sub_col inner
-        pt_kargs c = cold_args();
+        pt_kargs c = cold_args(a);
         if (c->pcg_mode == PT_PCG_SAMPLE) pcg_seed(pcg, c->s0, c->q0 + gpix * (unsigned)nsamp + (unsigned)s);
         const int sr = s / S, sc = s - sr * S;
         up = ((double)sc + pcg_float(pcg)) / (double)S;
         vp = ((double)sr + pcg_float(pcg)) / (double)S;
       }
-      const Ray ray = primary_ray(col, grow, up, vp);
+      const Ray ray = primary_ray(a, col, grow, up, vp);
       double best_t;
       const int hit = world_query<RENDERER == PT_RENDERER_ONOFF, HOIST>(a, ray, INFINITY, best_t, active);
       if (active) nrays++;
       V3 c;
       {
-        pt_kargs ca = cold_args();
+        pt_kargs ca = cold_args(a);
         c.x = ca->bg[0];
         c.y = ca->bg[1];
         c.z = ca->bg[2];
       }
       if (RENDERER == PT_RENDERER_ONOFF) {  // render.py:52-53
         if (hit >= 0) {
-          pt_kargs ca = cold_args();
+          pt_kargs ca = cold_args(a);
           c.x = ca->onoff[0];
           c.y = ca->onoff[1];
           c.z = ca->onoff[2];
         }
       } else if (RENDERER == PT_RENDERER_FLAT) {  // render.py:65-74
         if (hit >= 0) {
-          const PtShapeAux *ax = cold_args()->aux + hit;
+          const PtShapeAux *ax = cold_args(a)->aux + hit;
           Hit h;
           h.u = 0.0;
           h.v = 0.0;
@@ -602,7 +606,7 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAV
         h.n = {0.0, 0.0, 1.0};
         h.u = 0.0;
         h.v = 0.0;
-        pt_kargs ca = cold_args();
+        pt_kargs ca = cold_args(a);
         const PtShapeAux *ax = ca->aux + (hit >= 0 ? hit : 0);
         V3 res = c;
         if (lit) {
@@ -672,9 +676,9 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAV
       cum.y = cum.y * k;
       cum.z = cum.z * k;
     }
-    if (active) store_pixel(pix, cum);
+    if (active) store_pixel(a, pix, cum);
   }
-  add_ray_count(nrays);
+  add_ray_count(a, nrays);
 }
 
 // ---- tile culling for primary rays -------------------------------------------------------------------
@@ -699,8 +703,8 @@ PT_DEV V3 unit3(V3 v) {
   return r;
 }
 // direction of the primary ray through continuous image position (x, y) (perspective camera)
-PT_DEV V3 primary_dir_at(double x, double y) {
-  pt_kargs c = cold_args();
+PT_DEV V3 primary_dir_at(const PtKArgs &a, double x, double y) {
+  pt_kargs c = cold_args(a);
   const double u = x / (double)c->W, v = 1.0 - y / (double)c->H;
   V3 d = {c->cam_dist, (1.0 - 2.0 * u) * c->cam_aspect, 2.0 * v - 1.0};
   return xf_vec(c->cam_m, d);
@@ -723,11 +727,11 @@ struct TileCone {
 // pixels (all jitter samples included) lie inside the rectangle [x0, x1] x [grow0, grow1 + 1] of the
 // image plane; primary directions are affine in image position, so the convex cone spanned by the
 // four corner rays contains every ray of the tile.
-PT_DEV TileCone tile_cone(int x0, int x1, int grow0, int grow1) {
+PT_DEV TileCone tile_cone(const PtKArgs &a, int x0, int x1, int grow0, int grow1) {
   TileCone tc;
   const int lane = threadIdx.x & 63;
   {
-    pt_kargs c = cold_args();
+    pt_kargs c = cold_args(a);
     const V3 o = {-c->cam_dist, 0.0, 0.0};
     const V3 apex = xf_point(c->cam_m, o);
     tc.ox = (float)apex.x;
@@ -736,9 +740,9 @@ PT_DEV TileCone tile_cone(int x0, int x1, int grow0, int grow1) {
     tc.oabs = fmaxf(fmaxf(fabsf(tc.ox), fabsf(tc.oy)), fabsf(tc.oz));
   }
   const double y0 = (double)grow0, y1 = (double)grow1 + 1.0;
-  const V3 dc = primary_dir_at(0.5 * ((double)x0 + (double)x1), 0.5 * (y0 + y1));
+  const V3 dc = primary_dir_at(a, 0.5 * ((double)x0 + (double)x1), 0.5 * (y0 + y1));
   // lane k computes corner k & 3; the min over lanes 0..3 is the min over the whole wave
-  const V3 dk = primary_dir_at((lane & 1) ? (double)x1 : (double)x0, (lane & 2) ? y1 : y0);
+  const V3 dk = primary_dir_at(a, (lane & 1) ? (double)x1 : (double)x0, (lane & 2) ? y1 : y0);
   const float cx = (float)dc.x, cy = (float)dc.y, cz = (float)dc.z;
   const float rc = __frsqrt_rn(cx * cx + cy * cy + cz * cz);
   tc.ax = cx * rc;
@@ -833,7 +837,7 @@ template <int RENDERER>
 __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAVES_SIMPLE, 8))) void pt_tile_kernel(const PtKArgs a) {
   int S, W, rows_local, npass;
   {
-    pt_kargs c = cold_args();
+    pt_kargs c = cold_args(a);
     S = c->S;
     W = c->W;
     rows_local = c->rows_local;
@@ -854,16 +858,16 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAV
     const int ccol = col < W ? col : W - 1, clrow = lrow < rows_local ? lrow : rows_local - 1;
     const long long pix = (long long)clrow * W + ccol;
     int pcol, grow;
-    pixel_coords(pix, pcol, grow);
+    pixel_coords(a, pix, pcol, grow);
 
     // ---- cull: one bounding sphere per lane per pass -> ballot -> LDS ----
     int gx0, gr0, gx1, gr1;  // tile rectangle: columns [tx*8, ..), global rows of its first/last local row
-    pixel_coords((long long)(ty * 8) * W + tx * 8, gx0, gr0);
+    pixel_coords(a, (long long)(ty * 8) * W + tx * 8, gx0, gr0);
     {
       const int last_lrow = (ty * 8 + 7 < rows_local) ? ty * 8 + 7 : rows_local - 1;
-      pixel_coords((long long)last_lrow * W + tx * 8, gx1, gr1);
+      pixel_coords(a, (long long)last_lrow * W + tx * 8, gx1, gr1);
     }
-    const TileCone tc = tile_cone(tx * 8, (tx * 8 + 8 < W) ? tx * 8 + 8 : W, gr0, gr1);
+    const TileCone tc = tile_cone(a, tx * 8, (tx * 8 + 8 < W) ? tx * 8 + 8 : W, gr0, gr1);
     for (int p = 0; p < npass; ++p) {
       const int slot = p * 64 + lane;
       bool keep = false;
@@ -878,7 +882,7 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAV
     Pcg pcg;
     unsigned long long gpix = 0;
     if (S > 0) {
-      pt_kargs c = cold_args();
+      pt_kargs c = cold_args(a);
       gpix = (unsigned long long)grow * c->W + pcol;
       if (c->pcg_mode == PT_PCG_PIXEL) pcg_seed(pcg, c->s0, c->q0 + gpix);
     }
@@ -886,33 +890,33 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAV
     for (int s = 0; s < nsamp; ++s) {
       double up = 0.5, vp = 0.5;
       if (S > 0) {  // imagetracer.py:86-93
-        pt_kargs c = cold_args();
+        pt_kargs c = cold_args(a);
         if (c->pcg_mode == PT_PCG_SAMPLE) pcg_seed(pcg, c->s0, c->q0 + gpix * (unsigned)nsamp + (unsigned)s);
         const int sr = s / S, sc = s - sr * S;
         up = ((double)sc + pcg_float(pcg)) / (double)S;
         vp = ((double)sr + pcg_float(pcg)) / (double)S;
       }
-      const Ray ray = primary_ray(pcol, grow, up, vp);
+      const Ray ray = primary_ray(a, pcol, grow, up, vp);
       double best_t;
       const int hit = world_query_tile<RENDERER == PT_RENDERER_ONOFF>(a, ray, mbase, npass, best_t, active);
       if (active) nrays++;
       V3 c;
       {
-        pt_kargs ca = cold_args();
+        pt_kargs ca = cold_args(a);
         c.x = ca->bg[0];
         c.y = ca->bg[1];
         c.z = ca->bg[2];
       }
       if (RENDERER == PT_RENDERER_ONOFF) {  // render.py:52-53
         if (hit >= 0) {
-          pt_kargs ca = cold_args();
+          pt_kargs ca = cold_args(a);
           c.x = ca->onoff[0];
           c.y = ca->onoff[1];
           c.z = ca->onoff[2];
         }
       } else {  // render.py:65-74
         if (hit >= 0) {
-          const PtShapeAux *ax = cold_args()->aux + hit;
+          const PtShapeAux *ax = cold_args(a)->aux + hit;
           Hit h;
           h.u = 0.0;
           h.v = 0.0;
@@ -938,10 +942,10 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAV
       cum.y = cum.y * k;
       cum.z = cum.z * k;
     }
-    if (active) store_pixel(pix, cum);
+    if (active) store_pixel(a, pix, cum);
     __builtin_amdgcn_wave_barrier();  // the next tile overwrites this wave's mask slice
   }
-  add_ray_count(nrays);
+  add_ray_count(a, nrays);
 }
 
 // ---- PathTracer (render.py:99-139) as a per-lane state machine ----------------------------------------
@@ -965,7 +969,7 @@ PT_DEV double &ws_at(const PathCtx &w, int slot, int field) {
 }
 
 // next pixel for every lane with `need` set; returns -1 when the frame is exhausted
-PT_DEV long long next_pixel(bool need, long long npix) {
+PT_DEV long long next_pixel(const PtKArgs &a, bool need, long long npix) {
   const unsigned long long mask = __ballot(need);
   long long pix = -1;
   if (need) {
@@ -973,7 +977,7 @@ PT_DEV long long next_pixel(bool need, long long npix) {
     const int leader = __ffsll((long long)mask) - 1;
     const int rank = __popcll(mask & ((1ULL << lane) - 1ULL));
     unsigned long long base = 0;
-    if (lane == leader) base = atomicAdd(cold_args()->queue, (unsigned long long)__popcll(mask));
+    if (lane == leader) base = atomicAdd(cold_args(a)->queue, (unsigned long long)__popcll(mask));
     base = __shfl(base, leader, 64);
     const long long p = (long long)(base + rank);
     pix = p < npix ? p : -1;
@@ -981,24 +985,50 @@ PT_DEV long long next_pixel(bool need, long long npix) {
   return pix;
 }
 
+// Two kinds of work alternate inside a wave, each executed only by the lanes that need it and only
+// when enough of them do (the bodies are skipped wave-wide otherwise):
+//   P-step  lanes starting a sample: jitter draws, primary ray, world query, shading of the first
+//           hit.  Most samples end here (the ray leaves the scene or hits an emitter).
+//   S-step  lanes inside a path: deliver the child's radiance up the frame stack / scatter the next
+//           child ray, query it against ALL shapes, shade.
+// Batching S-steps until >= 16 lanes wait keeps the expensive scatter/shade code (fp64 sin, cos,
+// sqrt, div) from running for one or two lanes at a time; regions of pure background never run it.
+//
+// TILED (perspective camera): a wave works through PT_REGION^2-pixel regions; its lanes take the region's
+// pixels dynamically (wave-local counter) and P-steps use the hoisted, culled tile query against the
+// region's survivor masks.  !TILED (orthogonal camera): pixels come from one global queue and P-steps
+// run the full shape loop.
+template <bool TILED>
 __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAVES_PATH, 8))) void pt_path_kernel(const PtKArgs a) {
   PathCtx w;
-  int S, nsamp, N;
+  int S, nsamp, N, W = 0, rows_local = 0, npass = 0, D = 0, rr = 0;
   {
-    pt_kargs c = cold_args();
+    pt_kargs c = cold_args(a);
     w.ws = c->ws;
     w.nthreads = (size_t)c->nthreads;
     w.stride = (size_t)c->frame_doubles * w.nthreads;
     w.gtid = blockIdx.x * PT_BLOCK + threadIdx.x;
     S = c->S;
     N = c->N;
+    W = c->W;
+    rows_local = c->rows_local;
+    npass = c->npass;
+    D = c->D;
+    rr = c->rr;
   }
   nsamp = S > 0 ? S * S : 1;
   const double invN = 1.0 / (double)N;
-  long long pix = next_pixel(true, a.npix);
-  bool alive = pix >= 0;
+  const int lane = threadIdx.x & 63;
+  const int mbase = (threadIdx.x >> 6) * npass;
+  const int regions_x = (W + PT_REGION - 1) / PT_REGION;
+  const int nregions = regions_x * ((rows_local + PT_REGION - 1) / PT_REGION);
+  int region = -1, next_pos = PT_REGION * PT_REGION;  // TILED bookkeeping (wave-uniform)
+  bool exhausted = false;           // !TILED: the global queue is empty
   unsigned long long nrays = 0;
 
+  // lane state.  mode 0: starts a sample at the next P-step; 1: inside a path (S-steps); 2: no pixel
+  int mode = 2;
+  long long pix = -1;
   Pcg pcg;
   pcg.state = 0;
   pcg.inc = 1;
@@ -1008,12 +1038,17 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAV
   ray.o = {0.0, 0.0, 0.0};
   ray.d = {1.0, 0.0, 0.0};
   ray.tmin = 1e-5;
+  // what the last shade() left for the next S-step: a value to deliver, or a child to spawn
+  V3 ret = {0.0, 0.0, 0.0};
+  bool spawn = false;
+  V3 f_wp = {0.0, 0.0, 0.0}, f_n = {0.0, 0.0, 1.0}, f_in = {1.0, 0.0, 0.0};
+  int f_brdf = 0;
 
-  // (re)start: pixel coordinates + seeds + the sample's primary ray
+  // pixel coordinates + seeds + the sample's primary ray (imagetracer.py:86-97)
   auto start_sample = [&]() {
-    pt_kargs c = cold_args();
+    pt_kargs c = cold_args(a);
     if (samp == 0) {
-      pixel_coords(pix, col, grow);
+      pixel_coords(a, pix, col, grow);
       if (c->pcg_mode == PT_PCG_PIXEL) pcg_seed(pcg, c->s0, c->q0 + ((unsigned long long)grow * c->W + col));
     }
     if (c->pcg_mode == PT_PCG_SAMPLE)
@@ -1024,175 +1059,264 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAV
       up = ((double)sc + pcg_float(pcg)) / (double)S;
       vp = ((double)sr + pcg_float(pcg)) / (double)S;
     }
-    ray = primary_ray(col, grow, up, vp);
+    ray = primary_ray(a, col, grow, up, vp);
   };
-  if (alive) start_sample();
 
-  while (__any(alive)) {
-    V3 ret = {0.0, 0.0, 0.0};
-    bool spawn = false;
-    // registers describing the frame just pushed (child 0 is spawned from them)
-    V3 f_wp = {0.0, 0.0, 0.0}, f_n = {0.0, 0.0, 1.0}, f_in = ray.d;
-    int f_brdf = 0;
-    bool need_pixel = false;
-
-    // ---- the convergent hot loop: one world query for this lane's current ray (depth = sp) ----
-    // (max_depth < 0 never reaches the device: the frame is black, the host clears it)
-    const bool query = alive;
-    double best_t;
-    const int hit = world_query<false, false>(a, ray, INFINITY, best_t, query);
-    if (query) {
-      nrays++;
-      if (hit < 0) {  // render.py:103-105
-        pt_kargs c = cold_args();
-        ret.x = c->bg[0];
-        ret.y = c->bg[1];
-        ret.z = c->bg[2];
+  // render.py:103-139 up to (not including) the recursion: sets `ret`, or pushes frame `sp` and asks
+  // for child 0 (`spawn`).  `ray` is the ray that was queried, at depth `sp`.
+  auto shade = [&](int hit, double best_t) {
+    spawn = false;
+    if (hit < 0) {  // render.py:103-105
+      pt_kargs c = cold_args(a);
+      ret.x = c->bg[0];
+      ret.y = c->bg[1];
+      ret.z = c->bg[2];
+      return;
+    }
+    const PtShapeAux *ax = cold_args(a)->aux + hit;
+    V3 hc, em;
+    double lum;
+    Hit h;
+    h.u = 0.0;
+    h.v = 0.0;
+    const bool uv = ax->needs_uv != 0;
+    bool details = false;
+    if (uv) {
+      hit_details(a, ray, best_t, hit, h, true);
+      details = true;
+    }
+    hc = brdf_pigment(a, ax, h.u, h.v);
+    em = emitted_pigment(a, ax, h.u, h.v);
+    lum = max2(max2(hc.x, hc.y), hc.z);
+    if (sp >= rr) {  // render.py:116-123
+      const double q = max2(0.05, 1.0 - lum);
+      if (pcg_float(pcg) > q) {
+        const double k = 1.0 / (1.0 - q);
+        hc.x = hc.x * k;
+        hc.y = hc.y * k;
+        hc.z = hc.z * k;
       } else {
-        const PtShapeAux *ax = cold_args()->aux + hit;
-        Hit h;
-        hit_details(a, ray, best_t, hit, h, ax->needs_uv != 0);
-        V3 hc = brdf_pigment(a, ax, h.u, h.v);
-        const V3 em = emitted_pigment(a, ax, h.u, h.v);
-        const double lum = max2(max2(hc.x, hc.y), hc.z);
-        bool go_on = true;
-        if (sp >= cold_args()->rr) {  // render.py:116-123
-          const double q = max2(0.05, 1.0 - lum);
-          if (pcg_float(pcg) > q) {
-            const double k = 1.0 / (1.0 - q);
-            hc.x = hc.x * k;
-            hc.y = hc.y * k;
-            hc.z = hc.z * k;
-          } else {
-            ret = em;
-            go_on = false;
+        ret = em;
+        return;
+      }
+    }
+    if (!(lum > 0.0)) {  // render.py:139 with cum_radiance = 0
+      ret.x = em.x + 0.0 * invN;
+      ret.y = em.y + 0.0 * invN;
+      ret.z = em.z + 0.0 * invN;
+      return;
+    }
+    // render.py:126-137: push the frame, child 0 is scattered at the next S-step
+    if (!details) hit_details(a, ray, best_t, hit, h, false);
+    ws_at(w, sp, 0) = hc.x;
+    ws_at(w, sp, 1) = hc.y;
+    ws_at(w, sp, 2) = hc.z;
+    ws_at(w, sp, 3) = em.x;
+    ws_at(w, sp, 4) = em.y;
+    ws_at(w, sp, 5) = em.z;
+    if (N > 1) {
+      ws_at(w, sp, 6) = 0.0;
+      ws_at(w, sp, 7) = 0.0;
+      ws_at(w, sp, 8) = 0.0;
+      ws_at(w, sp, 9) = 0.0;
+      ws_at(w, sp, 10) = h.wp.x;
+      ws_at(w, sp, 11) = h.wp.y;
+      ws_at(w, sp, 12) = h.wp.z;
+      ws_at(w, sp, 13) = h.n.x;
+      ws_at(w, sp, 14) = h.n.y;
+      ws_at(w, sp, 15) = h.n.z;
+      ws_at(w, sp, 16) = ray.d.x;
+      ws_at(w, sp, 17) = ray.d.y;
+      ws_at(w, sp, 18) = ray.d.z;
+      ws_at(w, sp, 19) = (double)ax->brdf_kind;
+    }
+    f_wp = h.wp;
+    f_n = h.n;
+    f_in = ray.d;
+    f_brdf = ax->brdf_kind;
+    sp++;
+    spawn = true;
+  };
+
+  // the primary call returned `ret`: one sample done (imagetracer.py:94-104)
+  auto finish_sample = [&]() {
+    if (S > 0) {
+      cum.x = cum.x + ret.x;
+      cum.y = cum.y + ret.y;
+      cum.z = cum.z + ret.z;
+    } else {
+      cum = ret;
+    }
+    mode = 0;
+    if (++samp == nsamp) {
+      if (S > 0) {
+        const double k = 1.0 / (double)(S * S);
+        cum.x = cum.x * k;
+        cum.y = cum.y * k;
+        cum.z = cum.z * k;
+      }
+      store_pixel(a, pix, cum);
+      cum.x = 0.0;
+      cum.y = 0.0;
+      cum.z = 0.0;
+      samp = 0;
+      mode = 2;
+    }
+  };
+
+  for (;;) {
+    // ---- pixels for idle lanes ----
+    if (TILED) {
+      if (next_pos >= PT_REGION * PT_REGION && !__any(mode != 2)) {
+        // next region for this wave: one atomic by lane 0, then the region's cone and survivor masks
+        unsigned rid = 0;
+        if (lane == 0) rid = (unsigned)atomicAdd(cold_args(a)->queue, 1ULL);
+        region = (int)__builtin_amdgcn_readfirstlane((int)rid);
+        if (region >= nregions) break;
+        const int ry = region / regions_x, rx = region - ry * regions_x;
+        int gx0, gr0, gx1, gr1;
+        pixel_coords(a, (long long)(ry * PT_REGION) * W + rx * PT_REGION, gx0, gr0);
+        const int last_lrow = (ry * PT_REGION + PT_REGION - 1 < rows_local) ? ry * PT_REGION + PT_REGION - 1 : rows_local - 1;
+        pixel_coords(a, (long long)last_lrow * W + rx * PT_REGION, gx1, gr1);
+        const TileCone tc = tile_cone(a, rx * PT_REGION, (rx * PT_REGION + PT_REGION < W) ? rx * PT_REGION + PT_REGION : W, gr0, gr1);
+        __builtin_amdgcn_wave_barrier();
+        for (int p = 0; p < npass; ++p) {
+          const int slot = p * 64 + lane;
+          bool keep = false;
+          if (slot < a.n_shapes) keep = cone_keeps(tc, a.bounds[slot]);
+          const unsigned long long m = __ballot(keep);
+          if (lane == 0) pt_lds_masks[mbase + p] = m;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        next_pos = 0;
+      }
+      bool need = mode == 2;  // positions outside the image are skipped
+      while (next_pos < PT_REGION * PT_REGION) {
+        const unsigned long long nm = __ballot(need);
+        if (nm == 0ULL) break;
+        const int pos = next_pos + __popcll(nm & ((1ULL << lane) - 1ULL));
+        next_pos += __popcll(nm);
+        if (need && pos < PT_REGION * PT_REGION) {
+          const int ry = region / regions_x, rx = region - ry * regions_x;
+          const int lx = pos % PT_REGION, ly = pos / PT_REGION;
+          const int pc = rx * PT_REGION + lx, lrow = ry * PT_REGION + ly;
+          if (pc < W && lrow < rows_local) {
+            pix = (long long)lrow * W + pc;
+            mode = 0;
+            need = false;
           }
         }
-        if (go_on) {
-          if (lum > 0.0) {  // render.py:126-137: push the frame, spawn child 0
-            ws_at(w, sp, 0) = hc.x;
-            ws_at(w, sp, 1) = hc.y;
-            ws_at(w, sp, 2) = hc.z;
-            ws_at(w, sp, 3) = em.x;
-            ws_at(w, sp, 4) = em.y;
-            ws_at(w, sp, 5) = em.z;
-            if (N > 1) {
-              ws_at(w, sp, 6) = 0.0;
-              ws_at(w, sp, 7) = 0.0;
-              ws_at(w, sp, 8) = 0.0;
-              ws_at(w, sp, 9) = 0.0;
-              ws_at(w, sp, 10) = h.wp.x;
-              ws_at(w, sp, 11) = h.wp.y;
-              ws_at(w, sp, 12) = h.wp.z;
-              ws_at(w, sp, 13) = h.n.x;
-              ws_at(w, sp, 14) = h.n.y;
-              ws_at(w, sp, 15) = h.n.z;
-              ws_at(w, sp, 16) = ray.d.x;
-              ws_at(w, sp, 17) = ray.d.y;
-              ws_at(w, sp, 18) = ray.d.z;
-              ws_at(w, sp, 19) = (double)ax->brdf_kind;
-            }
-            f_wp = h.wp;
-            f_n = h.n;
-            f_in = ray.d;
-            f_brdf = ax->brdf_kind;
-            sp++;
-            spawn = true;
-          } else {  // render.py:139 with cum_radiance = 0
-            ret.x = em.x + 0.0 * invN;
-            ret.y = em.y + 0.0 * invN;
-            ret.z = em.z + 0.0 * invN;
+      }
+    } else {
+      const bool need = mode == 2 && !exhausted;
+      if (__any(need)) {
+        const long long np = next_pixel(a, need, a.npix);
+        if (need) {
+          if (np >= 0) {
+            pix = np;
+            mode = 0;
           }
         }
+        exhausted = __any(need && np < 0);
+      }
+      if (!__any(mode != 2)) break;
+    }
+
+    const int n_start = __popcll(__ballot(mode == 0));
+    const int n_path = __popcll(__ballot(mode == 1));
+    if (n_start == 0 && n_path == 0) continue;  // TILED: region exhausted, fetch the next one
+    const bool do_p = n_start > 0 && n_path < 48;
+    const bool do_s = n_path >= 16 || (n_path > 0 && !do_p);
+
+    // ---- P-step ----
+    if (do_p) {
+      const bool prim = mode == 0;
+      if (prim) start_sample();
+      double tp = INFINITY;
+      int hp;
+      if (TILED)
+        hp = world_query_tile<false>(a, ray, mbase, npass, tp, prim);
+      else
+        hp = world_query<false, false>(a, ray, INFINITY, tp, prim);
+      if (prim) {
+        nrays++;
+        shade(hp, tp);
+        if (spawn)
+          mode = 1;
+        else
+          finish_sample();
       }
     }
 
-    // ---- unwind: deliver `ret` up the stack / spawn the next child, until a ray needs a query ----
-    bool unwinding = alive;
-    while (unwinding) {
-      if (spawn) {
-        // scatter_ray consumes its draws even when the child is beyond max_depth
-        ray = scatter_ray(f_brdf, pcg, f_in, f_wp, f_n);
-        spawn = false;
-        if (sp > cold_args()->D) {  // render.py:100-101: the child returns black without a world query
-          ret.x = 0.0;
-          ret.y = 0.0;
-          ret.z = 0.0;
-          continue;
-        }
-        break;
-      }
-      if (sp == 0) {  // the primary call returned: one sample done (imagetracer.py:94-104)
-        if (S > 0) {
-          cum.x = cum.x + ret.x;
-          cum.y = cum.y + ret.y;
-          cum.z = cum.z + ret.z;
-        } else {
-          cum = ret;
-        }
-        if (++samp == nsamp) {
-          if (S > 0) {
-            const double k = 1.0 / (double)(S * S);
-            cum.x = cum.x * k;
-            cum.y = cum.y * k;
-            cum.z = cum.z * k;
+    // ---- S-step ----
+    if (do_s) {
+      const bool path = mode == 1;
+      bool have_ray = false;
+      bool unwinding = path;
+      while (unwinding) {
+        if (spawn) {
+          // scatter_ray consumes its draws even when the child is beyond max_depth
+          ray = scatter_ray(f_brdf, pcg, f_in, f_wp, f_n);
+          spawn = false;
+          if (sp > D) {  // render.py:100-101: the child returns black without a world query
+            ret.x = 0.0;
+            ret.y = 0.0;
+            ret.z = 0.0;
+            continue;
           }
-          store_pixel(pix, cum);
-          cum.x = 0.0;
-          cum.y = 0.0;
-          cum.z = 0.0;
-          samp = 0;
-          need_pixel = true;  // refilled below, wave-aggregated
+          have_ray = true;
           break;
         }
-        start_sample();
-        break;
+        if (sp == 0) {
+          finish_sample();
+          break;
+        }
+        // a child of frame sp-1 returned `ret` (render.py:135-137)
+        const int fs = sp - 1;
+        const V3 hc = {ws_at(w, fs, 0), ws_at(w, fs, 1), ws_at(w, fs, 2)};
+        V3 fc = {0.0, 0.0, 0.0};
+        int done = 0;
+        if (N > 1) {
+          fc.x = ws_at(w, fs, 6);
+          fc.y = ws_at(w, fs, 7);
+          fc.z = ws_at(w, fs, 8);
+          done = (int)ws_at(w, fs, 9);
+        }
+        fc.x = fc.x + hc.x * ret.x;
+        fc.y = fc.y + hc.y * ret.y;
+        fc.z = fc.z + hc.z * ret.z;
+        done++;
+        if (done < N) {
+          ws_at(w, fs, 6) = fc.x;
+          ws_at(w, fs, 7) = fc.y;
+          ws_at(w, fs, 8) = fc.z;
+          ws_at(w, fs, 9) = (double)done;
+          f_wp = {ws_at(w, fs, 10), ws_at(w, fs, 11), ws_at(w, fs, 12)};
+          f_n = {ws_at(w, fs, 13), ws_at(w, fs, 14), ws_at(w, fs, 15)};
+          f_in = {ws_at(w, fs, 16), ws_at(w, fs, 17), ws_at(w, fs, 18)};
+          f_brdf = (int)ws_at(w, fs, 19);
+          spawn = true;
+          continue;
+        }
+        // render.py:139
+        ret.x = ws_at(w, fs, 3) + fc.x * invN;
+        ret.y = ws_at(w, fs, 4) + fc.y * invN;
+        ret.z = ws_at(w, fs, 5) + fc.z * invN;
+        sp = fs;
       }
-      // a child of frame sp-1 returned `ret` (render.py:135-137)
-      const int fs = sp - 1;
-      const V3 hc = {ws_at(w, fs, 0), ws_at(w, fs, 1), ws_at(w, fs, 2)};
-      V3 fc = {0.0, 0.0, 0.0};
-      int done = 0;
-      if (N > 1) {
-        fc.x = ws_at(w, fs, 6);
-        fc.y = ws_at(w, fs, 7);
-        fc.z = ws_at(w, fs, 8);
-        done = (int)ws_at(w, fs, 9);
-      }
-      fc.x = fc.x + hc.x * ret.x;
-      fc.y = fc.y + hc.y * ret.y;
-      fc.z = fc.z + hc.z * ret.z;
-      done++;
-      if (done < N) {
-        ws_at(w, fs, 6) = fc.x;
-        ws_at(w, fs, 7) = fc.y;
-        ws_at(w, fs, 8) = fc.z;
-        ws_at(w, fs, 9) = (double)done;
-        f_wp = {ws_at(w, fs, 10), ws_at(w, fs, 11), ws_at(w, fs, 12)};
-        f_n = {ws_at(w, fs, 13), ws_at(w, fs, 14), ws_at(w, fs, 15)};
-        f_in = {ws_at(w, fs, 16), ws_at(w, fs, 17), ws_at(w, fs, 18)};
-        f_brdf = (int)ws_at(w, fs, 19);
-        spawn = true;
-        continue;
-      }
-      // render.py:139
-      ret.x = ws_at(w, fs, 3) + fc.x * invN;
-      ret.y = ws_at(w, fs, 4) + fc.y * invN;
-      ret.z = ws_at(w, fs, 5) + fc.z * invN;
-      sp = fs;
-    }
-
-    // ---- refill: lanes whose pixel is complete take the next one from the queue ----
-    if (__any(need_pixel)) {
-      const long long np = next_pixel(need_pixel, a.npix);
-      if (need_pixel) {
-        pix = np;
-        alive = np >= 0;
-        if (alive) start_sample();
+      if (__any(have_ray)) {
+        double ts;
+        const int hs = world_query<false, false>(a, ray, INFINITY, ts, have_ray);
+        if (have_ray) {
+          nrays++;
+          shade(hs, ts);
+        }
       }
     }
   }
-  add_ray_count(nrays);
+  add_ray_count(a, nrays);
 }
 
 // ---- primitive probe: lets the tests check IEEE exactness of device sqrt / div and measure the ulp

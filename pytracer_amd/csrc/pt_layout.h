@@ -78,6 +78,7 @@ struct alignas(32) PtHoist {
 };
 
 struct PtKArgs {
+  const PtKArgs *cold;              // this same block in device memory (see cold_args())
   const PtShapeRec *recs;
   const PtShapeAux *aux;
   const PtHoist *hoist;

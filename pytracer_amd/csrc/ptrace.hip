@@ -59,6 +59,10 @@ struct pt_scene {
   unsigned long long *ray_partials = nullptr;  // one word per workgroup
   int ray_partials_n = 0;
   unsigned long long *queue = nullptr;  // path-tracer pixel queue head
+  PtKArgs *args_dev = nullptr;          // device copy of the argument block (cold fields)
+  PtKArgs args_last;                    // what args_dev holds
+  bool args_valid = false;
+  hipStream_t args_stream = nullptr;
   unsigned long long *ray_counter_host = nullptr;  // pinned
   hipStream_t stream = nullptr;
   hipStream_t last_stream = nullptr;  // stream of the most recent launch
@@ -162,6 +166,7 @@ extern "C" void pt_scene_free(pt_scene *s) {
   (void)hipFree(s->ray_counter);
   (void)hipFree(s->ray_partials);
   (void)hipFree(s->queue);
+  (void)hipFree(s->args_dev);
   if (s->ray_counter_host) (void)hipHostFree(s->ray_counter_host);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
@@ -369,6 +374,7 @@ extern "C" int pt_scene_upload(const pt_scene_desc *d, int device, pt_scene **ou
   };
   if ((rc = hip_or_free(hipMalloc((void **)&s->ray_counter, sizeof(unsigned long long)), "hipMalloc(counter)"))) return rc;
   if ((rc = hip_or_free(hipMalloc((void **)&s->queue, sizeof(unsigned long long)), "hipMalloc(queue)"))) return rc;
+  if ((rc = hip_or_free(hipMalloc((void **)&s->args_dev, sizeof(PtKArgs)), "hipMalloc(args)"))) return rc;
   if ((rc = hip_or_free(hipHostMalloc((void **)&s->ray_counter_host, sizeof(unsigned long long)), "hipHostMalloc"))) return rc;
   *s->ray_counter_host = 0;
   if ((rc = hip_or_free(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking), "hipStreamCreate"))) return rc;
@@ -472,15 +478,23 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
     const int wg_per_cu = env_wg > 0 ? env_wg : 3;
     cap = (long long)s->n_cu * wg_per_cu;
   }
-  const bool hoist = cam->kind == PT_CAMERA_PERSPECTIVE && p->renderer != PT_RENDERER_PATHTRACER && s->n_shapes > 0;
-  // 8x8 tiles with culled shape lists: primary rays of a perspective camera (OnOff, Flat)
   static const int env_cull = getenv("PTRACE_CULL") ? atoi(getenv("PTRACE_CULL")) : 1;
+  // the tiled path tracer (perspective camera): primary rays use the hoisted, culled tile query
+  const bool path_tiled = p->renderer == PT_RENDERER_PATHTRACER && cam->kind == PT_CAMERA_PERSPECTIVE &&
+                          s->n_shapes > 0 && env_cull != 0;
+  const bool hoist = cam->kind == PT_CAMERA_PERSPECTIVE && s->n_shapes > 0 &&
+                     (p->renderer != PT_RENDERER_PATHTRACER || path_tiled);
+  // 8x8 tiles with culled shape lists: primary rays of a perspective camera (OnOff, Flat)
   const bool tile = hoist && env_cull != 0 && s->n_shapes >= 4 &&
                     (p->renderer == PT_RENDERER_ONOFF || p->renderer == PT_RENDERER_FLAT);
   int grid = (int)std::max<long long>(1, std::min(want, cap));
   if (tile) {
     const long long wave_tiles = (long long)((p->width + 7) / 8) * ((rows + 7) / 8);
     grid = (int)std::max<long long>(1, std::min<long long>((wave_tiles + 3) / 4, cap));
+  }
+  if (path_tiled) {
+    const long long regions = (long long)((p->width + PT_REGION - 1) / PT_REGION) * ((rows + PT_REGION - 1) / PT_REGION);
+    grid = (int)std::max<long long>(1, std::min<long long>((regions + 3) / 4, cap));
   }
   a.nthreads = grid * PT_BLOCK;
   s->stats.grid = grid;
@@ -543,6 +557,18 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
     a.ws = s->ws;
   }
 
+  // the cold half of the argument block is read from device memory: refresh the copy when it changed
+  // (the output pointer stays a by-value argument: double-buffered frames alternate it every launch)
+  a.cold = s->args_dev;
+  PtKArgs cold = a;
+  cold.out = nullptr;
+  if (!(s->args_valid && s->args_stream == st && memcmp(&s->args_last, &cold, sizeof cold) == 0)) {
+    // pageable source: the runtime stages the bytes before returning, so `cold` may go out of scope
+    HIP_TRY(hipMemcpyAsync(s->args_dev, &cold, sizeof cold, hipMemcpyHostToDevice, st));
+    s->args_last = cold;
+    s->args_valid = true;
+    s->args_stream = st;
+  }
   const bool prof = s->timing && s->profiling && (size_t)(2 * s->prof_used + 1) < s->prof.size();
   if (s->timing) HIP_TRY(hipEventRecord(prof ? s->prof[2 * s->prof_used] : s->ev0, st));
   if (tile) {
@@ -573,7 +599,13 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
         hipLaunchKernelGGL((pt_simple_kernel<PT_RENDERER_POINTLIGHT, false>), dim3(grid), dim3(PT_BLOCK), 0, st, a);
       break;
     default:
-      hipLaunchKernelGGL(pt_path_kernel, dim3(grid), dim3(PT_BLOCK), 0, st, a);
+      if (path_tiled) {
+        const size_t lds = (size_t)4 * a.npass * sizeof(unsigned long long);
+        s->stats.lds_bytes = (int)lds;
+        hipLaunchKernelGGL(pt_path_kernel<true>, dim3(grid), dim3(PT_BLOCK), lds, st, a);
+      } else {
+        hipLaunchKernelGGL(pt_path_kernel<false>, dim3(grid), dim3(PT_BLOCK), 0, st, a);
+      }
       break;
   }
   HIP_TRY(hipGetLastError());

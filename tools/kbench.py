@@ -23,6 +23,22 @@ CONFIGS = {
     "c2s2": (32, True, False, 1280, 720, dict(renderer=abi.RENDERER_FLAT, samples_per_side=2)),
     "c3": (32, False, False, 1280, 720, dict(renderer=abi.RENDERER_PATHTRACER, samples_per_side=4, num_of_rays=1,
                                              max_depth=3, rr_limit=3, path_state=45, path_seq=54)),
+    "c3q": (32, False, False, 640, 360, dict(renderer=abi.RENDERER_PATHTRACER, samples_per_side=4, num_of_rays=1,
+                                             max_depth=3, rr_limit=3, path_state=45, path_seq=54)),
+    "c3s1": (32, False, False, 1280, 720, dict(renderer=abi.RENDERER_PATHTRACER, samples_per_side=1, num_of_rays=1,
+                                              max_depth=3, rr_limit=3, path_state=45, path_seq=54)),
+    "c3s2": (32, False, False, 1280, 720, dict(renderer=abi.RENDERER_PATHTRACER, samples_per_side=2, num_of_rays=1,
+                                              max_depth=3, rr_limit=3, path_state=45, path_seq=54)),
+    "c3sample": (32, False, False, 1280, 720, dict(renderer=abi.RENDERER_PATHTRACER, samples_per_side=4, num_of_rays=1,
+                                                  max_depth=3, rr_limit=3, path_state=45, path_seq=54, pcg_mode=abi.PCG_SAMPLE)),
+    "t8s4": (32, False, False, 8, 8, dict(renderer=abi.RENDERER_PATHTRACER, samples_per_side=4, num_of_rays=1,
+                                          max_depth=3, rr_limit=3, path_state=45, path_seq=54)),
+    "t8s1": (32, False, False, 8, 8, dict(renderer=abi.RENDERER_PATHTRACER, samples_per_side=1, num_of_rays=1,
+                                          max_depth=3, rr_limit=3, path_state=45, path_seq=54)),
+    "t8s8": (32, False, False, 8, 8, dict(renderer=abi.RENDERER_PATHTRACER, samples_per_side=8, num_of_rays=1,
+                                          max_depth=3, rr_limit=3, path_state=45, path_seq=54)),
+    "f8s4": (32, False, False, 8, 8, dict(renderer=abi.RENDERER_FLAT, samples_per_side=4)),
+    "f8s8": (32, False, False, 8, 8, dict(renderer=abi.RENDERER_FLAT, samples_per_side=8)),
     "c3n10": (32, False, False, 1280, 720, dict(renderer=abi.RENDERER_PATHTRACER, samples_per_side=1, num_of_rays=10,
                                                 max_depth=3, rr_limit=3, path_state=45, path_seq=54)),
     "c4crop": (256, False, True, 960, 540, dict(renderer=abi.RENDERER_PATHTRACER, samples_per_side=4, num_of_rays=1,
