@@ -1164,7 +1164,14 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAV
     }
   };
 
+#ifdef PT_DEBUG_TIME
+  unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
+#define PT_STAMP(k) do { const unsigned long long tn = __builtin_amdgcn_s_memtime(); tsum[k] += tn - tprev; tprev = tn; } while (0)
+#else
+#define PT_STAMP(k) do { } while (0)
+#endif
   for (;;) {
+    PT_STAMP(7);
     // ---- pixels for idle lanes ----
     if (TILED) {
       if (next_pos >= PT_REGION * PT_REGION && !__any(mode != 2)) {
@@ -1224,6 +1231,7 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAV
       if (!__any(mode != 2)) break;
     }
 
+    PT_STAMP(0);
     const int n_start = __popcll(__ballot(mode == 0));
     const int n_path = __popcll(__ballot(mode == 1));
     if (n_start == 0 && n_path == 0) continue;  // TILED: region exhausted, fetch the next one
@@ -1234,12 +1242,14 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAV
     if (do_p) {
       const bool prim = mode == 0;
       if (prim) start_sample();
+      PT_STAMP(1);
       double tp = INFINITY;
       int hp;
       if (TILED)
         hp = world_query_tile<false>(a, ray, mbase, npass, tp, prim);
       else
         hp = world_query<false, false>(a, ray, INFINITY, tp, prim);
+      PT_STAMP(2);
       if (prim) {
         nrays++;
         shade(hp, tp);
@@ -1248,6 +1258,7 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAV
         else
           finish_sample();
       }
+      PT_STAMP(3);
     }
 
     // ---- S-step ----
@@ -1306,6 +1317,7 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAV
         ret.z = ws_at(w, fs, 5) + fc.z * invN;
         sp = fs;
       }
+      PT_STAMP(4);
       if (__any(have_ray)) {
         double ts;
         const int hs = world_query<false, false>(a, ray, INFINITY, ts, have_ray);
@@ -1314,8 +1326,13 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAV
           shade(hs, ts);
         }
       }
+      PT_STAMP(5);
     }
   }
+#ifdef PT_DEBUG_TIME
+  if ((threadIdx.x & 63) == 0)
+    for (int q = 0; q < 8; ++q) atomicAdd(cold_args(a)->queue + 1 + q, tsum[q]);
+#endif
   add_ray_count(a, nrays);
 }
 

@@ -373,7 +373,7 @@ extern "C" int pt_scene_upload(const pt_scene_desc *d, int device, pt_scene **ou
     return code;
   };
   if ((rc = hip_or_free(hipMalloc((void **)&s->ray_counter, sizeof(unsigned long long)), "hipMalloc(counter)"))) return rc;
-  if ((rc = hip_or_free(hipMalloc((void **)&s->queue, sizeof(unsigned long long)), "hipMalloc(queue)"))) return rc;
+  if ((rc = hip_or_free(hipMalloc((void **)&s->queue, 16 * sizeof(unsigned long long)), "hipMalloc(queue)"))) return rc;
   if ((rc = hip_or_free(hipMalloc((void **)&s->args_dev, sizeof(PtKArgs)), "hipMalloc(args)"))) return rc;
   if ((rc = hip_or_free(hipHostMalloc((void **)&s->ray_counter_host, sizeof(unsigned long long)), "hipHostMalloc"))) return rc;
   *s->ray_counter_host = 0;
@@ -542,7 +542,7 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
   }
   if (p->renderer == PT_RENDERER_PATHTRACER) {
     a.queue = s->queue;
-    HIP_TRY(hipMemsetAsync(s->queue, 0, sizeof(unsigned long long), st));
+    HIP_TRY(hipMemsetAsync(s->queue, 0, 16 * sizeof(unsigned long long), st));
     a.frame_doubles = p->num_of_rays > 1 ? 20 : 6;
     const size_t slots = (size_t)std::max(p->max_depth, 0) + 1;
     const size_t need = slots * a.frame_doubles * (size_t)a.nthreads * sizeof(double);
@@ -752,6 +752,16 @@ extern "C" int pt_profile_end(pt_scene *s, double *total_kernel_ms, int *launche
   *launches = s->prof_used;
   s->profiling = false;
   s->prof_used = 0;
+  return PT_OK;
+}
+
+// debug: the 16 words of the path-tracer queue block (word 0 = queue head, 1..8 = section cycle sums of
+// a -DPT_DEBUG_TIME build)
+extern "C" int pt_debug_read_queue(pt_scene *s, unsigned long long *out16) {
+  if (!s || !out16) return fail(PT_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(out16, s->queue, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   return PT_OK;
 }
 
