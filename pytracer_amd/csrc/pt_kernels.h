@@ -34,6 +34,9 @@
 #ifndef PT_WAVES_SIMPLE
 #define PT_WAVES_SIMPLE 4
 #endif
+#ifndef PT_WAVES_TILE
+#define PT_WAVES_TILE 4
+#endif
 #ifndef PT_REGION
 #define PT_REGION 8  // path tracer: a wave's region is PT_REGION x PT_REGION pixels
 #endif
@@ -833,8 +836,12 @@ PT_DEV int world_query_tile(const PtKArgs &a, const Ray &r, int mbase, int npass
 }
 
 // OnOff / Flat / PointLight with a perspective camera: 8x8 tiles, culled shape lists.
-template <int RENDERER>
-__global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAVES_SIMPLE, 8))) void pt_tile_kernel(const PtKArgs a) {
+// WAVES = waves per SIMD the register allocator must make room for: 4 (128 VGPRs; the compiler spills
+// ~16 loop-invariant registers to scratch once per thread) wins when a tile does a lot of work per
+// thread (several samples, many culling passes); 3 (no spill, no scratch traffic) is as fast for one
+// sample per pixel and keeps the HBM traffic at the algorithmic 12 B/pixel.
+template <int RENDERER, int WAVES>
+__global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) void pt_tile_kernel(const PtKArgs a) {
   int S, W, rows_local, npass;
   {
     pt_kargs c = cold_args(a);
