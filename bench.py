@@ -144,14 +144,20 @@ def main():
         n = world_size
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
+    # (PT_DIST_BACKEND=gloo + fewer GPUs than ranks: rehearsal of the N > 1 path on a one-GPU box)
+    backend = os.environ.get("PT_DIST_BACKEND", "nccl")
+    local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dist = None
     if world_size > 1:
         import torch.distributed as dist  # noqa: F811
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world_size,
-                                device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world_size,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world_size)
 
     W, H = frame_size(n)
     world = scenes.synthetic_world(32, with_plane=True)
@@ -202,6 +208,12 @@ def main():
     kernel_total_ms, kernel_launches = ds.profile_end()
     ds.set_timing(True)
 
+    # N > 1: the frame assembled on rank 0 must be bit-identical to the same frame rendered by one rank
+    gather_check = None
+    if dist is not None and rank == 0:
+        full = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+        ds.render_into(cam, abi.copy_params(par, n_ranks=1, rank=0), full.data_ptr(), full.numel() * 4, None)
+        gather_check = "ok" if torch.equal(full, loop.image()) else "MISMATCH"
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -256,6 +268,8 @@ def main():
                         "algorithmic_bytes_per_launch": alg_bytes},
             },
         }
+        if gather_check is not None:
+            result["gather_check"] = gather_check
         tr = measured_traffic()
         if tr is not None and n == 1:
             result["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
