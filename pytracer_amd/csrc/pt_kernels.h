@@ -128,6 +128,15 @@ PT_DEV V3 normalize3(V3 a) {
   V3 r = {a.x / n, a.y / n, a.z / n};
   return r;
 }
+// ocml's fp64 sin/cos/atan2/acos are polynomial kernels with ~25 double constants each.  Inlined, LICM
+// hoists those constants out of the pixel loops into VGPRs that stay live for the whole kernel (~50
+// registers for code that runs once per bounce at most).  Behind a call they live only in the callee.
+#define PT_NOINLINE static __device__ __attribute__((noinline))
+PT_NOINLINE double pt_sin(double x) { return sin(x); }
+PT_NOINLINE double pt_cos(double x) { return cos(x); }
+PT_NOINLINE double pt_atan2(double y, double x) { return atan2(y, x); }
+PT_NOINLINE double pt_acos(double x) { return acos(x); }
+
 PT_DEV double max2(double a, double b) { return (b > a) ? b : a; }  // Python max(a, b)
 
 // ---- the shape loop: World.ray_intersection (world.py:51-69) ---------------------------------------
@@ -355,11 +364,11 @@ PT_DEV void hit_details(const PtKArgs &a, const Ray &r, double t, int i, Hit &h,
     nn.y = keep ? hp.y : -hp.y;
     nn.z = keep ? hp.z : -hp.z;
     if (need_uv) {  // shapes.py:36-42
-      const double uu = atan2(hp.y, hp.x) / (2.0 * PT_PI);
+      const double uu = pt_atan2(hp.y, hp.x) / (2.0 * PT_PI);
       h.u = (uu >= 0.0) ? uu : uu + 1.0;
       double z = hp.z;  // the reference raises ValueError outside [-1, 1]: clamp
       z = (z > 1.0) ? 1.0 : ((z < -1.0) ? -1.0 : z);
-      h.v = acos(z) / PT_PI;
+      h.v = pt_acos(z) / PT_PI;
     }
   } else {
     nn.x = 0.0;
@@ -415,7 +424,7 @@ PT_DEV Ray scatter_ray(int brdf_kind, Pcg &pcg, V3 incoming, V3 point, V3 n) {
     const double cts = pcg_float(pcg);
     const double ct = sqrt(cts), st = sqrt(1.0 - cts);
     const double phi = 2.0 * PT_PI * pcg_float(pcg);
-    const double cp = cos(phi), sp = sin(phi);
+    const double cp = pt_cos(phi), sp = pt_sin(phi);
     r.d.x = ct * (cp * e1.x) + ct * (sp * e2.x) + st * n.x;
     r.d.y = ct * (cp * e1.y) + ct * (sp * e2.y) + st * n.y;
     r.d.z = ct * (cp * e1.z) + ct * (sp * e2.z) + st * n.z;
@@ -654,8 +663,8 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAV
               bc.z = pc.z * k;
             } else {  // materials.py:164-173
               const V3 out_dir = {-ray.d.x, -ray.d.y, -ray.d.z};
-              const double th_in = acos(dot3(normalize3(h.n), normalize3(in_dir)));
-              const double th_out = acos(dot3(normalize3(h.n), normalize3(out_dir)));
+              const double th_in = pt_acos(dot3(normalize3(h.n), normalize3(in_dir)));
+              const double th_out = pt_acos(dot3(normalize3(h.n), normalize3(out_dir)));
               if (fabs(th_in - th_out) < ax->brdf_param) bc = brdf_pigment(a, ax, h.u, h.v);
             }
             res.x = res.x + bc.x * L[3] * cos_theta * df;
@@ -836,10 +845,8 @@ PT_DEV int world_query_tile(const PtKArgs &a, const Ray &r, int mbase, int npass
 }
 
 // OnOff / Flat / PointLight with a perspective camera: 8x8 tiles, culled shape lists.
-// WAVES = waves per SIMD the register allocator must make room for: 4 (128 VGPRs; the compiler spills
-// ~16 loop-invariant registers to scratch once per thread) wins when a tile does a lot of work per
-// thread (several samples, many culling passes); 3 (no spill, no scratch traffic) is as fast for one
-// sample per pixel and keeps the HBM traffic at the algorithmic 12 B/pixel.
+// WAVES = waves per SIMD the register allocator must make room for.  With the transcendental
+// functions out of line the Flat kernel needs 93 VGPRs: 5 waves per SIMD, no scratch.
 template <int RENDERER, int WAVES>
 __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) void pt_tile_kernel(const PtKArgs a) {
   int S, W, rows_local, npass;

@@ -574,13 +574,10 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
   if (tile) {
     const size_t lds = (size_t)4 * a.npass * sizeof(unsigned long long);
     s->stats.lds_bytes = (int)lds;
-    const bool heavy = p->samples_per_side > 1 || s->n_shapes > 256;  // see pt_tile_kernel's WAVES
     if (p->renderer == PT_RENDERER_ONOFF)
       hipLaunchKernelGGL((pt_tile_kernel<PT_RENDERER_ONOFF, 4>), dim3(grid), dim3(PT_BLOCK), lds, st, a);
-    else if (heavy)
-      hipLaunchKernelGGL((pt_tile_kernel<PT_RENDERER_FLAT, 4>), dim3(grid), dim3(PT_BLOCK), lds, st, a);
     else
-      hipLaunchKernelGGL((pt_tile_kernel<PT_RENDERER_FLAT, 3>), dim3(grid), dim3(PT_BLOCK), lds, st, a);
+      hipLaunchKernelGGL((pt_tile_kernel<PT_RENDERER_FLAT, 4>), dim3(grid), dim3(PT_BLOCK), lds, st, a);
   } else
   switch (p->renderer) {
     case PT_RENDERER_ONOFF:
