@@ -1001,12 +1001,12 @@ PT_DEV long long next_pixel(const PtKArgs &a, bool need, long long npix) {
 
 // Two kinds of work alternate inside a wave, each executed only by the lanes that need it and only
 // when enough of them do (the bodies are skipped wave-wide otherwise):
-//   P-step  lanes starting a sample: jitter draws, primary ray, world query, shading of the first
-//           hit.  Most samples end here (the ray leaves the scene or hits an emitter).
-//   S-step  lanes inside a path: deliver the child's radiance up the frame stack / scatter the next
-//           child ray, query it against ALL shapes, shade.
-// Batching S-steps until >= 16 lanes wait keeps the expensive scatter/shade code (fp64 sin, cos,
-// sqrt, div) from running for one or two lanes at a time; regions of pure background never run it.
+//   P  lanes starting a sample (mode 0): jitter draws, primary ray, query against the survivors.
+//   S  lanes holding a scattered ray (mode 1): query against ALL shapes.
+// Both kinds then share one shade + unwind block (deliver radiance up the frame stack, scatter the
+// next child) which leaves each lane with a ray to query (mode 1), a finished sample (mode 0) or a
+// finished pixel (mode 2).  S queries are batched until >= 16 lanes wait, so the 32..10k-shape loop
+// does not run for one or two lanes at a time; regions of pure background never run it.
 //
 // TILED (perspective camera): a wave works through PT_REGION^2-pixel regions; its lanes take the region's
 // pixels dynamically (wave-local counter) and P-steps use the hoisted, culled tile query against the
@@ -1052,7 +1052,7 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAV
   ray.o = {0.0, 0.0, 0.0};
   ray.d = {1.0, 0.0, 0.0};
   ray.tmin = 1e-5;
-  // what the last shade() left for the next S-step: a value to deliver, or a child to spawn
+  // what shade() hands to the unwind loop of the same step: a value to deliver, or a child to spawn
   V3 ret = {0.0, 0.0, 0.0};
   bool spawn = false;
   V3 f_wp = {0.0, 0.0, 0.0}, f_n = {0.0, 0.0, 1.0}, f_in = {1.0, 0.0, 0.0};
@@ -1252,9 +1252,12 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAV
     const bool do_p = n_start > 0 && n_path < 48;
     const bool do_s = n_path >= 16 || (n_path > 0 && !do_p);
 
-    // ---- P-step ----
+    // ---- queries: primary rays against the region's survivors, scattered rays against everything ----
+    const bool prim = do_p && mode == 0;
+    const bool scat = do_s && mode == 1;
+    double best_t = INFINITY;
+    int hit = -1;
     if (do_p) {
-      const bool prim = mode == 0;
       if (prim) start_sample();
       PT_STAMP(1);
       double tp = INFINITY;
@@ -1263,85 +1266,82 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAV
         hp = world_query_tile<false>(a, ray, mbase, npass, tp, prim);
       else
         hp = world_query<false, false>(a, ray, INFINITY, tp, prim);
-      PT_STAMP(2);
       if (prim) {
-        nrays++;
-        shade(hp, tp);
-        if (spawn)
-          mode = 1;
-        else
-          finish_sample();
+        hit = hp;
+        best_t = tp;
       }
-      PT_STAMP(3);
+      PT_STAMP(2);
     }
-
-    // ---- S-step ----
     if (do_s) {
-      const bool path = mode == 1;
-      bool have_ray = false;
-      bool unwinding = path;
-      while (unwinding) {
-        if (spawn) {
-          // scatter_ray consumes its draws even when the child is beyond max_depth
-          ray = scatter_ray(f_brdf, pcg, f_in, f_wp, f_n);
-          spawn = false;
-          if (sp > D) {  // render.py:100-101: the child returns black without a world query
-            ret.x = 0.0;
-            ret.y = 0.0;
-            ret.z = 0.0;
-            continue;
-          }
-          have_ray = true;
-          break;
-        }
-        if (sp == 0) {
-          finish_sample();
-          break;
-        }
-        // a child of frame sp-1 returned `ret` (render.py:135-137)
-        const int fs = sp - 1;
-        const V3 hc = {ws_at(w, fs, 0), ws_at(w, fs, 1), ws_at(w, fs, 2)};
-        V3 fc = {0.0, 0.0, 0.0};
-        int done = 0;
-        if (N > 1) {
-          fc.x = ws_at(w, fs, 6);
-          fc.y = ws_at(w, fs, 7);
-          fc.z = ws_at(w, fs, 8);
-          done = (int)ws_at(w, fs, 9);
-        }
-        fc.x = fc.x + hc.x * ret.x;
-        fc.y = fc.y + hc.y * ret.y;
-        fc.z = fc.z + hc.z * ret.z;
-        done++;
-        if (done < N) {
-          ws_at(w, fs, 6) = fc.x;
-          ws_at(w, fs, 7) = fc.y;
-          ws_at(w, fs, 8) = fc.z;
-          ws_at(w, fs, 9) = (double)done;
-          f_wp = {ws_at(w, fs, 10), ws_at(w, fs, 11), ws_at(w, fs, 12)};
-          f_n = {ws_at(w, fs, 13), ws_at(w, fs, 14), ws_at(w, fs, 15)};
-          f_in = {ws_at(w, fs, 16), ws_at(w, fs, 17), ws_at(w, fs, 18)};
-          f_brdf = (int)ws_at(w, fs, 19);
-          spawn = true;
-          continue;
-        }
-        // render.py:139
-        ret.x = ws_at(w, fs, 3) + fc.x * invN;
-        ret.y = ws_at(w, fs, 4) + fc.y * invN;
-        ret.z = ws_at(w, fs, 5) + fc.z * invN;
-        sp = fs;
+      double ts;
+      const int hs = world_query<false, false>(a, ray, INFINITY, ts, scat);
+      if (scat) {
+        hit = hs;
+        best_t = ts;
       }
       PT_STAMP(4);
-      if (__any(have_ray)) {
-        double ts;
-        const int hs = world_query<false, false>(a, ray, INFINITY, ts, have_ray);
-        if (have_ray) {
-          nrays++;
-          shade(hs, ts);
-        }
-      }
-      PT_STAMP(5);
     }
+
+    // ---- shade the hit, then unwind: deliver radiance up the stack / scatter the next child, until
+    //      this lane has a ray that needs a query (mode 1) or its sample is complete (mode 0 / 2) ----
+    const bool work = prim || scat;
+    if (work) {
+      nrays++;
+      shade(hit, best_t);
+      mode = 1;
+    }
+    bool unwinding = work;
+    while (unwinding) {
+      if (spawn) {
+        // scatter_ray consumes its draws even when the child is beyond max_depth
+        ray = scatter_ray(f_brdf, pcg, f_in, f_wp, f_n);
+        spawn = false;
+        if (sp > D) {  // render.py:100-101: the child returns black without a world query
+          ret.x = 0.0;
+          ret.y = 0.0;
+          ret.z = 0.0;
+          continue;
+        }
+        break;  // mode 1: queried at the next S-step
+      }
+      if (sp == 0) {
+        finish_sample();  // mode 0 (next sample) or 2 (pixel done)
+        break;
+      }
+      // a child of frame sp-1 returned `ret` (render.py:135-137)
+      const int fs = sp - 1;
+      const V3 hc = {ws_at(w, fs, 0), ws_at(w, fs, 1), ws_at(w, fs, 2)};
+      V3 fc = {0.0, 0.0, 0.0};
+      int done = 0;
+      if (N > 1) {
+        fc.x = ws_at(w, fs, 6);
+        fc.y = ws_at(w, fs, 7);
+        fc.z = ws_at(w, fs, 8);
+        done = (int)ws_at(w, fs, 9);
+      }
+      fc.x = fc.x + hc.x * ret.x;
+      fc.y = fc.y + hc.y * ret.y;
+      fc.z = fc.z + hc.z * ret.z;
+      done++;
+      if (done < N) {
+        ws_at(w, fs, 6) = fc.x;
+        ws_at(w, fs, 7) = fc.y;
+        ws_at(w, fs, 8) = fc.z;
+        ws_at(w, fs, 9) = (double)done;
+        f_wp = {ws_at(w, fs, 10), ws_at(w, fs, 11), ws_at(w, fs, 12)};
+        f_n = {ws_at(w, fs, 13), ws_at(w, fs, 14), ws_at(w, fs, 15)};
+        f_in = {ws_at(w, fs, 16), ws_at(w, fs, 17), ws_at(w, fs, 18)};
+        f_brdf = (int)ws_at(w, fs, 19);
+        spawn = true;
+        continue;
+      }
+      // render.py:139
+      ret.x = ws_at(w, fs, 3) + fc.x * invN;
+      ret.y = ws_at(w, fs, 4) + fc.y * invN;
+      ret.z = ws_at(w, fs, 5) + fc.z * invN;
+      sp = fs;
+    }
+    PT_STAMP(5);
   }
 #ifdef PT_DEBUG_TIME
   if ((threadIdx.x & 63) == 0)
