@@ -172,6 +172,21 @@ int pt_set_timing(pt_scene *scene, int enable);
  * kernel is launched on; end synchronises and returns the summed kernel time and the launch count. */
 int pt_profile_begin(pt_scene *scene, int capacity);
 int pt_profile_end(pt_scene *scene, double *total_kernel_ms, int *launches);
+/* ---- HdrImage post-processing on the device (main.py:203-213) --------------
+ * `img_dev` is a frame in HBM as pt_render_device leaves it: H*W*3 values of `fmt` (PT_OUT_*), row 0 on
+ * top.  `stream` as in pt_render_device (NULL: the default stream, call returns when done). */
+/* HdrImage.write_pfm payload (hdrimages.py:113-118): W*H*3 float32, bottom row first, little (0) or
+ * big (1) endian, into out_dev (W*H*12 bytes, device).  The ASCII header is the caller's. */
+int pt_image_pack_pfm(int device, const void *img_dev, int fmt, int width, int height, int big_endian,
+                      void *out_dev, void *stream);
+/* HdrImage.average_luminosity (hdrimages.py:120-128) -> *out (host).  Synchronises. */
+int pt_image_average_luminosity(int device, const void *img_dev, int fmt, int width, int height, double delta,
+                                double *out, void *stream);
+/* normalize_image (x * scale, scale = factor / luminosity; hdrimages.py:130-140), optionally clamp_image
+ * (x / (1 + x); :142-146), optionally written back in place, optionally the LDR bytes of write_ldr_image
+ * (int(255 * pow(x, 1/gamma)); :160-166) into rgb8_dev (W*H*3 bytes, row 0 on top; may be NULL). */
+int pt_image_tonemap(int device, void *img_dev, int fmt, int width, int height, double scale, int clamp,
+                     double gamma, unsigned char *rgb8_dev, int write_back, void *stream);
 /* Copy the last error message of the calling thread (NUL-terminated) into buf; returns its length. */
 int pt_last_error(char *buf, size_t n);
 /* Library/ABI version: (major<<16)|minor. */

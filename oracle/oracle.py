@@ -192,3 +192,32 @@ def radiance(scene: abi.FlatScene, params: abi.Params, pcg: Pcg, ray, depth: int
     d = scene.desc()
     lib().pto_radiance(C.byref(d), C.byref(params), pcg.st, _p(r), depth, _p(o), C.byref(n))
     return o, int(n.value)
+
+
+# ---- HdrImage post-processing (next-3) ------------------------------------------------------------------
+def pack_pfm(img: np.ndarray, big_endian: bool = False) -> bytes:
+    a = np.ascontiguousarray(img, dtype=np.float64)
+    h, w = a.shape[:2]
+    out = np.zeros(w * h * 12, dtype=np.uint8)
+    L = lib()
+    L.pto_pack_pfm.argtypes = [_pd, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.pto_pack_pfm(_p(a.reshape(-1)), w, h, int(big_endian), out.ctypes.data_as(C.c_void_p))
+    return out.tobytes()
+
+
+def average_luminosity(img: np.ndarray, delta: float = 1e-10) -> float:
+    a = np.ascontiguousarray(img, dtype=np.float64).reshape(-1)
+    L = lib()
+    L.pto_average_luminosity.restype = C.c_double
+    L.pto_average_luminosity.argtypes = [_pd, C.c_longlong, C.c_double]
+    return float(L.pto_average_luminosity(_p(a), a.size // 3, delta))
+
+
+def tonemap(img: np.ndarray, scale: float, clamp: bool = True, gamma: float = 1.0):
+    """-> (normalized [+clamped] image, LDR bytes [H, W, 3] uint8)"""
+    a = np.array(img, dtype=np.float64, order="C")
+    rgb = np.zeros(a.shape, dtype=np.uint8)
+    L = lib()
+    L.pto_tonemap.argtypes = [_pd, C.c_longlong, C.c_double, C.c_int, C.c_double, C.c_void_p, C.c_int]
+    L.pto_tonemap(_p(a.reshape(-1)), a.size, scale, int(clamp), gamma, rgb.ctypes.data_as(C.c_void_p), 1)
+    return a, rgb

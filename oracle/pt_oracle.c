@@ -785,3 +785,56 @@ void pto_radiance(const pt_scene_desc *s, const pt_params *p, uint64_t pcg_state
   out[2] = c.z;
   if (n_rays) *n_rays = ctx.n_rays;
 }
+
+/* ---- HdrImage post-processing ----------------------------------------------*/
+/* hdrimages.py:113-118: float32 payload, bottom row first; struct.pack("<f" / ">f") */
+void pto_pack_pfm(const double *img, int W, int H, int big_endian, unsigned char *out) {
+  size_t k = 0;
+  for (int y = H - 1; y >= 0; --y)
+    for (int x = 0; x < W; ++x)
+      for (int c = 0; c < 3; ++c) {
+        float f = (float)img[((size_t)y * W + x) * 3 + c];
+        unsigned char b[4];
+        memcpy(b, &f, 4); /* host is little endian */
+        if (big_endian) {
+          out[k++] = b[3];
+          out[k++] = b[2];
+          out[k++] = b[1];
+          out[k++] = b[0];
+        } else {
+          out[k++] = b[0];
+          out[k++] = b[1];
+          out[k++] = b[2];
+          out[k++] = b[3];
+        }
+      }
+}
+
+/* hdrimages.py:120-128 with colors.py:59-63; sequential sum exactly as the reference loops */
+double pto_average_luminosity(const double *img, long long npix, double delta) {
+  double cumsum = 0.0;
+  for (long long i = 0; i < npix; ++i) {
+    const double r = img[i * 3], g = img[i * 3 + 1], b = img[i * 3 + 2];
+    double mx = r, mn = r; /* Python max/min keep the first of equal values; the value is the same */
+    if (g > mx) mx = g;
+    if (b > mx) mx = b;
+    if (g < mn) mn = g;
+    if (b < mn) mn = b;
+    cumsum += log10(delta + (mx + mn) / 2);
+  }
+  return pow(10, cumsum / (double)npix);
+}
+
+/* hdrimages.py:130-146 (normalize with scale = factor / luminosity, clamp) and :160-166 (LDR bytes) */
+void pto_tonemap(double *img, long long n, double scale, int clamp, double gamma, unsigned char *rgb8,
+                 int write_back) {
+  for (long long i = 0; i < n; ++i) {
+    double x = img[i] * scale;
+    if (clamp) x = x / (1 + x);
+    if (write_back) img[i] = x;
+    if (rgb8) {
+      int b = (int)(255 * pow(x, 1 / gamma));
+      rgb8[i] = (unsigned char)(b < 0 ? 0 : (b > 255 ? 255 : b));
+    }
+  }
+}

@@ -13,7 +13,8 @@ _lib = None
 # every symbol include/ptrace.h declares
 EXPORTS = ("pt_device_count", "pt_scene_upload", "pt_scene_free", "pt_rows_for_rank", "pt_output_bytes",
            "pt_render", "pt_render_device", "pt_get_stats", "pt_set_count_rays", "pt_sync", "pt_last_error",
-           "pt_version", "pt_profile_begin", "pt_profile_end", "pt_set_timing")
+           "pt_version", "pt_profile_begin", "pt_profile_end", "pt_set_timing", "pt_image_pack_pfm",
+           "pt_image_average_luminosity", "pt_image_tonemap")
 
 
 class PtraceError(RuntimeError):
@@ -65,6 +66,14 @@ def lib():
         L.pt_profile_begin.argtypes = [C.c_void_p, C.c_int]
         L.pt_profile_end.restype = C.c_int
         L.pt_profile_end.argtypes = [C.c_void_p, P(C.c_double), P(C.c_int)]
+        L.pt_image_pack_pfm.restype = C.c_int
+        L.pt_image_pack_pfm.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.pt_image_average_luminosity.restype = C.c_int
+        L.pt_image_average_luminosity.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double,
+                                                  P(C.c_double), C.c_void_p]
+        L.pt_image_tonemap.restype = C.c_int
+        L.pt_image_tonemap.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double,
+                                       C.c_void_p, C.c_int, C.c_void_p]
         L.pt_debug_probe.restype = C.c_int
         L.pt_debug_probe.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         _lib = L

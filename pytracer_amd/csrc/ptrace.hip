@@ -17,6 +17,7 @@
 #include "../../include/ptrace.h"
 #include "pt_kernels.h"
 #include "pt_layout.h"
+#include "pt_post.h"
 
 #define PT_VERSION ((1 << 16) | 0)
 
@@ -752,6 +753,70 @@ extern "C" int pt_profile_end(pt_scene *s, double *total_kernel_ms, int *launche
   *launches = s->prof_used;
   s->profiling = false;
   s->prof_used = 0;
+  return PT_OK;
+}
+
+// ---- HdrImage post-processing (pt_post.h) -------------------------------------------------------------
+static int post_check(int device, const void *img, int fmt, int w, int h) {
+  if (!img) return fail(PT_ERR_INVALID, "null image");
+  if (w <= 0 || h <= 0) return fail(PT_ERR_INVALID, "bad image size %dx%d", w, h);
+  if (fmt != PT_OUT_F64 && fmt != PT_OUT_F32) return fail(PT_ERR_INVALID, "unknown pixel format %d", fmt);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(PT_ERR_NODEVICE, "no HIP device visible");
+  if (device < 0 || device >= ndev) return fail(PT_ERR_INVALID, "device %d out of range", device);
+  HIP_TRY(hipSetDevice(device));
+  return PT_OK;
+}
+
+static int post_grid(long long n) { return (int)std::max<long long>(1, std::min<long long>((n + 255) / 256, 4096)); }
+
+extern "C" int pt_image_pack_pfm(int device, const void *img_dev, int fmt, int width, int height, int big_endian,
+                                 void *out_dev, void *stream) {
+  int rc = post_check(device, img_dev, fmt, width, height);
+  if (rc) return rc;
+  if (!out_dev) return fail(PT_ERR_INVALID, "null output");
+  hipStream_t st = (hipStream_t)stream;
+  const long long n = (long long)width * height * 3;
+  hipLaunchKernelGGL(pt_post_pfm_kernel, dim3(post_grid(n)), dim3(256), 0, st, img_dev, fmt == PT_OUT_F32 ? 1 : 0,
+                     width, height, big_endian ? 1 : 0, (uint32_t *)out_dev);
+  HIP_TRY(hipGetLastError());
+  if (!stream) HIP_TRY(hipStreamSynchronize(st));
+  return PT_OK;
+}
+
+extern "C" int pt_image_average_luminosity(int device, const void *img_dev, int fmt, int width, int height,
+                                           double delta, double *out, void *stream) {
+  int rc = post_check(device, img_dev, fmt, width, height);
+  if (rc) return rc;
+  if (!out) return fail(PT_ERR_INVALID, "null output");
+  hipStream_t st = (hipStream_t)stream;
+  const long long npix = (long long)width * height;
+  const int nblocks = (int)((npix + PT_POST_CHUNK - 1) / PT_POST_CHUNK);
+  double *partials = nullptr;
+  HIP_TRY(hipMalloc((void **)&partials, (size_t)(nblocks + 1) * sizeof(double)));
+  hipLaunchKernelGGL(pt_post_loglum_kernel, dim3(nblocks), dim3(256), 0, st, img_dev, fmt == PT_OUT_F32 ? 1 : 0, npix,
+                     delta, partials);
+  hipLaunchKernelGGL(pt_post_sum_kernel, dim3(1), dim3(256), 0, st, partials, nblocks, partials + nblocks);
+  double sum = 0.0;
+  hipError_t e = hipMemcpyAsync(&sum, partials + nblocks, sizeof(double), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  (void)hipFree(partials);
+  if (e != hipSuccess) return fail(PT_ERR_HIP, "average_luminosity failed: %s", hipGetErrorString(e));
+  *out = std::pow(10.0, sum / (double)npix);  // hdrimages.py:128
+  return PT_OK;
+}
+
+extern "C" int pt_image_tonemap(int device, void *img_dev, int fmt, int width, int height, double scale, int clamp,
+                                double gamma, unsigned char *rgb8_dev, int write_back, void *stream) {
+  int rc = post_check(device, img_dev, fmt, width, height);
+  if (rc) return rc;
+  if (rgb8_dev && !(gamma > 0.0)) return fail(PT_ERR_INVALID, "gamma must be positive");
+  hipStream_t st = (hipStream_t)stream;
+  const long long n = (long long)width * height * 3;
+  hipLaunchKernelGGL(pt_post_tonemap_kernel, dim3(post_grid(n)), dim3(256), 0, st, img_dev, fmt == PT_OUT_F32 ? 1 : 0, n,
+                     scale, clamp ? 1 : 0, rgb8_dev ? 1.0 / gamma : 1.0, rgb8_dev, write_back ? 1 : 0);
+  HIP_TRY(hipGetLastError());
+  if (!stream) HIP_TRY(hipStreamSynchronize(st));
   return PT_OK;
 }
 

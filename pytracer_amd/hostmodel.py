@@ -306,3 +306,28 @@ class HdrImage:
         assert self.valid_coordinates(x, y)
         self.array[y, x] = (new_color.r, new_color.g, new_color.b)
         self._pixels = None
+
+    # -- post-processing (hdrimages.py:96-171): upload, run the device kernels, download -----------------
+    def _device(self):
+        from .postprocess import DeviceImage
+
+        return DeviceImage.from_numpy(self.array)
+
+    def write_pfm(self, stream, endianness=1):
+        self._device().write_pfm(stream, endianness)
+
+    def average_luminosity(self, delta=1e-10):
+        return self._device().average_luminosity(delta)
+
+    def normalize_image(self, factor, luminosity=None):
+        d = self._device()
+        d.normalize_image(factor, luminosity)
+        self.set_array(d.numpy())
+
+    def clamp_image(self):
+        d = self._device()
+        d.clamp_image()
+        self.set_array(d.numpy())
+
+    def write_ldr_image(self, stream, format, gamma=1.0):
+        self._device().write_ldr_image(stream, format, gamma)

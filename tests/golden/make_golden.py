@@ -456,9 +456,41 @@ def g9_furnace():
     save("g9_furnace", rows=np.array(rows), **scenes)
 
 
+def g10_postprocess():
+    """main.py:203-213 on two frames: PFM bytes (both endiannesses), average luminosity, normalize + clamp,
+    LDR bytes (gamma 1.0 and 2.2).  Pillow is not needed: the LDR integers are computed as
+    write_ldr_image computes them (hdrimages.py:160-166)."""
+    from io import BytesIO
+    from pytracer.hdrimages import Endianness
+    out = {}
+    for tag, name in (("a", "g5_c2_flat_160x90"), ("b", "g5_demo_path_40x30_n2d2_pixel")):
+        px = np.load(os.path.join(HERE, name + ".npz"))["pixels"]
+        h, w = px.shape[:2]
+        img = HdrImage(w, h)
+        img.pixels = [Color(*map(float, px[y, x])) for y in range(h) for x in range(w)]
+        for endian, key in ((Endianness.LITTLE_ENDIAN, "le"), (Endianness.BIG_ENDIAN, "be")):
+            buf = BytesIO()
+            img.write_pfm(buf, endianness=endian)
+            out[f"{tag}_pfm_{key}"] = np.frombuffer(buf.getvalue(), dtype=np.uint8)
+        lum = img.average_luminosity()
+        out[f"{tag}_lum"] = np.array(lum)
+        out[f"{tag}_lum_delta0"] = np.array(img.average_luminosity(delta=1e-3))
+        img.normalize_image(factor=1.0)
+        img.clamp_image()
+        out[f"{tag}_toned"] = pixels_array(img)
+        for gamma, key in ((1.0, "g10"), (2.2, "g22")):
+            out[f"{tag}_ldr_{key}"] = np.array(
+                [[int(255 * math.pow(c, 1 / gamma)) for c in (p.r, p.g, p.b)] for p in img.pixels],
+                dtype=np.int32).reshape(h, w, 3)
+        out[f"{tag}_pixels"] = px
+    save("g10_postprocess", **out)
+
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g6", "g8", "g9", "g5"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g6", "g8", "g9", "g5", "g10"]
     table = {"g1": g1_pcg, "g2": g2_xform, "g3": g3_shapes, "g4": g4_camera, "g6": g6_g7_scatter_onb,
-             "g8": g8_pigments, "g9": g9_furnace, "g5": g5_frames}
+             "g8": g8_pigments, "g9": g9_furnace, "g5": g5_frames, "g10": g10_postprocess}
     for k in which:
         table[k]()
+
