@@ -173,8 +173,10 @@ int pt_set_timing(pt_scene *scene, int enable);
 int pt_profile_begin(pt_scene *scene, int capacity);
 int pt_profile_end(pt_scene *scene, double *total_kernel_ms, int *launches);
 /* ---- HdrImage post-processing on the device (main.py:203-213) --------------
- * `img_dev` is a frame in HBM as pt_render_device leaves it: H*W*3 values of `fmt` (PT_OUT_*), row 0 on
- * top.  `stream` as in pt_render_device (NULL: the default stream, call returns when done). */
+ * `img_dev` is a frame of H*W*3 values of `fmt` (PT_OUT_*), row 0 on top: either in HBM, as
+ * pt_render_device leaves it, or in host memory (an HdrImage's array) — the library detects which and
+ * stages host buffers through the device; the same holds for the output buffers.  `stream` as in
+ * pt_render_device (NULL: the default stream; the call returns when done). */
 /* HdrImage.write_pfm payload (hdrimages.py:113-118): W*H*3 float32, bottom row first, little (0) or
  * big (1) endian, into out_dev (W*H*12 bytes, device).  The ASCII header is the caller's. */
 int pt_image_pack_pfm(int device, const void *img_dev, int fmt, int width, int height, int big_endian,

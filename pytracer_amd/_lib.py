@@ -27,6 +27,33 @@ def lib_path() -> str:
     return _LIB_PATH
 
 
+def _share_hip_runtime_with_torch() -> None:
+    """One process must hold ONE HIP runtime.  PyTorch-ROCm bundles its own ``libamdhip64.so`` (soname
+    ``libamdhip64.so.7``, the soname libptrace.so needs too).  If libptrace.so is loaded first, the dynamic
+    loader binds it to /opt/rocm's copy and a later ``import torch`` brings a second runtime that finds no
+    GPU ("No HIP GPUs are available").  Preloading torch's copy — without importing torch — makes both
+    share it whichever comes first."""
+    import importlib.util
+    import sys
+
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    libdir = os.path.join(os.path.dirname(spec.origin), "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        cand = os.path.join(libdir, name)
+        if os.path.exists(cand):
+            try:
+                C.CDLL(cand, mode=C.RTLD_GLOBAL)
+            except OSError:
+                return
+
+
 def lib():
     """The loaded C-ABI library; raises if it has not been built (``python -m pytracer_amd.build``)."""
     global _lib
@@ -35,6 +62,7 @@ def lib():
             raise ImportError(
                 f"{_LIB_PATH} is missing: the HIP extension has not been built. "
                 "Run `python -m pytracer_amd.build` (needs hipcc); there is no CPU fallback.")
+        _share_hip_runtime_with_torch()
         L = C.CDLL(_LIB_PATH)
         P = C.POINTER
         L.pt_device_count.restype = C.c_int

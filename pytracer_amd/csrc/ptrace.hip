@@ -770,31 +770,77 @@ static int post_check(int device, const void *img, int fmt, int w, int h) {
 
 static int post_grid(long long n) { return (int)std::max<long long>(1, std::min<long long>((n + 255) / 256, 4096)); }
 
-extern "C" int pt_image_pack_pfm(int device, const void *img_dev, int fmt, int width, int height, int big_endian,
-                                 void *out_dev, void *stream) {
-  int rc = post_check(device, img_dev, fmt, width, height);
+static bool is_device_ptr(const void *p) {
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+    (void)hipGetLastError();  // plain host memory: not an error for us
+    return false;
+  }
+  return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+
+// Image and output buffers may be device memory (a frame left in HBM by pt_render_device) or plain host
+// memory (an HdrImage's array); host buffers are staged through a temporary device copy.
+struct Staged {
+  void *dev = nullptr;
+  void *host = nullptr;
+  size_t bytes = 0;
+  bool owned = false;
+  ~Staged() {
+    if (owned && dev) (void)hipFree(dev);
+  }
+  int in(const void *p, size_t n, bool copy_in, hipStream_t st) {
+    bytes = n;
+    if (is_device_ptr(p)) {
+      dev = const_cast<void *>(p);
+      return PT_OK;
+    }
+    host = const_cast<void *>(p);
+    owned = true;
+    HIP_TRY(hipMalloc(&dev, n));
+    if (copy_in) HIP_TRY(hipMemcpyAsync(dev, p, n, hipMemcpyHostToDevice, st));
+    return PT_OK;
+  }
+  int out(hipStream_t st) {
+    if (owned) {
+      HIP_TRY(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+    }
+    return PT_OK;
+  }
+};
+
+extern "C" int pt_image_pack_pfm(int device, const void *img, int fmt, int width, int height, int big_endian,
+                                 void *out, void *stream) {
+  int rc = post_check(device, img, fmt, width, height);
   if (rc) return rc;
-  if (!out_dev) return fail(PT_ERR_INVALID, "null output");
+  if (!out) return fail(PT_ERR_INVALID, "null output");
   hipStream_t st = (hipStream_t)stream;
   const long long n = (long long)width * height * 3;
-  hipLaunchKernelGGL(pt_post_pfm_kernel, dim3(post_grid(n)), dim3(256), 0, st, img_dev, fmt == PT_OUT_F32 ? 1 : 0,
-                     width, height, big_endian ? 1 : 0, (uint32_t *)out_dev);
+  Staged si, so;
+  if ((rc = si.in(img, (size_t)n * (fmt == PT_OUT_F32 ? 4 : 8), true, st))) return rc;
+  if ((rc = so.in(out, (size_t)n * 4, false, st))) return rc;
+  hipLaunchKernelGGL(pt_post_pfm_kernel, dim3(post_grid(n)), dim3(256), 0, st, si.dev, fmt == PT_OUT_F32 ? 1 : 0,
+                     width, height, big_endian ? 1 : 0, (uint32_t *)so.dev);
   HIP_TRY(hipGetLastError());
-  if (!stream) HIP_TRY(hipStreamSynchronize(st));
+  if ((rc = so.out(st))) return rc;
+  if (!stream || si.owned) HIP_TRY(hipStreamSynchronize(st));
   return PT_OK;
 }
 
-extern "C" int pt_image_average_luminosity(int device, const void *img_dev, int fmt, int width, int height,
+extern "C" int pt_image_average_luminosity(int device, const void *img, int fmt, int width, int height,
                                            double delta, double *out, void *stream) {
-  int rc = post_check(device, img_dev, fmt, width, height);
+  int rc = post_check(device, img, fmt, width, height);
   if (rc) return rc;
   if (!out) return fail(PT_ERR_INVALID, "null output");
   hipStream_t st = (hipStream_t)stream;
   const long long npix = (long long)width * height;
+  Staged si;
+  if ((rc = si.in(img, (size_t)npix * 3 * (fmt == PT_OUT_F32 ? 4 : 8), true, st))) return rc;
   const int nblocks = (int)((npix + PT_POST_CHUNK - 1) / PT_POST_CHUNK);
   double *partials = nullptr;
   HIP_TRY(hipMalloc((void **)&partials, (size_t)(nblocks + 1) * sizeof(double)));
-  hipLaunchKernelGGL(pt_post_loglum_kernel, dim3(nblocks), dim3(256), 0, st, img_dev, fmt == PT_OUT_F32 ? 1 : 0, npix,
+  hipLaunchKernelGGL(pt_post_loglum_kernel, dim3(nblocks), dim3(256), 0, st, si.dev, fmt == PT_OUT_F32 ? 1 : 0, npix,
                      delta, partials);
   hipLaunchKernelGGL(pt_post_sum_kernel, dim3(1), dim3(256), 0, st, partials, nblocks, partials + nblocks);
   double sum = 0.0;
@@ -806,17 +852,23 @@ extern "C" int pt_image_average_luminosity(int device, const void *img_dev, int 
   return PT_OK;
 }
 
-extern "C" int pt_image_tonemap(int device, void *img_dev, int fmt, int width, int height, double scale, int clamp,
-                                double gamma, unsigned char *rgb8_dev, int write_back, void *stream) {
-  int rc = post_check(device, img_dev, fmt, width, height);
+extern "C" int pt_image_tonemap(int device, void *img, int fmt, int width, int height, double scale, int clamp,
+                                double gamma, unsigned char *rgb8, int write_back, void *stream) {
+  int rc = post_check(device, img, fmt, width, height);
   if (rc) return rc;
-  if (rgb8_dev && !(gamma > 0.0)) return fail(PT_ERR_INVALID, "gamma must be positive");
+  if (rgb8 && !(gamma > 0.0)) return fail(PT_ERR_INVALID, "gamma must be positive");
   hipStream_t st = (hipStream_t)stream;
   const long long n = (long long)width * height * 3;
-  hipLaunchKernelGGL(pt_post_tonemap_kernel, dim3(post_grid(n)), dim3(256), 0, st, img_dev, fmt == PT_OUT_F32 ? 1 : 0, n,
-                     scale, clamp ? 1 : 0, rgb8_dev ? 1.0 / gamma : 1.0, rgb8_dev, write_back ? 1 : 0);
+  Staged si, so;
+  if ((rc = si.in(img, (size_t)n * (fmt == PT_OUT_F32 ? 4 : 8), true, st))) return rc;
+  if (rgb8 && (rc = so.in(rgb8, (size_t)n, false, st))) return rc;
+  hipLaunchKernelGGL(pt_post_tonemap_kernel, dim3(post_grid(n)), dim3(256), 0, st, si.dev, fmt == PT_OUT_F32 ? 1 : 0, n,
+                     scale, clamp ? 1 : 0, rgb8 ? 1.0 / gamma : 1.0, rgb8 ? (unsigned char *)so.dev : nullptr,
+                     write_back ? 1 : 0);
   HIP_TRY(hipGetLastError());
-  if (!stream) HIP_TRY(hipStreamSynchronize(st));
+  if (write_back && (rc = si.out(st))) return rc;
+  if (rgb8 && (rc = so.out(st))) return rc;
+  if (!stream || si.owned || so.owned) HIP_TRY(hipStreamSynchronize(st));
   return PT_OK;
 }
 

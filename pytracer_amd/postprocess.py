@@ -2,9 +2,10 @@
 does after ``fire_all_rays`` — ``write_pfm``, ``average_luminosity``, ``normalize_image``,
 ``clamp_image``, ``write_ldr_image`` (hdrimages.py:96-171) — on a frame that sits in HBM.
 
-``DeviceImage`` wraps a ``[H, W, 3]`` torch tensor (fp32 or fp64, row 0 on top) on the GPU and mirrors
-the reference method names; torch only provides the memory, every operation is a HIP kernel behind the
-C-ABI (``pt_image_*``).  PNG encoding itself stays on the host (Pillow), as in the reference.
+``DeviceImage`` wraps ``[H, W, 3]`` pixels (fp32 or fp64, row 0 on top) — a CUDA torch tensor left in HBM
+by ``pt_render_device`` or a host numpy array — and mirrors the reference method names; every operation is
+a HIP kernel behind the C-ABI (``pt_image_*``).  PNG encoding itself stays on the host (Pillow), as in
+the reference.
 """
 from __future__ import annotations
 
@@ -12,7 +13,6 @@ import ctypes as C
 from typing import Optional
 
 import numpy as np
-import torch
 
 from . import _lib, abi
 
@@ -20,31 +20,44 @@ LITTLE_ENDIAN, BIG_ENDIAN = 1, 2  # hdrimages.py:26-30 (Endianness values)
 
 
 class DeviceImage:
-    def __init__(self, tensor: torch.Tensor):
-        if tensor.dim() != 3 or tensor.shape[2] != 3 or not tensor.is_cuda or not tensor.is_contiguous():
-            raise ValueError("expected a contiguous [H, W, 3] CUDA tensor")
-        if tensor.dtype not in (torch.float32, torch.float64):
-            raise ValueError("expected float32 or float64 pixels")
-        self.t = tensor
-        self.height, self.width = int(tensor.shape[0]), int(tensor.shape[1])
-        self.fmt = abi.OUT_F32 if tensor.dtype == torch.float32 else abi.OUT_F64
-        self.device = tensor.device.index or 0
+    """``[H, W, 3]`` fp32/fp64 pixels: a CUDA torch tensor (frame resident in HBM) or a numpy array (host;
+    the C-ABI stages it through the device).  Either way every operation below is a HIP kernel."""
+
+    def __init__(self, pixels, device: int = 0):
+        self.is_torch = hasattr(pixels, "data_ptr")
+        if self.is_torch:
+            if pixels.dim() != 3 or pixels.shape[2] != 3 or not pixels.is_cuda or not pixels.is_contiguous():
+                raise ValueError("expected a contiguous [H, W, 3] CUDA tensor")
+            f32 = str(pixels.dtype) == "torch.float32"
+            if not f32 and str(pixels.dtype) != "torch.float64":
+                raise ValueError("expected float32 or float64 pixels")
+            self.device = pixels.device.index or 0
+        else:
+            pixels = np.ascontiguousarray(pixels)
+            if pixels.ndim != 3 or pixels.shape[2] != 3 or pixels.dtype not in (np.float32, np.float64):
+                raise ValueError("expected a [H, W, 3] float32/float64 array")
+            f32 = pixels.dtype == np.float32
+            self.device = device
+        self.t = pixels
+        self.height, self.width = int(pixels.shape[0]), int(pixels.shape[1])
+        self.fmt = abi.OUT_F32 if f32 else abi.OUT_F64
 
     @classmethod
     def from_numpy(cls, arr, device: int = 0) -> "DeviceImage":
-        a = np.ascontiguousarray(arr)
-        return cls(torch.from_numpy(a).to(f"cuda:{device}").contiguous())
+        return cls(np.array(arr, order="C"), device)
+
+    def _ptr(self):
+        return C.c_void_p(self.t.data_ptr() if self.is_torch else self.t.ctypes.data)
 
     def numpy(self) -> np.ndarray:
-        return self.t.cpu().numpy()
+        return self.t.cpu().numpy() if self.is_torch else self.t
 
     # -- hdrimages.py:96-118 ---------------------------------------------------------------------------
     def pfm_payload(self, endianness: int = LITTLE_ENDIAN) -> bytes:
-        out = torch.empty(self.width * self.height * 12, dtype=torch.uint8, device=self.t.device)
-        _lib.check(_lib.lib().pt_image_pack_pfm(self.device, C.c_void_p(self.t.data_ptr()), self.fmt, self.width,
-                                                self.height, int(endianness == BIG_ENDIAN),
-                                                C.c_void_p(out.data_ptr()), None))
-        return out.cpu().numpy().tobytes()
+        out = np.empty(self.width * self.height * 12, dtype=np.uint8)
+        _lib.check(_lib.lib().pt_image_pack_pfm(self.device, self._ptr(), self.fmt, self.width, self.height,
+                                                int(endianness == BIG_ENDIAN), out.ctypes.data_as(C.c_void_p), None))
+        return out.tobytes()
 
     def write_pfm(self, stream, endianness: int = LITTLE_ENDIAN) -> None:
         endianness_str = "-1.0" if endianness == LITTLE_ENDIAN else "1.0"
@@ -54,14 +67,14 @@ class DeviceImage:
     # -- hdrimages.py:120-146 --------------------------------------------------------------------------
     def average_luminosity(self, delta: float = 1e-10) -> float:
         out = C.c_double(0.0)
-        _lib.check(_lib.lib().pt_image_average_luminosity(self.device, C.c_void_p(self.t.data_ptr()), self.fmt,
-                                                          self.width, self.height, float(delta), C.byref(out), None))
+        _lib.check(_lib.lib().pt_image_average_luminosity(self.device, self._ptr(), self.fmt, self.width, self.height,
+                                                          float(delta), C.byref(out), None))
         return float(out.value)
 
-    def _tonemap(self, scale: float, clamp: bool, gamma: float, rgb8: Optional[torch.Tensor], write_back: bool):
-        _lib.check(_lib.lib().pt_image_tonemap(self.device, C.c_void_p(self.t.data_ptr()), self.fmt, self.width,
-                                               self.height, float(scale), int(clamp), float(gamma),
-                                               C.c_void_p(rgb8.data_ptr()) if rgb8 is not None else None,
+    def _tonemap(self, scale: float, clamp: bool, gamma: float, rgb8: Optional[np.ndarray], write_back: bool):
+        _lib.check(_lib.lib().pt_image_tonemap(self.device, self._ptr(), self.fmt, self.width, self.height,
+                                               float(scale), int(clamp), float(gamma),
+                                               rgb8.ctypes.data_as(C.c_void_p) if rgb8 is not None else None,
                                                int(write_back), None))
 
     def normalize_image(self, factor: float, luminosity: Optional[float] = None) -> None:
@@ -75,9 +88,9 @@ class DeviceImage:
     # -- hdrimages.py:148-171 ----------------------------------------------------------------------------
     def ldr_bytes(self, gamma: float = 1.0) -> np.ndarray:
         """``[H, W, 3]`` uint8: int(255 * pow(c, 1/gamma)) per channel (no change to the image)."""
-        rgb8 = torch.empty((self.height, self.width, 3), dtype=torch.uint8, device=self.t.device)
+        rgb8 = np.empty((self.height, self.width, 3), dtype=np.uint8)
         self._tonemap(1.0, False, gamma, rgb8, False)
-        return rgb8.cpu().numpy()
+        return rgb8
 
     def write_ldr_image(self, stream, format: str, gamma: float = 1.0) -> None:
         from PIL import Image  # host-side encoder, as in the reference

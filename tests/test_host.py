@@ -126,3 +126,23 @@ def test_struct_sizes_match_header():
     assert C.sizeof(abi.Params) == 4 * 4 + 9 * 8 + 4 * 4 + 4 * 8 + 4 * 4
     assert C.sizeof(abi.Stats) == 2 * 8 + 2 * 8 + 4 * 4
     assert C.sizeof(abi.SceneDesc) == 25 * 8
+
+
+def test_fill_image_into_reference_style_hdrimage():
+    """pytracer's HdrImage keeps a list of Color objects (hdrimages.py:70): filled with its own class."""
+    from pytracer_amd.tracer import _fill_image
+
+    class RefColor:
+        def __init__(self, r=0.0, g=0.0, b=0.0):
+            self.r, self.g, self.b = r, g, b
+
+    class RefImage:
+        def __init__(self, w, h):
+            self.width, self.height = w, h
+            self.pixels = [RefColor() for _ in range(w * h)]
+
+    img = RefImage(3, 2)
+    arr = np.arange(18, dtype=np.float64).reshape(2, 3, 3)
+    _fill_image(img, arr)
+    assert all(isinstance(c, RefColor) for c in img.pixels)
+    assert (img.pixels[4].r, img.pixels[4].g, img.pixels[4].b) == (12.0, 13.0, 14.0)  # (x=1, y=1) -> 1*3+1

@@ -105,6 +105,24 @@ def test_device_postprocess_golden(tag):
 
 
 @pytest.mark.gpu
+def test_device_resident_tensor_path():
+    """A frame left in HBM by pt_render_device (a torch tensor) goes through the same kernels in place."""
+    import torch
+
+    from pytracer_amd.postprocess import DeviceImage
+
+    g = util.load("g10_postprocess")
+    t = torch.from_numpy(g["a_pixels"]).cuda().contiguous()
+    img = DeviceImage(t)
+    buf = BytesIO()
+    img.write_pfm(buf)
+    assert buf.getvalue() == g["a_pfm_le"].tobytes()
+    img.normalize_image(factor=1.0)
+    img.clamp_image()
+    assert util.rel_err(t.cpu().numpy(), g["a_toned"]).max() <= 1e-12  # modified in HBM, in place
+
+
+@pytest.mark.gpu
 def test_hdrimage_standin_methods():
     from pytracer_amd import hostmodel as hm
 
