@@ -962,6 +962,55 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
   add_ray_count(a, nrays);
 }
 
+// ---- region ordering for the path tracer -------------------------------------------------------------
+// A region's cost grows with the shapes its primary rays can reach (bounces happen there); regions of
+// pure background cost 16 cheap steps.  The frame time is set by the longest per-wave chain, so the
+// expensive regions must start first: key = survivors of the region's cull, then a counting sort
+// (descending).  The order only changes WHEN a region is rendered, never its pixels.
+__global__ void pt_region_keys(const PtKArgs a, unsigned char *keys) {
+  pt_kargs c = cold_args(a);
+  const int W = c->W, rows_local = c->rows_local, npass = c->npass;
+  const int lane = threadIdx.x & 63;
+  const int regions_x = (W + PT_REGION - 1) / PT_REGION;
+  const int nregions = regions_x * ((rows_local + PT_REGION - 1) / PT_REGION);
+  const int nwaves = gridDim.x * (blockDim.x >> 6);
+  for (int region = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); region < nregions; region += nwaves) {
+    const int ry = region / regions_x, rx = region - ry * regions_x;
+    int gx0, gr0, gx1, gr1;
+    pixel_coords(a, (long long)(ry * PT_REGION) * W + rx * PT_REGION, gx0, gr0);
+    const int last_lrow = (ry * PT_REGION + PT_REGION - 1 < rows_local) ? ry * PT_REGION + PT_REGION - 1 : rows_local - 1;
+    pixel_coords(a, (long long)last_lrow * W + rx * PT_REGION, gx1, gr1);
+    const TileCone tc = tile_cone(a, rx * PT_REGION, (rx * PT_REGION + PT_REGION < W) ? rx * PT_REGION + PT_REGION : W, gr0, gr1);
+    int count = 0;
+    for (int p = 0; p < npass; ++p) {
+      const int slot = p * 64 + lane;
+      bool keep = false;
+      if (slot < a.n_shapes) keep = cone_keeps(tc, a.bounds[slot]);
+      count += __popcll(__ballot(keep));
+    }
+    if (lane == 0) keys[region] = (unsigned char)(count > 255 ? 255 : count);
+  }
+}
+
+// one workgroup: histogram (256 bins) -> descending offsets -> scatter
+__global__ void pt_region_sort(const unsigned char *keys, int n, int *order) {
+  __shared__ int hist[256];
+  __shared__ int offs[256];
+  for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += blockDim.x) atomicAdd(&hist[keys[i]], 1);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int k = 255; k >= 0; --k) {
+      offs[k] = run;
+      run += hist[k];
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += blockDim.x) order[atomicAdd(&offs[keys[i]], 1)] = i;
+}
+
 // ---- PathTracer (render.py:99-139) as a per-lane state machine ----------------------------------------
 // The reference recursion is depth-first; frame `k` of the explicit stack is the call at depth k.
 // Frame fields (in ws, [slot][field][thread] so a wave's accesses are contiguous):
@@ -1194,6 +1243,10 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAV
         if (lane == 0) rid = (unsigned)atomicAdd(cold_args(a)->queue, 1ULL);
         region = (int)__builtin_amdgcn_readfirstlane((int)rid);
         if (region >= nregions) break;
+        {
+          const int *order = cold_args(a)->region_order;  // expensive regions first (pt_region_sort)
+          if (order) region = order[region];
+        }
         const int ry = region / regions_x, rx = region - ry * regions_x;
         int gx0, gr0, gx1, gr1;
         pixel_coords(a, (long long)(ry * PT_REGION) * W + rx * PT_REGION, gx0, gr0);

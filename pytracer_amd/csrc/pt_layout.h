@@ -92,6 +92,7 @@ struct PtKArgs {
   double *ws;                      // path-tracer frame stack: [slot][field][thread]
   unsigned long long *ray_counter; // per-workgroup partial counts; may be null
   unsigned long long *queue;       // path tracer: next unassigned pixel (zeroed per launch)
+  const int *region_order;         // path tracer: region visiting order (may be null = raster order)
   long long npix;                  // pixels this launch covers (rows_local * W)
   int n_shapes, n_lights;
   int n_spheres;                   // recs[0..n_spheres) are spheres, recs[n_spheres..n_shapes) planes

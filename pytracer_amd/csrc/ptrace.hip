@@ -61,6 +61,9 @@ struct pt_scene {
   int ray_partials_n = 0;
   unsigned long long *queue = nullptr;  // path-tracer pixel queue head
   PtKArgs *args_dev = nullptr;          // device copy of the argument block (cold fields)
+  unsigned char *region_keys = nullptr;  // path tracer region ordering
+  int *region_order = nullptr;
+  int region_cap = 0;
   PtKArgs args_last;                    // what args_dev holds
   bool args_valid = false;
   hipStream_t args_stream = nullptr;
@@ -168,6 +171,8 @@ extern "C" void pt_scene_free(pt_scene *s) {
   (void)hipFree(s->ray_partials);
   (void)hipFree(s->queue);
   (void)hipFree(s->args_dev);
+  (void)hipFree(s->region_keys);
+  (void)hipFree(s->region_order);
   if (s->ray_counter_host) (void)hipHostFree(s->ray_counter_host);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
@@ -558,6 +563,24 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
     a.ws = s->ws;
   }
 
+  // path tracer: visit the expensive regions first (pt_region_keys / pt_region_sort)
+  static const int env_order = getenv("PTRACE_REGION_ORDER") ? atoi(getenv("PTRACE_REGION_ORDER")) : 1;
+  const int nregions = path_tiled ? ((p->width + PT_REGION - 1) / PT_REGION) * ((rows + PT_REGION - 1) / PT_REGION) : 0;
+  const bool ordered = path_tiled && env_order != 0 && nregions > 4 * grid;
+  if (ordered) {
+    if (nregions > s->region_cap) {
+      HIP_TRY(hipStreamSynchronize(st));
+      if (s->region_keys) HIP_TRY(hipFree(s->region_keys));
+      if (s->region_order) HIP_TRY(hipFree(s->region_order));
+      s->region_keys = nullptr;
+      s->region_order = nullptr;
+      s->region_cap = 0;
+      HIP_TRY(hipMalloc((void **)&s->region_keys, (size_t)nregions));
+      HIP_TRY(hipMalloc((void **)&s->region_order, (size_t)nregions * sizeof(int)));
+      s->region_cap = nregions;
+    }
+    a.region_order = s->region_order;
+  }
   // the cold half of the argument block is read from device memory: refresh the copy when it changed
   // (the output pointer stays a by-value argument: double-buffered frames alternate it every launch)
   a.cold = s->args_dev;
@@ -572,6 +595,11 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
   }
   const bool prof = s->timing && s->profiling && (size_t)(2 * s->prof_used + 1) < s->prof.size();
   if (s->timing) HIP_TRY(hipEventRecord(prof ? s->prof[2 * s->prof_used] : s->ev0, st));
+  // (inside the timed bracket: the ordering pre-pass is part of the frame's kernel time)
+  if (ordered) {
+    hipLaunchKernelGGL(pt_region_keys, dim3(std::min(grid, (nregions + 3) / 4)), dim3(PT_BLOCK), 0, st, a, s->region_keys);
+    hipLaunchKernelGGL(pt_region_sort, dim3(1), dim3(1024), 0, st, s->region_keys, nregions, s->region_order);
+  }
   if (tile) {
     const size_t lds = (size_t)4 * a.npass * sizeof(unsigned long long);
     s->stats.lds_bytes = (int)lds;
