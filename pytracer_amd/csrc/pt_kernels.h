@@ -480,6 +480,16 @@ PT_DEV void pixel_coords(const PtKArgs &a, long long pix, int &col, int &grow) {
   grow = (blk * c->n_ranks + c->rank) * rb + (lr - blk * rb);
 }
 
+// local (rank-compact) row -> GLOBAL row, 32-bit arithmetic only
+PT_DEV int global_row(const PtKArgs &a, int lrow) {
+  pt_kargs c = cold_args(a);
+  const int nr = c->n_ranks;
+  if (nr == 1) return lrow;
+  const int rb = c->row_block;
+  const int blk = lrow / rb;
+  return (blk * nr + c->rank) * rb + (lrow - blk * rb);
+}
+
 PT_DEV void store_pixel(const PtKArgs &a, long long pix, V3 v) {
   pt_kargs c = cold_args(a);
   if (c->out_f32) {
@@ -701,27 +711,6 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAV
 // bounding sphere per pass; the survivors come back as one 64-bit ballot per pass, staged in LDS
 // (wave-private slice) and replayed for every sample.  Survivors run the exact reference arithmetic
 // in ascending slot order; ties go to the lower World.shapes index as everywhere else.
-PT_DEV double wave_min(double v) {
-  for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off, 64));
-  return v;
-}
-PT_DEV double wave_sum(double v) {
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
-}
-PT_DEV V3 unit3(V3 v) {
-  const double n = sqrt(v.x * v.x + v.y * v.y + v.z * v.z);
-  V3 r = {v.x / n, v.y / n, v.z / n};
-  return r;
-}
-// direction of the primary ray through continuous image position (x, y) (perspective camera)
-PT_DEV V3 primary_dir_at(const PtKArgs &a, double x, double y) {
-  pt_kargs c = cold_args(a);
-  const double u = x / (double)c->W, v = 1.0 - y / (double)c->H;
-  V3 d = {c->cam_dist, (1.0 - 2.0 * u) * c->cam_aspect, 2.0 * v - 1.0};
-  return xf_vec(c->cam_m, d);
-}
-
 // The cone and the rejection test run in fp32 (sqrt/rcp are single instructions there) with explicit
 // conservative margins: every rounding error of the fp32 evaluation (<~1e-6 relative, plus the
 // absolute error of C - O for large coordinates) is covered by widening the cone by 2e-6 in cos and
@@ -742,30 +731,30 @@ struct TileCone {
 PT_DEV TileCone tile_cone(const PtKArgs &a, int x0, int x1, int grow0, int grow1) {
   TileCone tc;
   const int lane = threadIdx.x & 63;
-  {
-    pt_kargs c = cold_args(a);
-    const V3 o = {-c->cam_dist, 0.0, 0.0};
-    const V3 apex = xf_point(c->cam_m, o);
-    tc.ox = (float)apex.x;
-    tc.oy = (float)apex.y;
-    tc.oz = (float)apex.z;
-    tc.oabs = fmaxf(fmaxf(fabsf(tc.ox), fabsf(tc.oy)), fabsf(tc.oz));
-  }
-  const double y0 = (double)grow0, y1 = (double)grow1 + 1.0;
-  const V3 dc = primary_dir_at(a, 0.5 * ((double)x0 + (double)x1), 0.5 * (y0 + y1));
+  pt_kargs c = cold_args(a);
+  // the host folded camera.py:116-124 and imagetracer.py:56-58 into d(x, y) = d0 + x*dx + y*dy (fp32)
+  const float d0x = c->cone_d0[0], d0y = c->cone_d0[1], d0z = c->cone_d0[2];
+  const float dxx = c->cone_dx[0], dxy = c->cone_dx[1], dxz = c->cone_dx[2];
+  const float dyx = c->cone_dy[0], dyy = c->cone_dy[1], dyz = c->cone_dy[2];
+  tc.ox = c->cone_apex[0];
+  tc.oy = c->cone_apex[1];
+  tc.oz = c->cone_apex[2];
+  tc.oabs = fmaxf(fmaxf(fabsf(tc.ox), fabsf(tc.oy)), fabsf(tc.oz));
+  const float fx0 = (float)x0, fx1 = (float)x1, fy0 = (float)grow0, fy1 = (float)(grow1 + 1);
+  const float xm = 0.5f * (fx0 + fx1), ym = 0.5f * (fy0 + fy1);
+  const float cx = d0x + xm * dxx + ym * dyx, cy = d0y + xm * dxy + ym * dyy, cz = d0z + xm * dxz + ym * dyz;
   // lane k computes corner k & 3; the min over lanes 0..3 is the min over the whole wave
-  const V3 dk = primary_dir_at(a, (lane & 1) ? (double)x1 : (double)x0, (lane & 2) ? y1 : y0);
-  const float cx = (float)dc.x, cy = (float)dc.y, cz = (float)dc.z;
+  const float xk = (lane & 1) ? fx1 : fx0, yk = (lane & 2) ? fy1 : fy0;
+  const float kx = d0x + xk * dxx + yk * dyx, ky = d0y + xk * dxy + yk * dyy, kz = d0z + xk * dxz + yk * dyz;
   const float rc = __frsqrt_rn(cx * cx + cy * cy + cz * cz);
   tc.ax = cx * rc;
   tc.ay = cy * rc;
   tc.az = cz * rc;
-  const float kx = (float)dk.x, ky = (float)dk.y, kz = (float)dk.z;
   const float rk = __frsqrt_rn(kx * kx + ky * ky + kz * kz);
   float cs = (tc.ax * kx + tc.ay * ky + tc.az * kz) * rk;
   cs = fminf(cs, __shfl_xor(cs, 1, 64));
   cs = fminf(cs, __shfl_xor(cs, 2, 64));
-  cs -= 2e-6f;
+  cs -= 4e-6f;  // fp32 evaluation of the directions (~3e-7 relative) + of the dot product
   tc.all = !(cs > 0.05f);  // also catches NaN
   tc.cos_t = cs;
   tc.sin_t = __fsqrt_rn(fmaxf(0.0f, 1.0f - cs * cs)) * (1.0f + 1e-5f) + 1e-7f;
@@ -864,34 +853,42 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
   const int ntiles = tiles_x * tiles_y;
   const int nwaves = gridDim.x * (PT_BLOCK / 64);
   unsigned long long nrays = 0;
+#ifdef PT_DEBUG_TIME
+  unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
+#define PT_TSTAMP(k) do { const unsigned long long tn = __builtin_amdgcn_s_memtime(); tsum[k] += tn - tprev; tprev = tn; } while (0)
+#else
+#define PT_TSTAMP(k) do { } while (0)
+#endif
   for (int tile = blockIdx.x * (PT_BLOCK / 64) + wib; tile < ntiles; tile += nwaves) {
+    PT_TSTAMP(7);
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int col = tx * 8 + (lane & 7), lrow = ty * 8 + (lane >> 3);
     const bool active = col < W && lrow < rows_local;
     // clamp so that idle lanes of edge tiles stand on a real pixel (they only widen nothing)
     const int ccol = col < W ? col : W - 1, clrow = lrow < rows_local ? lrow : rows_local - 1;
     const long long pix = (long long)clrow * W + ccol;
-    int pcol, grow;
-    pixel_coords(a, pix, pcol, grow);
+    const int pcol = ccol, grow = global_row(a, clrow);
 
+    PT_TSTAMP(0);
     // ---- cull: one bounding sphere per lane per pass -> ballot -> LDS ----
-    int gx0, gr0, gx1, gr1;  // tile rectangle: columns [tx*8, ..), global rows of its first/last local row
-    pixel_coords(a, (long long)(ty * 8) * W + tx * 8, gx0, gr0);
-    {
-      const int last_lrow = (ty * 8 + 7 < rows_local) ? ty * 8 + 7 : rows_local - 1;
-      pixel_coords(a, (long long)last_lrow * W + tx * 8, gx1, gr1);
-    }
+    // tile rectangle: columns [tx*8, ..), global rows of its first/last local row
+    const int gr0 = global_row(a, ty * 8);
+    const int gr1 = global_row(a, (ty * 8 + 7 < rows_local) ? ty * 8 + 7 : rows_local - 1);
+    // the first pass's bounding sphere is requested before the cone arithmetic so that the two overlap
+    const float4 b_first = a.bounds[lane < a.n_shapes ? lane : 0];
     const TileCone tc = tile_cone(a, tx * 8, (tx * 8 + 8 < W) ? tx * 8 + 8 : W, gr0, gr1);
+    PT_TSTAMP(1);
     for (int p = 0; p < npass; ++p) {
       const int slot = p * 64 + lane;
       bool keep = false;
-      if (slot < a.n_shapes) keep = cone_keeps(tc, a.bounds[slot]);  // 16 B per lane, coalesced
+      if (slot < a.n_shapes) keep = cone_keeps(tc, p == 0 ? b_first : a.bounds[slot]);  // 16 B per lane, coalesced
       const unsigned long long m = __ballot(keep);
       if (lane == 0) pt_lds_masks[mbase + p] = m;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    PT_TSTAMP(2);
 
     Pcg pcg;
     unsigned long long gpix = 0;
@@ -911,8 +908,10 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
         vp = ((double)sr + pcg_float(pcg)) / (double)S;
       }
       const Ray ray = primary_ray(a, pcol, grow, up, vp);
+      PT_TSTAMP(3);
       double best_t;
       const int hit = world_query_tile<RENDERER == PT_RENDERER_ONOFF>(a, ray, mbase, npass, best_t, active);
+      PT_TSTAMP(4);
       if (active) nrays++;
       V3 c;
       {
@@ -949,6 +948,7 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
       } else {
         cum = c;
       }
+      PT_TSTAMP(5);
     }
     if (S > 0) {  // imagetracer.py:99-101
       const double k = 1.0 / (double)(S * S);
@@ -958,7 +958,13 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
     }
     if (active) store_pixel(a, pix, cum);
     __builtin_amdgcn_wave_barrier();  // the next tile overwrites this wave's mask slice
+    PT_TSTAMP(6);
   }
+#ifdef PT_DEBUG_TIME
+  // sampled (every 64th workgroup) so that the report's own atomics do not disturb the other waves
+  if ((threadIdx.x & 63) == 0 && (blockIdx.x & 63) == 0)
+    for (int q = 0; q < 8; ++q) atomicAdd(cold_args(a)->queue + 1 + q, tsum[q]);
+#endif
   add_ray_count(a, nrays);
 }
 
@@ -976,10 +982,8 @@ __global__ void pt_region_keys(const PtKArgs a, unsigned char *keys) {
   const int nwaves = gridDim.x * (blockDim.x >> 6);
   for (int region = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); region < nregions; region += nwaves) {
     const int ry = region / regions_x, rx = region - ry * regions_x;
-    int gx0, gr0, gx1, gr1;
-    pixel_coords(a, (long long)(ry * PT_REGION) * W + rx * PT_REGION, gx0, gr0);
-    const int last_lrow = (ry * PT_REGION + PT_REGION - 1 < rows_local) ? ry * PT_REGION + PT_REGION - 1 : rows_local - 1;
-    pixel_coords(a, (long long)last_lrow * W + rx * PT_REGION, gx1, gr1);
+    const int gr0 = global_row(a, ry * PT_REGION);
+    const int gr1 = global_row(a, (ry * PT_REGION + PT_REGION - 1 < rows_local) ? ry * PT_REGION + PT_REGION - 1 : rows_local - 1);
     const TileCone tc = tile_cone(a, rx * PT_REGION, (rx * PT_REGION + PT_REGION < W) ? rx * PT_REGION + PT_REGION : W, gr0, gr1);
     int count = 0;
     for (int p = 0; p < npass; ++p) {
@@ -1248,10 +1252,8 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAV
           if (order) region = order[region];
         }
         const int ry = region / regions_x, rx = region - ry * regions_x;
-        int gx0, gr0, gx1, gr1;
-        pixel_coords(a, (long long)(ry * PT_REGION) * W + rx * PT_REGION, gx0, gr0);
-        const int last_lrow = (ry * PT_REGION + PT_REGION - 1 < rows_local) ? ry * PT_REGION + PT_REGION - 1 : rows_local - 1;
-        pixel_coords(a, (long long)last_lrow * W + rx * PT_REGION, gx1, gr1);
+        const int gr0 = global_row(a, ry * PT_REGION);
+        const int gr1 = global_row(a, (ry * PT_REGION + PT_REGION - 1 < rows_local) ? ry * PT_REGION + PT_REGION - 1 : rows_local - 1);
         const TileCone tc = tile_cone(a, rx * PT_REGION, (rx * PT_REGION + PT_REGION < W) ? rx * PT_REGION + PT_REGION : W, gr0, gr1);
         __builtin_amdgcn_wave_barrier();
         for (int p = 0; p < npass; ++p) {

@@ -105,6 +105,9 @@ struct PtKArgs {
   int cam_kind;
   double cam_m[12];
   double cam_dist, cam_aspect;
+  // perspective primary direction as an affine function of the image position, fp32, for the tile cones only:
+  // d(x, y) = cone_d0 + x * cone_dx + y * cone_dy  (x in pixels from the left, y in global rows from the top)
+  float cone_d0[3], cone_dx[3], cone_dy[3], cone_apex[3];
   // image / renderer parameters (pt_params)
   int W, H, S;
   int N, D, rr;

@@ -435,6 +435,7 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
   a.hoist = s->hoist;
   a.diag = s->diag;
   a.hoist_diag = s->hoist_diag;
+  a.queue = s->queue;
   a.bounds = s->bounds;
   a.n_diag = s->n_diag;
   a.lights = s->lights;
@@ -448,6 +449,16 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
   memcpy(a.cam_m, cam->m, sizeof a.cam_m);
   a.cam_dist = cam->screen_distance;
   a.cam_aspect = cam->aspect_ratio;
+  {
+    // camera.py:116-124 + imagetracer.py:56-58: d = M3 * (dist, (1 - 2x/W) * aspect, 1 - 2y/H)
+    const double *m = cam->m, dist = cam->screen_distance, asp = cam->aspect_ratio;
+    for (int r = 0; r < 3; ++r) {
+      a.cone_d0[r] = (float)(m[r * 4 + 0] * dist + m[r * 4 + 1] * asp + m[r * 4 + 2]);
+      a.cone_dx[r] = (float)(m[r * 4 + 1] * (-2.0 * asp / p->width));
+      a.cone_dy[r] = (float)(m[r * 4 + 2] * (-2.0 / p->height));
+      a.cone_apex[r] = (float)(m[r * 4 + 0] * -dist + m[r * 4 + 3]);
+    }
+  }
   a.W = p->width;
   a.H = p->height;
   a.S = p->samples_per_side;
@@ -547,7 +558,6 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
     return PT_OK;
   }
   if (p->renderer == PT_RENDERER_PATHTRACER) {
-    a.queue = s->queue;
     HIP_TRY(hipMemsetAsync(s->queue, 0, 16 * sizeof(unsigned long long), st));
     a.frame_doubles = p->num_of_rays > 1 ? 20 : 6;
     const size_t slots = (size_t)std::max(p->max_depth, 0) + 1;
@@ -601,6 +611,9 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
     hipLaunchKernelGGL(pt_region_sort, dim3(1), dim3(1024), 0, st, s->region_keys, nregions, s->region_order);
   }
   if (tile) {
+#ifdef PT_DEBUG_TIME
+    HIP_TRY(hipMemsetAsync(s->queue, 0, 16 * sizeof(unsigned long long), st));
+#endif
     const size_t lds = (size_t)4 * a.npass * sizeof(unsigned long long);
     s->stats.lds_bytes = (int)lds;
     if (p->renderer == PT_RENDERER_ONOFF)
