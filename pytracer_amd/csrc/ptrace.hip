@@ -506,8 +506,10 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
                     (p->renderer == PT_RENDERER_ONOFF || p->renderer == PT_RENDERER_FLAT);
   int grid = (int)std::max<long long>(1, std::min(want, cap));
   if (tile) {
+    static const int env_twg = getenv("PTRACE_TILE_WG_PER_CU") ? atoi(getenv("PTRACE_TILE_WG_PER_CU")) : 0;
+    const long long tcap = env_twg > 0 ? (long long)s->n_cu * env_twg : cap;
     const long long wave_tiles = (long long)((p->width + 7) / 8) * ((rows + 7) / 8);
-    grid = (int)std::max<long long>(1, std::min<long long>((wave_tiles + 3) / 4, cap));
+    grid = (int)std::max<long long>(1, std::min<long long>((wave_tiles + 3) / 4, tcap));
   }
   if (path_tiled) {
     const long long regions = (long long)((p->width + PT_REGION - 1) / PT_REGION) * ((rows + PT_REGION - 1) / PT_REGION);
