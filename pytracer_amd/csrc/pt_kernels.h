@@ -1173,6 +1173,27 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAV
       ret.z = em.z + 0.0 * invN;
       return;
     }
+    if (sp + 1 > D) {
+      // Every child of this hit would be beyond max_depth: the reference still calls scatter_ray for each
+      // (consuming its draws: 2 for a diffuse BRDF, none for a mirror) and each child returns black at
+      // render.py:100-101 without a world query.  No ray, no frame, no geometry is needed: advance the
+      // generator and accumulate hit_color * 0 exactly as render.py:135-139 does.
+      const bool diffuse = ax->brdf_kind == PT_BRDF_DIFFUSE;
+      V3 fc = {0.0, 0.0, 0.0};
+      for (int i = 0; i < N; ++i) {
+        if (diffuse) {
+          pcg_next(pcg);
+          pcg_next(pcg);
+        }
+        fc.x = fc.x + hc.x * 0.0;
+        fc.y = fc.y + hc.y * 0.0;
+        fc.z = fc.z + hc.z * 0.0;
+      }
+      ret.x = em.x + fc.x * invN;
+      ret.y = em.y + fc.y * invN;
+      ret.z = em.z + fc.z * invN;
+      return;
+    }
     // render.py:126-137: push the frame, child 0 is scattered at the next S-step
     if (!details) hit_details(a, ray, best_t, hit, h, false);
     ws_at(w, sp, 0) = hc.x;
