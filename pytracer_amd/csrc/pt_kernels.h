@@ -342,9 +342,8 @@ PT_DEV int world_query(const PtKArgs &a, const Ray &r, double tmax, double &best
 // ---- the closest hit's HitRecord (shapes.py:123-131, 177-189; world.py:66-67) ----------------------
 // Computed once per ray for the winner only; every value is a pure function of (ray, shape, t), so
 // it equals what the reference computed for that candidate.
-PT_DEV void hit_details(const PtKArgs &a, const Ray &r, double t, int i, Hit &h, bool need_uv) {
-  const PtShapeRec *rec = a.recs + i;
-  const PtShapeAux *ax = cold_args(a)->aux + i;  // same (grouped) slot order as recs
+PT_DEV void hit_details(const PtShapeRec *rec, const PtShapeAux *ax, const Ray &r, double t, Hit &h, bool need_uv) {
+  // rec / ax: the winner's records (same grouped slot in both tables)
   double im[12];
 #pragma unroll
   for (int k = 0; k < 12; ++k) im[k] = rec->invm[k];
@@ -380,6 +379,13 @@ PT_DEV void hit_details(const PtKArgs &a, const Ray &r, double t, int i, Hit &h,
     }
   }
   h.n = normalize3(xf_normal(im, nn));
+}
+
+// Out-of-line entry for the path tracer: its kernel keeps ~40 VGPRs of path state alive; inlining the
+// HitRecord code (24 matrix doubles in flight) on top of that costs a wave of occupancy.
+PT_NOINLINE void hit_details_call(const PtShapeRec *rec, const PtShapeAux *ax, const Ray *r, double t, Hit *h,
+                                  bool need_uv) {
+  hit_details(rec, ax, *r, t, *h, need_uv);
 }
 
 // ---- pigments (materials.py:50-100) --------------------------------------------------------------------
@@ -439,6 +445,10 @@ PT_DEV Ray scatter_ray(int brdf_kind, Pcg &pcg, V3 incoming, V3 point, V3 n) {
     r.tmin = 1e-5;
   }
   return r;
+}
+
+PT_NOINLINE void scatter_ray_call(int brdf_kind, Pcg *pcg, const V3 *incoming, const V3 *point, const V3 *n, Ray *out) {
+  *out = scatter_ray(brdf_kind, *pcg, *incoming, *point, *n);
 }
 
 // ---- ImageTracer.fire_ray + Camera.fire_ray (imagetracer.py:48-58; camera.py:59-78, 103-124) -----
@@ -614,7 +624,7 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAV
           h.u = 0.0;
           h.v = 0.0;
           // Flat needs only (u, v); skip the whole HitRecord when both pigments are uniform
-          if (ax->needs_uv) hit_details(a, ray, best_t, hit, h, true);
+          if (ax->needs_uv) hit_details(a.recs + hit, ax, ray, best_t, h, true);
           const V3 p1 = brdf_pigment(a, ax, h.u, h.v);
           const V3 p2 = emitted_pigment(a, ax, h.u, h.v);
           c.x = p1.x + p2.x;
@@ -632,7 +642,7 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAV
         const PtShapeAux *ax = ca->aux + (hit >= 0 ? hit : 0);
         V3 res = c;
         if (lit) {
-          hit_details(a, ray, best_t, hit, h, ax->needs_uv != 0);
+          hit_details(a.recs + hit, ax, ray, best_t, h, ax->needs_uv != 0);
           const V3 em = emitted_pigment(a, ax, h.u, h.v);
           res.x = ca->ambient[0] + em.x;
           res.y = ca->ambient[1] + em.y;
@@ -933,7 +943,7 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
           Hit h;
           h.u = 0.0;
           h.v = 0.0;
-          if (ax->needs_uv) hit_details(a, ray, best_t, hit, h, true);
+          if (ax->needs_uv) hit_details(a.recs + hit, ax, ray, best_t, h, true);
           const V3 p1 = brdf_pigment(a, ax, h.u, h.v);
           const V3 p2 = emitted_pigment(a, ax, h.u, h.v);
           c.x = p1.x + p2.x;
@@ -1149,7 +1159,7 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAV
     const bool uv = ax->needs_uv != 0;
     bool details = false;
     if (uv) {
-      hit_details(a, ray, best_t, hit, h, true);
+      hit_details_call(a.recs + hit, ax, &ray, best_t, &h, true);
       details = true;
     }
     hc = brdf_pigment(a, ax, h.u, h.v);
@@ -1195,7 +1205,7 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAV
       return;
     }
     // render.py:126-137: push the frame, child 0 is scattered at the next S-step
-    if (!details) hit_details(a, ray, best_t, hit, h, false);
+    if (!details) hit_details_call(a.recs + hit, ax, &ray, best_t, &h, false);
     ws_at(w, sp, 0) = hc.x;
     ws_at(w, sp, 1) = hc.y;
     ws_at(w, sp, 2) = hc.z;
@@ -1370,7 +1380,7 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAV
     while (unwinding) {
       if (spawn) {
         // scatter_ray consumes its draws even when the child is beyond max_depth
-        ray = scatter_ray(f_brdf, pcg, f_in, f_wp, f_n);
+        scatter_ray_call(f_brdf, &pcg, &f_in, &f_wp, &f_n, &ray);
         spawn = false;
         if (sp > D) {  // render.py:100-101: the child returns black without a world query
           ret.x = 0.0;
