@@ -738,17 +738,32 @@ struct TileCone {
 // pixels (all jitter samples included) lie inside the rectangle [x0, x1] x [grow0, grow1 + 1] of the
 // image plane; primary directions are affine in image position, so the convex cone spanned by the
 // four corner rays contains every ray of the tile.
-PT_DEV TileCone tile_cone(const PtKArgs &a, int x0, int x1, int grow0, int grow1) {
+// the host folded camera.py:116-124 and imagetracer.py:56-58 into d(x, y) = d0 + x*dx + y*dy (fp32)
+struct ConeCam {
+  float d0[3], dx[3], dy[3], apex[3];
+};
+
+PT_DEV ConeCam cone_cam(const PtKArgs &a) {
+  ConeCam k;
+  pt_kargs c = cold_args(a);
+  for (int i = 0; i < 3; ++i) {
+    k.d0[i] = c->cone_d0[i];
+    k.dx[i] = c->cone_dx[i];
+    k.dy[i] = c->cone_dy[i];
+    k.apex[i] = c->cone_apex[i];
+  }
+  return k;
+}
+
+PT_DEV TileCone tile_cone(const ConeCam &k, int x0, int x1, int grow0, int grow1) {
   TileCone tc;
   const int lane = threadIdx.x & 63;
-  pt_kargs c = cold_args(a);
-  // the host folded camera.py:116-124 and imagetracer.py:56-58 into d(x, y) = d0 + x*dx + y*dy (fp32)
-  const float d0x = c->cone_d0[0], d0y = c->cone_d0[1], d0z = c->cone_d0[2];
-  const float dxx = c->cone_dx[0], dxy = c->cone_dx[1], dxz = c->cone_dx[2];
-  const float dyx = c->cone_dy[0], dyy = c->cone_dy[1], dyz = c->cone_dy[2];
-  tc.ox = c->cone_apex[0];
-  tc.oy = c->cone_apex[1];
-  tc.oz = c->cone_apex[2];
+  const float d0x = k.d0[0], d0y = k.d0[1], d0z = k.d0[2];
+  const float dxx = k.dx[0], dxy = k.dx[1], dxz = k.dx[2];
+  const float dyx = k.dy[0], dyy = k.dy[1], dyz = k.dy[2];
+  tc.ox = k.apex[0];
+  tc.oy = k.apex[1];
+  tc.oz = k.apex[2];
   tc.oabs = fmaxf(fmaxf(fabsf(tc.ox), fabsf(tc.oy)), fabsf(tc.oz));
   const float fx0 = (float)x0, fx1 = (float)x1, fy0 = (float)grow0, fy1 = (float)(grow1 + 1);
   const float xm = 0.5f * (fx0 + fx1), ym = 0.5f * (fy0 + fy1);
@@ -771,28 +786,38 @@ PT_DEV TileCone tile_cone(const PtKArgs &a, int x0, int x1, int grow0, int grow1
   return tc;
 }
 
+PT_DEV TileCone tile_cone(const PtKArgs &a, int x0, int x1, int grow0, int grow1) {
+  return tile_cone(cone_cam(a), x0, x1, grow0, grow1);
+}
+
 // may the bounding sphere touch the cone?  (conservative: true when in doubt)
+// In the half-plane (d, perp) = (distance along the axis, distance from the axis) the solid cone lies
+// on the side q <= 0 of the line through the apex with direction (cos t, sin t), where
+// q = perp*cos t - d*sin t; a point with q > 0 is at least q away from every point of the cone (also
+// behind the apex, where the true distance |v| is larger still).  So q > R proves a miss.  perp is
+// taken from the rejection vector v - d*axis (no cancellation between squares): the fp32 error of q
+// is a few 1e-7*|v| plus the error of C - O; behind the apex (d < 0) the deliberately enlarged sin t
+// adds up to 1.02e-5*|d|.  The margin is 4e-5*(|d| + perp) + 3*eps_abs.
 PT_DEV bool cone_keeps(const TileCone &tc, float4 b) {
   if (tc.all || !(b.w >= 0.0f)) return true;
   const float vx = b.x - tc.ox, vy = b.y - tc.oy, vz = b.z - tc.oz;
   const float eps_abs = 1e-6f * (fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fabsf(b.z)) + tc.oabs);
-  const float L = __fsqrt_rn(vx * vx + vy * vy + vz * vz);
-  const float R = b.w * (1.0f + 1e-5f) + eps_abs;
-  if (!(L > R)) return true;  // apex inside the sphere (or NaN)
-  const float sin_a = R / L;
-  if (!(sin_a < tc.cos_t)) return true;  // theta + alpha >= 90 degrees
-  const float cos_a = __fsqrt_rn(fmaxf(0.0f, 1.0f - sin_a * sin_a));
-  const float cos_sum = tc.cos_t * cos_a - tc.sin_t * sin_a;  // cos(theta + alpha), both < 90 degrees
-  const float lhs = vx * tc.ax + vy * tc.ay + vz * tc.az;
-  return !(lhs < L * cos_sum - (1e-5f * L + 2.0f * eps_abs));
+  const float d = vx * tc.ax + vy * tc.ay + vz * tc.az;
+  const float wx = vx - d * tc.ax, wy = vy - d * tc.ay, wz = vz - d * tc.az;
+  const float perp = __builtin_amdgcn_sqrtf(wx * wx + wy * wy + wz * wz);  // v_sqrt_f32, 1 ulp
+  const float q = perp * tc.cos_t - d * tc.sin_t;
+  const float R = b.w * (1.0f + 1e-5f) + 4e-5f * (fabsf(d) + perp) + 3.0f * eps_abs;
+  return !(q > R);  // also keeps NaN
 }
 
 // The survivor masks live in LDS and are always addressed through this array (never through a generic
 // pointer): DS reads and writes of one wave execute in order, FLAT accesses to the LDS aperture do not.
 extern __shared__ unsigned long long pt_lds_masks[];
 
-template <bool ANYHIT>
-PT_DEV int world_query_tile(const PtKArgs &a, const Ray &r, int mbase, int npass, double &best_t, bool active) {
+// HIER: the mask bits index the tile's cell list (pt_cell_kernel), which holds the slots.
+template <bool ANYHIT, bool HIER = false>
+PT_DEV int world_query_tile(const PtKArgs &a, const Ray &r, int mbase, int npass, double &best_t, bool active,
+                            const unsigned int *list = nullptr) {
   int best = -1;
   best_t = INFINITY;
   const double tmin = r.tmin, tmax = INFINITY;
@@ -805,8 +830,9 @@ PT_DEV int world_query_tile(const PtKArgs &a, const Ray &r, int mbase, int npass
     const unsigned m_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)mv);
     unsigned long long mask = ((unsigned long long)m_hi << 32) | (unsigned long long)m_lo;
     while (mask) {
-      const int slot = p * 64 + (__ffsll((long long)mask) - 1);
+      const int idx = p * 64 + (__ffsll((long long)mask) - 1);
       mask &= mask - 1;
+      const int slot = HIER ? PT_KI(list)[idx] : idx;
       if (slot < ns) {
         double dx, dy, dz, ox, oy, oz, cc;
         if (slot < nd && g.fast) {
@@ -843,10 +869,86 @@ PT_DEV int world_query_tile(const PtKArgs &a, const Ray &r, int mbase, int npass
   return best;
 }
 
+// Large scenes: a pre-pass culls the world once per PT_CELL x PT_CELL block of GLOBAL image pixels
+// (same cone test, same margins) into a slot list per cell; a tile then only looks at its cell's
+// list.  A workgroup takes a 2x2 group of cells and one chunk of at most PT_CELL_CHUNK shapes (each
+// bounding sphere is loaded once for four cells), collects the survivors in LDS (LDS atomics: global
+// round trips would serialise the passes) and appends them to the cells' lists with one global atomic
+// per cell.  A list is therefore in no particular order -- which cannot matter: the exact tests pick
+// the closest hit, ties by World.shapes index.  cell_count is zeroed before the launch.
+#ifndef PT_CELL
+#define PT_CELL 32
+#endif
+#define PT_CELL_CHUNK 2048
+__global__ __launch_bounds__(PT_BLOCK) void pt_cell_kernel(const PtKArgs a, int nchunks, int chunk_len) {
+  __shared__ unsigned short found[4][PT_CELL_CHUNK];  // offsets from the chunk's first slot
+  __shared__ int nfound[4], gbase[4];
+  int W, H;
+  {
+    pt_kargs c = cold_args(a);
+    W = c->W;
+    H = c->H;
+  }
+  const ConeCam cam = cone_cam(a);
+  const int lane = threadIdx.x & 63;
+  const int group = blockIdx.x / nchunks, chunk = blockIdx.x - group * nchunks;
+  const int groups_x = (a.cells_x + 1) >> 1;
+  const int gy = group / groups_x, gx = group - gy * groups_x;
+  const int cells_y = (H + PT_CELL - 1) / PT_CELL;
+  const int gx1 = (gx + 1) * 2 * PT_CELL < W ? (gx + 1) * 2 * PT_CELL : W;
+  const int gr1 = (gy + 1) * 2 * PT_CELL - 1 < H - 1 ? (gy + 1) * 2 * PT_CELL - 1 : H - 1;
+  const TileCone tg = tile_cone(cam, gx * 2 * PT_CELL, gx1, gy * 2 * PT_CELL, gr1);
+  TileCone tc[4];
+  int cell[4];
+  for (int k = 0; k < 4; ++k) {
+    const int cx = gx * 2 + (k & 1), cy = gy * 2 + (k >> 1);
+    cell[k] = (cx < a.cells_x && cy < cells_y) ? cy * a.cells_x + cx : -1;
+    const int ccx = cx < a.cells_x ? cx : a.cells_x - 1, ccy = cy < cells_y ? cy : cells_y - 1;
+    const int x1 = (ccx + 1) * PT_CELL < W ? (ccx + 1) * PT_CELL : W;
+    const int r1 = (ccy + 1) * PT_CELL - 1 < H - 1 ? (ccy + 1) * PT_CELL - 1 : H - 1;
+    tc[k] = tile_cone(cam, ccx * PT_CELL, x1, ccy * PT_CELL, r1);
+  }
+  if (threadIdx.x < 4) nfound[threadIdx.x] = 0;
+  __syncthreads();
+  const int n = a.n_shapes;
+  const int s0 = chunk * chunk_len, s1 = s0 + chunk_len < n ? s0 + chunk_len : n;
+  float4 b_next = a.bounds[s0 + (int)threadIdx.x < s1 ? s0 + (int)threadIdx.x : 0];
+  for (int p0 = s0; p0 < s1; p0 += PT_BLOCK) {
+    const int slot = p0 + (int)threadIdx.x;
+    const bool in = slot < s1;
+    const float4 b = b_next;
+    b_next = a.bounds[slot + PT_BLOCK < s1 ? slot + PT_BLOCK : 0];
+    if (!__ballot(in && cone_keeps(tg, b))) continue;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (cell[k] < 0) continue;
+      const unsigned long long m = __ballot(in && cone_keeps(tc[k], b));
+      if (!m) continue;
+      int base = 0;
+      if (lane == 0) base = atomicAdd(&nfound[k], __popcll(m));  // ds_add_rtn
+      base = __builtin_amdgcn_readfirstlane(base);
+      if ((m >> lane) & 1ull) found[k][base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)(slot - s0);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    const int k = threadIdx.x;
+    gbase[k] = (cell[k] >= 0 && nfound[k] > 0) ? atomicAdd(a.cell_count + cell[k], nfound[k]) : 0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (cell[k] < 0) continue;
+    unsigned int *dst = a.cell_list + (size_t)cell[k] * a.cell_stride + gbase[k];
+    for (int i = threadIdx.x; i < nfound[k]; i += PT_BLOCK) dst[i] = (unsigned)(s0 + found[k][i]);
+  }
+}
+
 // OnOff / Flat / PointLight with a perspective camera: 8x8 tiles, culled shape lists.
 // WAVES = waves per SIMD the register allocator must make room for.  With the transcendental
 // functions out of line the Flat kernel needs 93 VGPRs: 5 waves per SIMD, no scratch.
-template <int RENDERER, int WAVES>
+// HIER (large scenes): the tile culls its 32x32 cell's survivor list instead of the whole world.
+template <int RENDERER, int WAVES, bool HIER>
 __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) void pt_tile_kernel(const PtKArgs a) {
   int S, W, rows_local, npass;
   {
@@ -885,15 +987,33 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
     const int gr0 = global_row(a, ty * 8);
     const int gr1 = global_row(a, (ty * 8 + 7 < rows_local) ? ty * 8 + 7 : rows_local - 1);
     // the first pass's bounding sphere is requested before the cone arithmetic so that the two overlap
-    const float4 b_first = a.bounds[lane < a.n_shapes ? lane : 0];
+    const float4 b_first = a.bounds[(!HIER && lane < a.n_shapes) ? lane : 0];
     const TileCone tc = tile_cone(a, tx * 8, (tx * 8 + 8 < W) ? tx * 8 + 8 : W, gr0, gr1);
     PT_TSTAMP(1);
-    for (int p = 0; p < npass; ++p) {
-      const int slot = p * 64 + lane;
-      bool keep = false;
-      if (slot < a.n_shapes) keep = cone_keeps(tc, p == 0 ? b_first : a.bounds[slot]);  // 16 B per lane, coalesced
-      const unsigned long long m = __ballot(keep);
-      if (lane == 0) pt_lds_masks[mbase + p] = m;
+    int tpass = npass;
+    const unsigned int *list = nullptr;
+    if (HIER) {
+      // the tile's 8 rows are consecutive global rows starting at a multiple of 8 (the host checks
+      // row_block % 8 == 0), so they lie in one cell row
+      const int cell = __builtin_amdgcn_readfirstlane((gr0 / PT_CELL) * a.cells_x + (tx * 8) / PT_CELL);
+      const int cnt = PT_KI(a.cell_count)[cell];
+      list = a.cell_list + (size_t)cell * a.cell_stride;
+      tpass = (cnt + 63) >> 6;
+      for (int p = 0; p < tpass; ++p) {
+        const int idx = p * 64 + lane;
+        bool keep = false;
+        if (idx < cnt) keep = cone_keeps(tc, a.bounds[list[idx]]);
+        const unsigned long long m = __ballot(keep);
+        if (lane == 0) pt_lds_masks[mbase + p] = m;
+      }
+    } else {
+      for (int p = 0; p < npass; ++p) {
+        const int slot = p * 64 + lane;
+        bool keep = false;
+        if (slot < a.n_shapes) keep = cone_keeps(tc, p == 0 ? b_first : a.bounds[slot]);  // 16 B per lane, coalesced
+        const unsigned long long m = __ballot(keep);
+        if (lane == 0) pt_lds_masks[mbase + p] = m;
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -920,7 +1040,7 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
       const Ray ray = primary_ray(a, pcol, grow, up, vp);
       PT_TSTAMP(3);
       double best_t;
-      const int hit = world_query_tile<RENDERER == PT_RENDERER_ONOFF>(a, ray, mbase, npass, best_t, active);
+      const int hit = world_query_tile<RENDERER == PT_RENDERER_ONOFF, HIER>(a, ray, mbase, tpass, best_t, active, list);
       PT_TSTAMP(4);
       if (active) nrays++;
       V3 c;

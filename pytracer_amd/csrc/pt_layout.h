@@ -93,6 +93,9 @@ struct PtKArgs {
   unsigned long long *ray_counter; // per-workgroup partial counts; may be null
   unsigned long long *queue;       // path tracer: next unassigned pixel (zeroed per launch)
   const int *region_order;         // path tracer: region visiting order (may be null = raster order)
+  unsigned int *cell_list;         // large scenes: [cell][cell_stride] surviving slots (pt_cell_kernel)
+  int *cell_count;                 // [cell] survivors
+  int cells_x, cell_stride;
   long long npix;                  // pixels this launch covers (rows_local * W)
   int n_shapes, n_lights;
   int n_spheres;                   // recs[0..n_spheres) are spheres, recs[n_spheres..n_shapes) planes

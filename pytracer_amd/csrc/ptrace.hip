@@ -64,6 +64,10 @@ struct pt_scene {
   unsigned char *region_keys = nullptr;  // path tracer region ordering
   int *region_order = nullptr;
   int region_cap = 0;
+  unsigned int *cell_list = nullptr;  // large scenes: per-cell survivor lists (pt_cell_kernel)
+  int *cell_count = nullptr;
+  size_t cell_list_cap = 0;
+  int cell_count_cap = 0;
   PtKArgs args_last;                    // what args_dev holds
   bool args_valid = false;
   hipStream_t args_stream = nullptr;
@@ -173,6 +177,8 @@ extern "C" void pt_scene_free(pt_scene *s) {
   (void)hipFree(s->args_dev);
   (void)hipFree(s->region_keys);
   (void)hipFree(s->region_order);
+  (void)hipFree(s->cell_list);
+  (void)hipFree(s->cell_count);
   if (s->ray_counter_host) (void)hipHostFree(s->ray_counter_host);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
@@ -593,6 +599,33 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
     }
     a.region_order = s->region_order;
   }
+  // large scenes: two-level culling (cells of PT_CELL x PT_CELL global pixels, then 8x8 tiles)
+  static const int env_hier = getenv("PTRACE_HIER_MIN") ? atoi(getenv("PTRACE_HIER_MIN")) : 256;
+  const int cells_x = (p->width + PT_CELL - 1) / PT_CELL, cells_y = (p->height + PT_CELL - 1) / PT_CELL;
+  const int ncells = cells_x * cells_y;
+  const int cell_stride = (s->n_shapes + 63) / 64 * 64;
+  const bool hier = tile && env_hier >= 0 && s->n_shapes > env_hier && (a.n_ranks == 1 || a.row_block % 8 == 0) &&
+                    (size_t)ncells * cell_stride * sizeof(unsigned int) <= ((size_t)2 << 30);
+  if (hier) {
+    const size_t need = (size_t)ncells * cell_stride;
+    if (need > s->cell_list_cap || ncells > s->cell_count_cap) {
+      HIP_TRY(hipStreamSynchronize(st));
+      if (s->cell_list) HIP_TRY(hipFree(s->cell_list));
+      if (s->cell_count) HIP_TRY(hipFree(s->cell_count));
+      s->cell_list = nullptr;
+      s->cell_count = nullptr;
+      s->cell_list_cap = 0;
+      s->cell_count_cap = 0;
+      HIP_TRY(hipMalloc((void **)&s->cell_list, need * sizeof(unsigned int)));
+      HIP_TRY(hipMalloc((void **)&s->cell_count, (size_t)ncells * sizeof(int)));
+      s->cell_list_cap = need;
+      s->cell_count_cap = ncells;
+    }
+    a.cell_list = s->cell_list;
+    a.cell_count = s->cell_count;
+    a.cells_x = cells_x;
+    a.cell_stride = cell_stride;
+  }
   // the cold half of the argument block is read from device memory: refresh the copy when it changed
   // (the output pointer stays a by-value argument: double-buffered frames alternate it every launch)
   a.cold = s->args_dev;
@@ -618,10 +651,23 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
 #endif
     const size_t lds = (size_t)4 * a.npass * sizeof(unsigned long long);
     s->stats.lds_bytes = (int)lds;
-    if (p->renderer == PT_RENDERER_ONOFF)
-      hipLaunchKernelGGL((pt_tile_kernel<PT_RENDERER_ONOFF, 4>), dim3(grid), dim3(PT_BLOCK), lds, st, a);
+    if (hier) {
+      // enough (cell group, shape chunk) pairs to fill the chip; a chunk is a multiple of the block
+      const int ngroups = ((cells_x + 1) / 2) * ((cells_y + 1) / 2), max_chunks = (s->n_shapes + PT_BLOCK - 1) / PT_BLOCK;
+      const int min_chunks = (s->n_shapes + PT_CELL_CHUNK - 1) / PT_CELL_CHUNK;  // a chunk's survivors fit in LDS
+      const int nchunks = std::max(min_chunks, std::min(max_chunks, (4 * s->n_cu + ngroups - 1) / ngroups));
+      const int chunk_len = (max_chunks + nchunks - 1) / nchunks * PT_BLOCK;
+      if (chunk_len > PT_CELL_CHUNK) return fail(PT_ERR_INVALID, "internal: cell chunk exceeds its LDS staging");
+      HIP_TRY(hipMemsetAsync(s->cell_count, 0, (size_t)ncells * sizeof(int), st));
+      hipLaunchKernelGGL(pt_cell_kernel, dim3(ngroups * nchunks), dim3(PT_BLOCK), 0, st, a, nchunks, chunk_len);
+      if (p->renderer == PT_RENDERER_ONOFF)
+        hipLaunchKernelGGL((pt_tile_kernel<PT_RENDERER_ONOFF, 4, true>), dim3(grid), dim3(PT_BLOCK), lds, st, a);
+      else
+        hipLaunchKernelGGL((pt_tile_kernel<PT_RENDERER_FLAT, 4, true>), dim3(grid), dim3(PT_BLOCK), lds, st, a);
+    } else if (p->renderer == PT_RENDERER_ONOFF)
+      hipLaunchKernelGGL((pt_tile_kernel<PT_RENDERER_ONOFF, 4, false>), dim3(grid), dim3(PT_BLOCK), lds, st, a);
     else
-      hipLaunchKernelGGL((pt_tile_kernel<PT_RENDERER_FLAT, 4>), dim3(grid), dim3(PT_BLOCK), lds, st, a);
+      hipLaunchKernelGGL((pt_tile_kernel<PT_RENDERER_FLAT, 4, false>), dim3(grid), dim3(PT_BLOCK), lds, st, a);
   } else
   switch (p->renderer) {
     case PT_RENDERER_ONOFF:

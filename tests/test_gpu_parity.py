@@ -183,6 +183,8 @@ def _cluster_world(n, spread, seed, rotated=False):
     (120, 0.6, True, 203, 117, 0, abi.RENDERER_ONOFF),
     (300, 1.5, True, 160, 96, 2, abi.RENDERER_FLAT),       # 5 culling passes, jittered samples
     (40, 0.2, False, 64, 64, 3, abi.RENDERER_FLAT),
+    (400, 1.5, True, 203, 117, 2, abi.RENDERER_FLAT),      # > 256 shapes: two-level culling (cells, then tiles)
+    (400, 1.0, False, 160, 96, 0, abi.RENDERER_ONOFF),
 ])
 def test_tile_culling_is_invisible(dev, oracle, n, spread, rotated, W, H, S, renderer):
     """The culled tile kernel must equal the oracle bit for bit (uniform pigments on the spheres,
@@ -200,12 +202,13 @@ def test_tile_culling_is_invisible(dev, oracle, n, spread, rotated, W, H, S, ren
         assert ds.stats().lds_bytes > 0, "expected the tile kernel"
         assert util.bits_equal(out, ora), f"max rel {util.rel_err(out, ora).max()}"
         assert ds.stats().n_rays == n_rays
-        # and under an awkward row partition (blocks of 7 rows over 3 ranks)
-        got = np.zeros_like(out)
-        for rank in range(3):
-            p = abi.copy_params(par, n_ranks=3, rank=rank, row_block=7)
-            got[abi.rows_for_rank(H, 7, 3, rank)] = ds.render(cam, p)
-        assert util.bits_equal(got, ora)
+        # and under an awkward row partition (blocks of 7 rows over 3 ranks), and the usual one
+        for rb in (7, 8):
+            got = np.zeros_like(out)
+            for rank in range(3):
+                p = abi.copy_params(par, n_ranks=3, rank=rank, row_block=rb)
+                got[abi.rows_for_rank(H, rb, 3, rank)] = ds.render(cam, p)
+            assert util.bits_equal(got, ora)
 
 
 @pytest.mark.parametrize("n_rays,depth,S,mode", [(1, 3, 4, abi.PCG_PIXEL), (2, 2, 2, abi.PCG_PIXEL),
