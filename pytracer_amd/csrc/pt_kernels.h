@@ -342,6 +342,9 @@ PT_DEV int world_query(const PtKArgs &a, const Ray &r, double tmax, double &best
 // ---- the closest hit's HitRecord (shapes.py:123-131, 177-189; world.py:66-67) ----------------------
 // Computed once per ray for the winner only; every value is a pure function of (ray, shape, t), so
 // it equals what the reference computed for that candidate.
+// INL: the transcendental functions inline (the latency-bound second pass of the path tracer, which has
+// registers to spare) instead of behind a call (everything that runs at 4-5 waves per SIMD).
+template <bool INL = false>
 PT_DEV void hit_details(const PtShapeRec *rec, const PtShapeAux *ax, const Ray &r, double t, Hit &h, bool need_uv) {
   // rec / ax: the winner's records (same grouped slot in both tables)
   double im[12];
@@ -363,11 +366,11 @@ PT_DEV void hit_details(const PtShapeRec *rec, const PtShapeAux *ax, const Ray &
     nn.y = keep ? hp.y : -hp.y;
     nn.z = keep ? hp.z : -hp.z;
     if (need_uv) {  // shapes.py:36-42
-      const double uu = pt_atan2(hp.y, hp.x) / (2.0 * PT_PI);
+      const double uu = (INL ? atan2(hp.y, hp.x) : pt_atan2(hp.y, hp.x)) / (2.0 * PT_PI);
       h.u = (uu >= 0.0) ? uu : uu + 1.0;
       double z = hp.z;  // the reference raises ValueError outside [-1, 1]: clamp
       z = (z > 1.0) ? 1.0 : ((z < -1.0) ? -1.0 : z);
-      h.v = pt_acos(z) / PT_PI;
+      h.v = (INL ? acos(z) : pt_acos(z)) / PT_PI;
     }
   } else {
     nn.x = 0.0;
@@ -418,6 +421,7 @@ PT_DEV V3 emitted_pigment(const PtKArgs &a, const PtShapeAux *ax, double u, doub
 }
 
 // ---- BRDF.scatter_ray (materials.py:132-152, 175-196; geometry.py:247-262) -------------------------
+template <bool INL = false>
 PT_DEV Ray scatter_ray(int brdf_kind, Pcg &pcg, V3 incoming, V3 point, V3 n) {
   Ray r;
   r.o = point;
@@ -430,7 +434,7 @@ PT_DEV Ray scatter_ray(int brdf_kind, Pcg &pcg, V3 incoming, V3 point, V3 n) {
     const double cts = pcg_float(pcg);
     const double ct = sqrt(cts), st = sqrt(1.0 - cts);
     const double phi = 2.0 * PT_PI * pcg_float(pcg);
-    const double cp = pt_cos(phi), sp = pt_sin(phi);
+    const double cp = INL ? cos(phi) : pt_cos(phi), sp = INL ? sin(phi) : pt_sin(phi);
     r.d.x = ct * (cp * e1.x) + ct * (sp * e2.x) + st * n.x;
     r.d.y = ct * (cp * e1.y) + ct * (sp * e2.y) + st * n.y;
     r.d.z = ct * (cp * e1.z) + ct * (sp * e2.z) + st * n.z;
@@ -517,7 +521,7 @@ PT_DEV void store_pixel(const PtKArgs &a, long long pix, V3 v) {
 
 // Ray accounting without a contended atomic: wave reduction -> LDS -> one plain store per workgroup
 // into a.ray_counter[blockIdx.x]; pt_sum_counts folds the per-workgroup partials afterwards.
-PT_DEV void add_ray_count(const PtKArgs &a, unsigned long long n) {
+PT_DEV void add_ray_count(const PtKArgs &a, unsigned long long n, int base = 0) {
   unsigned long long *counter = cold_args(a)->ray_counter;
   if (counter) {
     __shared__ unsigned long long partial[PT_BLOCK / 64];
@@ -527,7 +531,7 @@ PT_DEV void add_ray_count(const PtKArgs &a, unsigned long long n) {
     if (threadIdx.x == 0) {
       unsigned long long t = 0;
       for (int w = 0; w < PT_BLOCK / 64; ++w) t += partial[w];
-      counter[blockIdx.x] = t;
+      counter[base + blockIdx.x] = t;
     }
   }
 }
@@ -948,8 +952,15 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_cell_kernel(const PtKArgs a, int 
 // WAVES = waves per SIMD the register allocator must make room for.  With the transcendental
 // functions out of line the Flat kernel needs 93 VGPRs: 5 waves per SIMD, no scratch.
 // HIER (large scenes): the tile culls its 32x32 cell's survivor list instead of the whole world.
+//
+// RENDERER == PATHTRACER is the path tracer's first pass.  A sample whose primary ray misses, or hits
+// a surface whose BRDF pigment is black (hit_color_lum == 0: render.py:126 spawns nothing), ends at
+// depth 0 with radiance = background resp. emitted + 0*(1/N) and has drawn nothing but its two jitter
+// numbers -- exactly what this loop does.  A pixel all of whose samples end like that (sky, lamps) is
+// finished here at Flat speed; a pixel that meets anything else is abandoned (nothing stored, its
+// rays not counted) and flagged in region_mask for pt_path_kernel, which renders it from its seed.
 template <int RENDERER, int WAVES, bool HIER>
-__global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) void pt_tile_kernel(const PtKArgs a) {
+__global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) void pt_tile_kernel(const PtKArgs a, int count_base) {
   int S, W, rows_local, npass;
   {
     pt_kargs c = cold_args(a);
@@ -1028,7 +1039,10 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
       if (c->pcg_mode == PT_PCG_PIXEL) pcg_seed(pcg, c->s0, c->q0 + gpix);
     }
     V3 cum = {0.0, 0.0, 0.0};
+    bool alive = active;  // PATHTRACER: still a pixel this pass can finish
+    int pix_rays = 0;
     for (int s = 0; s < nsamp; ++s) {
+      if (RENDERER == PT_RENDERER_PATHTRACER && !__any(alive)) break;
       double up = 0.5, vp = 0.5;
       if (S > 0) {  // imagetracer.py:86-93
         pt_kargs c = cold_args(a);
@@ -1040,9 +1054,9 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
       const Ray ray = primary_ray(a, pcol, grow, up, vp);
       PT_TSTAMP(3);
       double best_t;
-      const int hit = world_query_tile<RENDERER == PT_RENDERER_ONOFF, HIER>(a, ray, mbase, tpass, best_t, active, list);
+      const int hit = world_query_tile<RENDERER == PT_RENDERER_ONOFF, HIER>(a, ray, mbase, tpass, best_t, alive, list);
       PT_TSTAMP(4);
-      if (active) nrays++;
+      if (alive) pix_rays++;
       V3 c;
       {
         pt_kargs ca = cold_args(a);
@@ -1056,6 +1070,24 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
           c.x = ca->onoff[0];
           c.y = ca->onoff[1];
           c.z = ca->onoff[2];
+        }
+      } else if (RENDERER == PT_RENDERER_PATHTRACER) {  // render.py:103-139 at depth 0, no recursion
+        if (hit >= 0) {
+          pt_kargs ca = cold_args(a);
+          const PtShapeAux *ax = ca->aux + hit;
+          Hit h;
+          h.u = 0.0;
+          h.v = 0.0;
+          if (ax->needs_uv) hit_details(a.recs + hit, ax, ray, best_t, h, true);
+          const V3 hc = brdf_pigment(a, ax, h.u, h.v);
+          const V3 em = emitted_pigment(a, ax, h.u, h.v);
+          const double lum = max2(max2(hc.x, hc.y), hc.z);
+          // Russian roulette already at depth 0 (rr_limit <= 0) draws a number: not for this pass
+          if (ca->rr <= 0 || lum > 0.0) alive = false;
+          const double invN = 1.0 / (double)ca->N;
+          c.x = em.x + 0.0 * invN;  // render.py:139 with cum_radiance = 0
+          c.y = em.y + 0.0 * invN;
+          c.z = em.z + 0.0 * invN;
         }
       } else {  // render.py:65-74
         if (hit >= 0) {
@@ -1086,46 +1118,35 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
       cum.y = cum.y * k;
       cum.z = cum.z * k;
     }
-    if (active) store_pixel(a, pix, cum);
+    if (alive) {
+      store_pixel(a, pix, cum);
+      nrays += (unsigned long long)pix_rays;
+    }
+    if (RENDERER == PT_RENDERER_PATHTRACER) {
+      const unsigned long long todo = __ballot(active && !alive);
+      if (lane == 0) {
+        pt_kargs c = cold_args(a);
+        c->region_mask[tile] = todo;
+        c->region_keys[tile] = (unsigned char)__popcll(todo);
+      }
+    }
     __builtin_amdgcn_wave_barrier();  // the next tile overwrites this wave's mask slice
     PT_TSTAMP(6);
   }
 #ifdef PT_DEBUG_TIME
   // sampled (every 64th workgroup) so that the report's own atomics do not disturb the other waves
-  if ((threadIdx.x & 63) == 0 && (blockIdx.x & 63) == 0)
+  if (RENDERER != PT_RENDERER_PATHTRACER && (threadIdx.x & 63) == 0 && (blockIdx.x & 63) == 0)
     for (int q = 0; q < 8; ++q) atomicAdd(cold_args(a)->queue + 1 + q, tsum[q]);
 #endif
-  add_ray_count(a, nrays);
+  add_ray_count(a, nrays, count_base);
 }
 
 // ---- region ordering for the path tracer -------------------------------------------------------------
-// A region's cost grows with the shapes its primary rays can reach (bounces happen there); regions of
-// pure background cost 16 cheap steps.  The frame time is set by the longest per-wave chain, so the
-// expensive regions must start first: key = survivors of the region's cull, then a counting sort
-// (descending).  The order only changes WHEN a region is rendered, never its pixels.
-__global__ void pt_region_keys(const PtKArgs a, unsigned char *keys) {
-  pt_kargs c = cold_args(a);
-  const int W = c->W, rows_local = c->rows_local, npass = c->npass;
-  const int lane = threadIdx.x & 63;
-  const int regions_x = (W + PT_REGION - 1) / PT_REGION;
-  const int nregions = regions_x * ((rows_local + PT_REGION - 1) / PT_REGION);
-  const int nwaves = gridDim.x * (blockDim.x >> 6);
-  for (int region = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); region < nregions; region += nwaves) {
-    const int ry = region / regions_x, rx = region - ry * regions_x;
-    const int gr0 = global_row(a, ry * PT_REGION);
-    const int gr1 = global_row(a, (ry * PT_REGION + PT_REGION - 1 < rows_local) ? ry * PT_REGION + PT_REGION - 1 : rows_local - 1);
-    const TileCone tc = tile_cone(a, rx * PT_REGION, (rx * PT_REGION + PT_REGION < W) ? rx * PT_REGION + PT_REGION : W, gr0, gr1);
-    int count = 0;
-    for (int p = 0; p < npass; ++p) {
-      const int slot = p * 64 + lane;
-      bool keep = false;
-      if (slot < a.n_shapes) keep = cone_keeps(tc, a.bounds[slot]);
-      count += __popcll(__ballot(keep));
-    }
-    if (lane == 0) keys[region] = (unsigned char)(count > 255 ? 255 : count);
-  }
-}
-
+// The first pass (pt_tile_kernel<PATHTRACER>) leaves, per 8x8 region, the mask of the pixels that need
+// real path tracing and their number as a key.  The frame time is set by the longest per-wave chain,
+// so the fullest regions start first: a counting sort (descending) of the keys; regions with key 0
+// sort last and are never visited (order[n] = number of regions with work).  The order only changes
+// WHEN a region is rendered, never its pixels.
 // one workgroup: histogram (256 bins) -> descending offsets -> scatter
 __global__ void pt_region_sort(const unsigned char *keys, int n, int *order) {
   __shared__ int hist[256];
@@ -1140,10 +1161,16 @@ __global__ void pt_region_sort(const unsigned char *keys, int n, int *order) {
       offs[k] = run;
       run += hist[k];
     }
+    order[n] = n - hist[0];
   }
   __syncthreads();
   for (int i = threadIdx.x; i < n; i += blockDim.x) order[atomicAdd(&offs[keys[i]], 1)] = i;
 }
+
+#ifdef PT_DEBUG_TIME
+#define PT_TRACE_LEN 8192
+__device__ unsigned long long pt_trace[PT_TRACE_LEN];
+#endif
 
 // ---- PathTracer (render.py:99-139) as a per-lane state machine ----------------------------------------
 // The reference recursion is depth-first; frame `k` of the explicit stack is the call at depth k.
@@ -1160,9 +1187,23 @@ struct PathCtx {
   size_t stride;  // frame_doubles * nthreads
   size_t nthreads;
   int gtid;
+  int lds_base, lds_frame;  // LDS frames: first double of the frame area, doubles per frame
 };
-PT_DEV double &ws_at(const PathCtx &w, int slot, int field) {
+// The frame stack lives in LDS whenever (max_depth x frame) x 256 lanes fits beside the survivor masks
+// (LDSF): the second pass is a chain of dependent steps per pixel, and a frame access that goes to
+// HBM costs more than the step's arithmetic.  Same [slot][field][lane] layout in both homes.
+extern __shared__ double pt_lds_f64[];  // the same dynamic LDS block as pt_lds_masks
+template <bool LDSF>
+PT_DEV double ws_get(const PathCtx &w, int slot, int field) {
+  if (LDSF) return pt_lds_f64[w.lds_base + (slot * w.lds_frame + field) * PT_BLOCK + (int)threadIdx.x];
   return w.ws[(size_t)slot * w.stride + (size_t)field * w.nthreads + w.gtid];
+}
+template <bool LDSF>
+PT_DEV void ws_put(const PathCtx &w, int slot, int field, double v) {
+  if (LDSF)
+    pt_lds_f64[w.lds_base + (slot * w.lds_frame + field) * PT_BLOCK + (int)threadIdx.x] = v;
+  else
+    w.ws[(size_t)slot * w.stride + (size_t)field * w.nthreads + w.gtid] = v;
 }
 
 // next pixel for every lane with `need` set; returns -1 when the frame is exhausted
@@ -1195,8 +1236,10 @@ PT_DEV long long next_pixel(const PtKArgs &a, bool need, long long npix) {
 // pixels dynamically (wave-local counter) and P-steps use the hoisted, culled tile query against the
 // region's survivor masks.  !TILED (orthogonal camera): pixels come from one global queue and P-steps
 // run the full shape loop.
-template <bool TILED>
-__global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAVES_PATH, 8))) void pt_path_kernel(const PtKArgs a) {
+// LAT: the second pass of the two-pass scheme runs at most a wave or two per SIMD and its time is the
+// longest chain of dependent steps of one pixel: everything inline, registers no object.
+template <bool TILED, bool LDSF, bool LAT>
+PT_DEV void path_trace(const PtKArgs &a) {
   PathCtx w;
   int S, nsamp, N, W = 0, rows_local = 0, npass = 0, D = 0, rr = 0;
   {
@@ -1205,6 +1248,8 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAV
     w.nthreads = (size_t)c->nthreads;
     w.stride = (size_t)c->frame_doubles * w.nthreads;
     w.gtid = blockIdx.x * PT_BLOCK + threadIdx.x;
+    w.lds_frame = c->frame_doubles;
+    w.lds_base = TILED ? 4 * c->npass : 0;  // behind the four waves' survivor masks (8-byte units)
     S = c->S;
     N = c->N;
     W = c->W;
@@ -1219,8 +1264,8 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAV
   const int mbase = (threadIdx.x >> 6) * npass;
   const int regions_x = (W + PT_REGION - 1) / PT_REGION;
   const int nregions = regions_x * ((rows_local + PT_REGION - 1) / PT_REGION);
-  int region = -1, next_pos = PT_REGION * PT_REGION;  // TILED bookkeeping (wave-uniform)
   bool exhausted = false;           // !TILED: the global queue is empty
+  bool first_region = true;         // TILED (wave-uniform)
   unsigned long long nrays = 0;
 
   // lane state.  mode 0: starts a sample at the next P-step; 1: inside a path (S-steps); 2: no pixel
@@ -1279,7 +1324,10 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAV
     const bool uv = ax->needs_uv != 0;
     bool details = false;
     if (uv) {
-      hit_details_call(a.recs + hit, ax, &ray, best_t, &h, true);
+      if (LAT)
+        hit_details<true>(a.recs + hit, ax, ray, best_t, h, true);
+      else
+        hit_details_call(a.recs + hit, ax, &ray, best_t, &h, true);
       details = true;
     }
     hc = brdf_pigment(a, ax, h.u, h.v);
@@ -1325,28 +1373,33 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAV
       return;
     }
     // render.py:126-137: push the frame, child 0 is scattered at the next S-step
-    if (!details) hit_details_call(a.recs + hit, ax, &ray, best_t, &h, false);
-    ws_at(w, sp, 0) = hc.x;
-    ws_at(w, sp, 1) = hc.y;
-    ws_at(w, sp, 2) = hc.z;
-    ws_at(w, sp, 3) = em.x;
-    ws_at(w, sp, 4) = em.y;
-    ws_at(w, sp, 5) = em.z;
+    if (!details) {
+      if (LAT)
+        hit_details<true>(a.recs + hit, ax, ray, best_t, h, false);
+      else
+        hit_details_call(a.recs + hit, ax, &ray, best_t, &h, false);
+    }
+    ws_put<LDSF>(w, sp, 0, hc.x);
+    ws_put<LDSF>(w, sp, 1, hc.y);
+    ws_put<LDSF>(w, sp, 2, hc.z);
+    ws_put<LDSF>(w, sp, 3, em.x);
+    ws_put<LDSF>(w, sp, 4, em.y);
+    ws_put<LDSF>(w, sp, 5, em.z);
     if (N > 1) {
-      ws_at(w, sp, 6) = 0.0;
-      ws_at(w, sp, 7) = 0.0;
-      ws_at(w, sp, 8) = 0.0;
-      ws_at(w, sp, 9) = 0.0;
-      ws_at(w, sp, 10) = h.wp.x;
-      ws_at(w, sp, 11) = h.wp.y;
-      ws_at(w, sp, 12) = h.wp.z;
-      ws_at(w, sp, 13) = h.n.x;
-      ws_at(w, sp, 14) = h.n.y;
-      ws_at(w, sp, 15) = h.n.z;
-      ws_at(w, sp, 16) = ray.d.x;
-      ws_at(w, sp, 17) = ray.d.y;
-      ws_at(w, sp, 18) = ray.d.z;
-      ws_at(w, sp, 19) = (double)ax->brdf_kind;
+      ws_put<LDSF>(w, sp, 6, 0.0);
+      ws_put<LDSF>(w, sp, 7, 0.0);
+      ws_put<LDSF>(w, sp, 8, 0.0);
+      ws_put<LDSF>(w, sp, 9, 0.0);
+      ws_put<LDSF>(w, sp, 10, h.wp.x);
+      ws_put<LDSF>(w, sp, 11, h.wp.y);
+      ws_put<LDSF>(w, sp, 12, h.wp.z);
+      ws_put<LDSF>(w, sp, 13, h.n.x);
+      ws_put<LDSF>(w, sp, 14, h.n.y);
+      ws_put<LDSF>(w, sp, 15, h.n.z);
+      ws_put<LDSF>(w, sp, 16, ray.d.x);
+      ws_put<LDSF>(w, sp, 17, ray.d.y);
+      ws_put<LDSF>(w, sp, 18, ray.d.z);
+      ws_put<LDSF>(w, sp, 19, (double)ax->brdf_kind);
     }
     f_wp = h.wp;
     f_n = h.n;
@@ -1383,8 +1436,20 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAV
   };
 
 #ifdef PT_DEBUG_TIME
+  // section sums for every wave, plus a step-by-step trace of the wave that drew the first (fullest) region
   unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
-#define PT_STAMP(k) do { const unsigned long long tn = __builtin_amdgcn_s_memtime(); tsum[k] += tn - tprev; tprev = tn; } while (0)
+  bool tracing = false;
+  int trace_n = 0;
+#define PT_STAMP(k)                                                                        \
+  do {                                                                                     \
+    const unsigned long long tn = __builtin_amdgcn_s_memtime();                            \
+    tsum[k] += tn - tprev;                                                                 \
+    const unsigned long long np_ = (unsigned long long)__popcll(__ballot(mode == 1));     \
+    if (tracing && lane == 0 && trace_n < PT_TRACE_LEN)                                    \
+      pt_trace[trace_n] = ((tn - tprev) << 16) | (np_ << 8) | (k);                         \
+    if (tracing) trace_n++;                                                                \
+    tprev = tn;                                                                            \
+  } while (0)
 #else
 #define PT_STAMP(k) do { } while (0)
 #endif
@@ -1392,16 +1457,25 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAV
     PT_STAMP(7);
     // ---- pixels for idle lanes ----
     if (TILED) {
-      if (next_pos >= PT_REGION * PT_REGION && !__any(mode != 2)) {
-        // next region for this wave: one atomic by lane 0, then the region's cone and survivor masks
+      if (!__any(mode != 2)) {
+        // next region for this wave, then the region's cone and survivor masks.  The first one is the
+        // wave's own index (thousands of waves start together: one atomic each on the queue head would
+        // serialise them); later ones come from the queue, one atomic by lane 0.
         unsigned rid = 0;
-        if (lane == 0) rid = (unsigned)atomicAdd(cold_args(a)->queue, 1ULL);
-        region = (int)__builtin_amdgcn_readfirstlane((int)rid);
-        if (region >= nregions) break;
-        {
-          const int *order = cold_args(a)->region_order;  // expensive regions first (pt_region_sort)
-          if (order) region = order[region];
+        if (first_region) {
+          rid = blockIdx.x * (PT_BLOCK / 64) + (threadIdx.x >> 6);
+          first_region = false;
+        } else {
+          if (lane == 0) rid = gridDim.x * (PT_BLOCK / 64) + (unsigned)atomicAdd(cold_args(a)->queue, 1ULL);
         }
+        const int seq = (int)__builtin_amdgcn_readfirstlane((int)rid);
+#ifdef PT_DEBUG_TIME
+        tracing = seq == 0;
+#endif
+        const int *order = cold_args(a)->region_order;  // fullest regions first (pt_region_sort)
+        if (seq >= order[nregions]) break;
+        const int region = order[seq];
+        const unsigned long long todo = cold_args(a)->region_mask[region];  // left over by the first pass
         const int ry = region / regions_x, rx = region - ry * regions_x;
         const int gr0 = global_row(a, ry * PT_REGION);
         const int gr1 = global_row(a, (ry * PT_REGION + PT_REGION - 1 < rows_local) ? ry * PT_REGION + PT_REGION - 1 : rows_local - 1);
@@ -1417,23 +1491,10 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAV
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        next_pos = 0;
-      }
-      bool need = mode == 2;  // positions outside the image are skipped
-      while (next_pos < PT_REGION * PT_REGION) {
-        const unsigned long long nm = __ballot(need);
-        if (nm == 0ULL) break;
-        const int pos = next_pos + __popcll(nm & ((1ULL << lane) - 1ULL));
-        next_pos += __popcll(nm);
-        if (need && pos < PT_REGION * PT_REGION) {
-          const int ry = region / regions_x, rx = region - ry * regions_x;
-          const int lx = pos % PT_REGION, ly = pos / PT_REGION;
-          const int pc = rx * PT_REGION + lx, lrow = ry * PT_REGION + ly;
-          if (pc < W && lrow < rows_local) {
-            pix = (long long)lrow * W + pc;
-            mode = 0;
-            need = false;
-          }
+        // every lane is idle here: lane l takes pixel l of the region (the first pass's layout)
+        if ((todo >> lane) & 1ULL) {
+          pix = (long long)(ry * PT_REGION + (lane >> 3)) * W + (rx * PT_REGION + (lane & 7));
+          mode = 0;
         }
       }
     } else {
@@ -1455,8 +1516,8 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAV
     const int n_start = __popcll(__ballot(mode == 0));
     const int n_path = __popcll(__ballot(mode == 1));
     if (n_start == 0 && n_path == 0) continue;  // TILED: region exhausted, fetch the next one
-    const bool do_p = n_start > 0 && n_path < 48;
-    const bool do_s = n_path >= 16 || (n_path > 0 && !do_p);
+    const bool do_p = n_start > 0 && n_path < cold_args(a)->p_max_path;
+    const bool do_s = n_path >= cold_args(a)->s_min_path || (n_path > 0 && !do_p);
 
     // ---- queries: primary rays against the region's survivors, scattered rays against everything ----
     const bool prim = do_p && mode == 0;
@@ -1500,7 +1561,10 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAV
     while (unwinding) {
       if (spawn) {
         // scatter_ray consumes its draws even when the child is beyond max_depth
-        scatter_ray_call(f_brdf, &pcg, &f_in, &f_wp, &f_n, &ray);
+        if (LAT)
+          ray = scatter_ray<true>(f_brdf, pcg, f_in, f_wp, f_n);
+        else
+          scatter_ray_call(f_brdf, &pcg, &f_in, &f_wp, &f_n, &ray);
         spawn = false;
         if (sp > D) {  // render.py:100-101: the child returns black without a world query
           ret.x = 0.0;
@@ -1516,35 +1580,35 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAV
       }
       // a child of frame sp-1 returned `ret` (render.py:135-137)
       const int fs = sp - 1;
-      const V3 hc = {ws_at(w, fs, 0), ws_at(w, fs, 1), ws_at(w, fs, 2)};
+      const V3 hc = {ws_get<LDSF>(w, fs, 0), ws_get<LDSF>(w, fs, 1), ws_get<LDSF>(w, fs, 2)};
       V3 fc = {0.0, 0.0, 0.0};
       int done = 0;
       if (N > 1) {
-        fc.x = ws_at(w, fs, 6);
-        fc.y = ws_at(w, fs, 7);
-        fc.z = ws_at(w, fs, 8);
-        done = (int)ws_at(w, fs, 9);
+        fc.x = ws_get<LDSF>(w, fs, 6);
+        fc.y = ws_get<LDSF>(w, fs, 7);
+        fc.z = ws_get<LDSF>(w, fs, 8);
+        done = (int)ws_get<LDSF>(w, fs, 9);
       }
       fc.x = fc.x + hc.x * ret.x;
       fc.y = fc.y + hc.y * ret.y;
       fc.z = fc.z + hc.z * ret.z;
       done++;
       if (done < N) {
-        ws_at(w, fs, 6) = fc.x;
-        ws_at(w, fs, 7) = fc.y;
-        ws_at(w, fs, 8) = fc.z;
-        ws_at(w, fs, 9) = (double)done;
-        f_wp = {ws_at(w, fs, 10), ws_at(w, fs, 11), ws_at(w, fs, 12)};
-        f_n = {ws_at(w, fs, 13), ws_at(w, fs, 14), ws_at(w, fs, 15)};
-        f_in = {ws_at(w, fs, 16), ws_at(w, fs, 17), ws_at(w, fs, 18)};
-        f_brdf = (int)ws_at(w, fs, 19);
+        ws_put<LDSF>(w, fs, 6, fc.x);
+        ws_put<LDSF>(w, fs, 7, fc.y);
+        ws_put<LDSF>(w, fs, 8, fc.z);
+        ws_put<LDSF>(w, fs, 9, (double)done);
+        f_wp = {ws_get<LDSF>(w, fs, 10), ws_get<LDSF>(w, fs, 11), ws_get<LDSF>(w, fs, 12)};
+        f_n = {ws_get<LDSF>(w, fs, 13), ws_get<LDSF>(w, fs, 14), ws_get<LDSF>(w, fs, 15)};
+        f_in = {ws_get<LDSF>(w, fs, 16), ws_get<LDSF>(w, fs, 17), ws_get<LDSF>(w, fs, 18)};
+        f_brdf = (int)ws_get<LDSF>(w, fs, 19);
         spawn = true;
         continue;
       }
       // render.py:139
-      ret.x = ws_at(w, fs, 3) + fc.x * invN;
-      ret.y = ws_at(w, fs, 4) + fc.y * invN;
-      ret.z = ws_at(w, fs, 5) + fc.z * invN;
+      ret.x = ws_get<LDSF>(w, fs, 3) + fc.x * invN;
+      ret.y = ws_get<LDSF>(w, fs, 4) + fc.y * invN;
+      ret.z = ws_get<LDSF>(w, fs, 5) + fc.z * invN;
       sp = fs;
     }
     PT_STAMP(5);
@@ -1554,6 +1618,17 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAV
     for (int q = 0; q < 8; ++q) atomicAdd(cold_args(a)->queue + 1 + q, tsum[q]);
 #endif
   add_ray_count(a, nrays);
+}
+
+// every pixel of the frame, pixels from one queue (orthogonal camera): throughput matters
+template <bool LDSF>
+__global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAVES_PATH, 8))) void pt_path_kernel(const PtKArgs a) {
+  path_trace<false, LDSF, false>(a);
+}
+// second pass behind pt_tile_kernel<PATHTRACER> (perspective camera): the flagged pixels, by region
+template <bool LDSF>
+__global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(1, 2))) void pt_path_regions_kernel(const PtKArgs a) {
+  path_trace<true, LDSF, true>(a);
 }
 
 // ---- primitive probe: lets the tests check IEEE exactness of device sqrt / div and measure the ulp

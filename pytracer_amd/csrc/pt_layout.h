@@ -93,9 +93,12 @@ struct PtKArgs {
   unsigned long long *ray_counter; // per-workgroup partial counts; may be null
   unsigned long long *queue;       // path tracer: next unassigned pixel (zeroed per launch)
   const int *region_order;         // path tracer: region visiting order (may be null = raster order)
+  unsigned long long *region_mask; // path tracer: [region] pixels the first pass left to pt_path_kernel
+  unsigned char *region_keys;      // path tracer: [region] their number
   unsigned int *cell_list;         // large scenes: [cell][cell_stride] surviving slots (pt_cell_kernel)
   int *cell_count;                 // [cell] survivors
   int cells_x, cell_stride;
+  int p_max_path, s_min_path;      // path tracer step batching (see pt_path_kernel)
   long long npix;                  // pixels this launch covers (rows_local * W)
   int n_shapes, n_lights;
   int n_spheres;                   // recs[0..n_spheres) are spheres, recs[n_spheres..n_shapes) planes

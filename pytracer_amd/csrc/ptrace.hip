@@ -63,6 +63,7 @@ struct pt_scene {
   PtKArgs *args_dev = nullptr;          // device copy of the argument block (cold fields)
   unsigned char *region_keys = nullptr;  // path tracer region ordering
   int *region_order = nullptr;
+  unsigned long long *region_mask = nullptr;
   int region_cap = 0;
   unsigned int *cell_list = nullptr;  // large scenes: per-cell survivor lists (pt_cell_kernel)
   int *cell_count = nullptr;
@@ -177,6 +178,7 @@ extern "C" void pt_scene_free(pt_scene *s) {
   (void)hipFree(s->args_dev);
   (void)hipFree(s->region_keys);
   (void)hipFree(s->region_order);
+  (void)hipFree(s->region_mask);
   (void)hipFree(s->cell_list);
   (void)hipFree(s->cell_count);
   if (s->ray_counter_host) (void)hipHostFree(s->ray_counter_host);
@@ -433,6 +435,16 @@ static int check_params(const pt_scene *s, const pt_camera *cam, const pt_params
   return PT_OK;
 }
 
+// LDS one workgroup of the path tracer may use (gfx950: 160 KiB per CU, all of it available to one
+// workgroup), less the few static bytes of the kernel itself
+static const size_t PT_LDS_BUDGET = 160 * 1024 - 512;
+
+// dynamic LDS above the default 64 KiB has to be asked for, once per kernel
+static hipError_t path_lds_limit(const void *kernel, size_t bytes) {
+  if (bytes <= 64 * 1024) return hipSuccess;
+  return hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PT_LDS_BUDGET);
+}
+
 static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *out_dev, hipStream_t st) {
   PtKArgs a;
   memset(&a, 0, sizeof a);
@@ -494,14 +506,25 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
   // grid: one lane per pixel up to the resident capacity of the chip, grid-stride beyond
   const long long want = (a.npix + PT_BLOCK - 1) / PT_BLOCK;
   long long cap = (long long)s->n_cu * 8;  // 8 x 256-thread workgroups per CU = 32 waves/CU
+  static const int env_cull = getenv("PTRACE_CULL") ? atoi(getenv("PTRACE_CULL")) : 1;
+  size_t frame_lds = 0;
+  bool lds_frames = false;  // path tracer: the frame stack fits in LDS
   if (p->renderer == PT_RENDERER_PATHTRACER) {
     // The path tracer hands pixels out dynamically; fewer resident lanes than pixels lets a lane
     // that drew a cheap pixel take several more while its neighbours finish an expensive one.
     static const int env_wg = getenv("PTRACE_PATH_WG_PER_CU") ? atoi(getenv("PTRACE_PATH_WG_PER_CU")) : 0;
-    const int wg_per_cu = env_wg > 0 ? env_wg : 3;
+    static const int env_ldsf = getenv("PTRACE_LDS_FRAMES") ? atoi(getenv("PTRACE_LDS_FRAMES")) : 1;
+    // one queue for all pixels: 152 VGPRs, 3 waves per SIMD; second pass by regions: built for 1-2
+    const bool regions = cam->kind == PT_CAMERA_PERSPECTIVE && s->n_shapes > 0 && env_cull != 0;
+    int wg_per_cu = env_wg > 0 ? env_wg : (regions ? 2 : 3);
+    // a frame is pushed for depths 0 .. max_depth-1 only (a hit at max_depth spawns nothing that is traced)
+    a.frame_doubles = p->num_of_rays > 1 ? 20 : 6;
+    frame_lds = (size_t)std::max(p->max_depth, 1) * a.frame_doubles * PT_BLOCK * sizeof(double);
+    const size_t mask_lds = (cam->kind == PT_CAMERA_PERSPECTIVE && env_cull != 0) ? (size_t)4 * a.npass * sizeof(unsigned long long) : 0;
+    lds_frames = env_ldsf != 0 && frame_lds + mask_lds <= PT_LDS_BUDGET;
+    if (lds_frames) wg_per_cu = std::min<int>(wg_per_cu, (int)(PT_LDS_BUDGET / (frame_lds + mask_lds)));
     cap = (long long)s->n_cu * wg_per_cu;
   }
-  static const int env_cull = getenv("PTRACE_CULL") ? atoi(getenv("PTRACE_CULL")) : 1;
   // the tiled path tracer (perspective camera): primary rays use the hoisted, culled tile query
   const bool path_tiled = p->renderer == PT_RENDERER_PATHTRACER && cam->kind == PT_CAMERA_PERSPECTIVE &&
                           s->n_shapes > 0 && env_cull != 0;
@@ -517,9 +540,11 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
     const long long wave_tiles = (long long)((p->width + 7) / 8) * ((rows + 7) / 8);
     grid = (int)std::max<long long>(1, std::min<long long>((wave_tiles + 3) / 4, tcap));
   }
+  int grid_first = 0;  // path tracer, first pass (pt_tile_kernel<PATHTRACER>): one wave per 8x8 region
   if (path_tiled) {
     const long long regions = (long long)((p->width + PT_REGION - 1) / PT_REGION) * ((rows + PT_REGION - 1) / PT_REGION);
     grid = (int)std::max<long long>(1, std::min<long long>((regions + 3) / 4, cap));
+    grid_first = (int)std::max<long long>(1, std::min<long long>((regions + 3) / 4, (long long)s->n_cu * 8));
   }
   a.nthreads = grid * PT_BLOCK;
   s->stats.grid = grid;
@@ -527,13 +552,13 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
   s->stats.lds_bytes = 0;
 
   if (s->count_rays) {
-    if (grid > s->ray_partials_n) {
+    if (grid + grid_first > s->ray_partials_n) {
       HIP_TRY(hipStreamSynchronize(st));
       if (s->ray_partials) HIP_TRY(hipFree(s->ray_partials));
       s->ray_partials = nullptr;
       s->ray_partials_n = 0;
-      HIP_TRY(hipMalloc((void **)&s->ray_partials, (size_t)grid * sizeof(unsigned long long)));
-      s->ray_partials_n = grid;
+      HIP_TRY(hipMalloc((void **)&s->ray_partials, (size_t)(grid + grid_first) * sizeof(unsigned long long)));
+      s->ray_partials_n = grid + grid_first;
     }
     a.ray_counter = s->ray_partials;
   }
@@ -567,10 +592,12 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
   }
   if (p->renderer == PT_RENDERER_PATHTRACER) {
     HIP_TRY(hipMemsetAsync(s->queue, 0, 16 * sizeof(unsigned long long), st));
-    a.frame_doubles = p->num_of_rays > 1 ? 20 : 6;
-    const size_t slots = (size_t)std::max(p->max_depth, 0) + 1;
-    const size_t need = slots * a.frame_doubles * (size_t)a.nthreads * sizeof(double);
-    if (need > s->ws_bytes) {
+    static const int env_pmax = getenv("PTRACE_P_MAXPATH") ? atoi(getenv("PTRACE_P_MAXPATH")) : 8;
+    static const int env_smin = getenv("PTRACE_S_MIN") ? atoi(getenv("PTRACE_S_MIN")) : 16;
+    a.p_max_path = env_pmax;
+    a.s_min_path = env_smin;
+    const size_t need = (size_t)std::max(p->max_depth, 1) * a.frame_doubles * (size_t)a.nthreads * sizeof(double);
+    if (!lds_frames && need > s->ws_bytes) {
       HIP_TRY(hipStreamSynchronize(st));
       if (s->ws) HIP_TRY(hipFree(s->ws));
       s->ws = nullptr;
@@ -581,30 +608,33 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
     a.ws = s->ws;
   }
 
-  // path tracer: visit the expensive regions first (pt_region_keys / pt_region_sort)
-  static const int env_order = getenv("PTRACE_REGION_ORDER") ? atoi(getenv("PTRACE_REGION_ORDER")) : 1;
+  // path tracer: per-region masks/keys from the first pass, visiting order from pt_region_sort
   const int nregions = path_tiled ? ((p->width + PT_REGION - 1) / PT_REGION) * ((rows + PT_REGION - 1) / PT_REGION) : 0;
-  const bool ordered = path_tiled && env_order != 0 && nregions > 4 * grid;
-  if (ordered) {
+  if (path_tiled) {
     if (nregions > s->region_cap) {
       HIP_TRY(hipStreamSynchronize(st));
       if (s->region_keys) HIP_TRY(hipFree(s->region_keys));
       if (s->region_order) HIP_TRY(hipFree(s->region_order));
+      if (s->region_mask) HIP_TRY(hipFree(s->region_mask));
       s->region_keys = nullptr;
       s->region_order = nullptr;
+      s->region_mask = nullptr;
       s->region_cap = 0;
       HIP_TRY(hipMalloc((void **)&s->region_keys, (size_t)nregions));
-      HIP_TRY(hipMalloc((void **)&s->region_order, (size_t)nregions * sizeof(int)));
+      HIP_TRY(hipMalloc((void **)&s->region_order, ((size_t)nregions + 1) * sizeof(int)));
+      HIP_TRY(hipMalloc((void **)&s->region_mask, (size_t)nregions * sizeof(unsigned long long)));
       s->region_cap = nregions;
     }
     a.region_order = s->region_order;
+    a.region_keys = s->region_keys;
+    a.region_mask = s->region_mask;
   }
   // large scenes: two-level culling (cells of PT_CELL x PT_CELL global pixels, then 8x8 tiles)
   static const int env_hier = getenv("PTRACE_HIER_MIN") ? atoi(getenv("PTRACE_HIER_MIN")) : 256;
   const int cells_x = (p->width + PT_CELL - 1) / PT_CELL, cells_y = (p->height + PT_CELL - 1) / PT_CELL;
   const int ncells = cells_x * cells_y;
   const int cell_stride = (s->n_shapes + 63) / 64 * 64;
-  const bool hier = tile && env_hier >= 0 && s->n_shapes > env_hier && (a.n_ranks == 1 || a.row_block % 8 == 0) &&
+  const bool hier = (tile || path_tiled) && env_hier >= 0 && s->n_shapes > env_hier && (a.n_ranks == 1 || a.row_block % 8 == 0) &&
                     (size_t)ncells * cell_stride * sizeof(unsigned int) <= ((size_t)2 << 30);
   if (hier) {
     const size_t need = (size_t)ncells * cell_stride;
@@ -640,17 +670,13 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
   }
   const bool prof = s->timing && s->profiling && (size_t)(2 * s->prof_used + 1) < s->prof.size();
   if (s->timing) HIP_TRY(hipEventRecord(prof ? s->prof[2 * s->prof_used] : s->ev0, st));
-  // (inside the timed bracket: the ordering pre-pass is part of the frame's kernel time)
-  if (ordered) {
-    hipLaunchKernelGGL(pt_region_keys, dim3(std::min(grid, (nregions + 3) / 4)), dim3(PT_BLOCK), 0, st, a, s->region_keys);
-    hipLaunchKernelGGL(pt_region_sort, dim3(1), dim3(1024), 0, st, s->region_keys, nregions, s->region_order);
-  }
-  if (tile) {
+  if (tile || path_tiled) {
 #ifdef PT_DEBUG_TIME
     HIP_TRY(hipMemsetAsync(s->queue, 0, 16 * sizeof(unsigned long long), st));
 #endif
     const size_t lds = (size_t)4 * a.npass * sizeof(unsigned long long);
     s->stats.lds_bytes = (int)lds;
+    const int tgrid = path_tiled ? grid_first : grid;
     if (hier) {
       // enough (cell group, shape chunk) pairs to fill the chip; a chunk is a multiple of the block
       const int ngroups = ((cells_x + 1) / 2) * ((cells_y + 1) / 2), max_chunks = (s->n_shapes + PT_BLOCK - 1) / PT_BLOCK;
@@ -661,13 +687,27 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
       HIP_TRY(hipMemsetAsync(s->cell_count, 0, (size_t)ncells * sizeof(int), st));
       hipLaunchKernelGGL(pt_cell_kernel, dim3(ngroups * nchunks), dim3(PT_BLOCK), 0, st, a, nchunks, chunk_len);
       if (p->renderer == PT_RENDERER_ONOFF)
-        hipLaunchKernelGGL((pt_tile_kernel<PT_RENDERER_ONOFF, 4, true>), dim3(grid), dim3(PT_BLOCK), lds, st, a);
+        hipLaunchKernelGGL((pt_tile_kernel<PT_RENDERER_ONOFF, 4, true>), dim3(tgrid), dim3(PT_BLOCK), lds, st, a, 0);
+      else if (p->renderer == PT_RENDERER_FLAT)
+        hipLaunchKernelGGL((pt_tile_kernel<PT_RENDERER_FLAT, 4, true>), dim3(tgrid), dim3(PT_BLOCK), lds, st, a, 0);
       else
-        hipLaunchKernelGGL((pt_tile_kernel<PT_RENDERER_FLAT, 4, true>), dim3(grid), dim3(PT_BLOCK), lds, st, a);
+        hipLaunchKernelGGL((pt_tile_kernel<PT_RENDERER_PATHTRACER, 4, true>), dim3(tgrid), dim3(PT_BLOCK), lds, st, a, grid);
     } else if (p->renderer == PT_RENDERER_ONOFF)
-      hipLaunchKernelGGL((pt_tile_kernel<PT_RENDERER_ONOFF, 4, false>), dim3(grid), dim3(PT_BLOCK), lds, st, a);
+      hipLaunchKernelGGL((pt_tile_kernel<PT_RENDERER_ONOFF, 4, false>), dim3(tgrid), dim3(PT_BLOCK), lds, st, a, 0);
+    else if (p->renderer == PT_RENDERER_FLAT)
+      hipLaunchKernelGGL((pt_tile_kernel<PT_RENDERER_FLAT, 4, false>), dim3(tgrid), dim3(PT_BLOCK), lds, st, a, 0);
     else
-      hipLaunchKernelGGL((pt_tile_kernel<PT_RENDERER_FLAT, 4, false>), dim3(grid), dim3(PT_BLOCK), lds, st, a);
+      hipLaunchKernelGGL((pt_tile_kernel<PT_RENDERER_PATHTRACER, 4, false>), dim3(tgrid), dim3(PT_BLOCK), lds, st, a, grid);
+    if (path_tiled) {
+      // second pass: the pixels the first one flagged, fullest regions first
+      hipLaunchKernelGGL(pt_region_sort, dim3(1), dim3(1024), 0, st, s->region_keys, nregions, s->region_order);
+      if (lds_frames) {
+        HIP_TRY(path_lds_limit((const void *)pt_path_regions_kernel<true>, lds + frame_lds));
+        hipLaunchKernelGGL((pt_path_regions_kernel<true>), dim3(grid), dim3(PT_BLOCK), lds + frame_lds, st, a);
+      } else {
+        hipLaunchKernelGGL((pt_path_regions_kernel<false>), dim3(grid), dim3(PT_BLOCK), lds, st, a);
+      }
+    }
   } else
   switch (p->renderer) {
     case PT_RENDERER_ONOFF:
@@ -689,12 +729,11 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
         hipLaunchKernelGGL((pt_simple_kernel<PT_RENDERER_POINTLIGHT, false>), dim3(grid), dim3(PT_BLOCK), 0, st, a);
       break;
     default:
-      if (path_tiled) {
-        const size_t lds = (size_t)4 * a.npass * sizeof(unsigned long long);
-        s->stats.lds_bytes = (int)lds;
-        hipLaunchKernelGGL(pt_path_kernel<true>, dim3(grid), dim3(PT_BLOCK), lds, st, a);
+      if (lds_frames) {
+        HIP_TRY(path_lds_limit((const void *)pt_path_kernel<true>, frame_lds));
+        hipLaunchKernelGGL((pt_path_kernel<true>), dim3(grid), dim3(PT_BLOCK), frame_lds, st, a);
       } else {
-        hipLaunchKernelGGL(pt_path_kernel<false>, dim3(grid), dim3(PT_BLOCK), 0, st, a);
+        hipLaunchKernelGGL((pt_path_kernel<false>), dim3(grid), dim3(PT_BLOCK), 0, st, a);
       }
       break;
   }
@@ -710,7 +749,7 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
     s->stats_valid = false;
   }
   if (s->count_rays) {
-    hipLaunchKernelGGL(pt_sum_counts, dim3(1), dim3(256), 0, st, s->ray_partials, grid, s->ray_counter);
+    hipLaunchKernelGGL(pt_sum_counts, dim3(1), dim3(256), 0, st, s->ray_partials, grid + grid_first, s->ray_counter);
     HIP_TRY(hipMemcpyAsync(s->ray_counter_host, s->ray_counter, sizeof(unsigned long long),
                            hipMemcpyDeviceToHost, st));
   }
@@ -970,6 +1009,14 @@ extern "C" int pt_debug_read_queue(pt_scene *s, unsigned long long *out16) {
   HIP_TRY(hipMemcpy(out16, s->queue, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   return PT_OK;
 }
+
+#ifdef PT_DEBUG_TIME
+extern "C" int pt_debug_read_trace(unsigned long long *out, int n) {
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(pt_trace), (size_t)std::min(n, PT_TRACE_LEN) * sizeof(unsigned long long)));
+  return PT_OK;
+}
+#endif
 
 // ---- diagnostics (not part of the reference seam): device primitive probe used by the tests -------------
 extern "C" int pt_debug_probe(int op, const double *x, const double *y, double *out, int n) {

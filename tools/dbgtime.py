@@ -9,15 +9,30 @@ W, H = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1280, 720
 nsph = int(sys.argv[3]) if len(sys.argv) > 3 else 32
 flat = flatten.flatten_world(scenes.synthetic_world(nsph, wide=nsph > 64))
 cam = flatten.flatten_camera(scenes.synthetic_camera(W, H))
-par = abi.make_params(W, H, abi.RENDERER_PATHTRACER, samples_per_side=4, num_of_rays=1, max_depth=3, rr_limit=3, path_state=45, path_seq=54)
+par = abi.make_params(W, H, abi.RENDERER_PATHTRACER, samples_per_side=int(os.environ.get('DBG_S', 4)), num_of_rays=int(os.environ.get('DBG_N', 1)), max_depth=3, rr_limit=3, path_state=45, path_seq=54)
 ds = DeviceScene(flat)
 for _ in range(2):
     out = ds.render(cam, par)
 q = (C.c_ulonglong * 16)()
 _lib.lib().pt_debug_read_queue(ds._h, q)
 t = np.array([q[i] for i in range(1, 9)], dtype=np.float64)
-names = ["handout", "start_sample", "tile query", "shade+finish(P)", "unwind/scatter(S)", "full query+shade(S)", "-", "loop top"]
+names = ["0 handout", "1 start_sample", "2 tile query (P)", "3 -", "4 full query (S)", "5 shade+unwind+scatter", "6 -", "7 loop top"]
 print("kernel ms", ds.stats().kernel_ms, "rays", ds.stats().n_rays)
 for n, v in zip(names, t):
     print(f"{n:22s} {v:12.0f} cycles")
 print("sum", t.sum(), "= per wave", t.sum() / (ds.stats().grid * 4))
+
+if os.environ.get("DBG_TRACE"):
+    n = 8192
+    buf = (C.c_ulonglong * n)()
+    _lib.lib().pt_debug_read_trace(buf, n)
+    rows = [(buf[i] >> 16, (buf[i] >> 8) & 0xff, buf[i] & 0xff) for i in range(n) if buf[i]]
+    print("trace entries", len(rows))
+    import collections
+    agg = collections.defaultdict(lambda: [0, 0])
+    for t, npath, k in rows:
+        agg[k][0] += 1
+        agg[k][1] += t
+    for k in sorted(agg):
+        print(f"stamp {k}: n={agg[k][0]} total={agg[k][1]} ticks avg={agg[k][1]/agg[k][0]:.1f}")
+    print("first 80:", " ".join(f"{k}:{t}({npth})" for t, npth, k in rows[:80]))
