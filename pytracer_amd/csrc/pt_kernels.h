@@ -339,6 +339,153 @@ PT_DEV int world_query(const PtKArgs &a, const Ray &r, double tmax, double &best
   return best;
 }
 
+// ---- closest hit for the latency-bound second pass of the path tracer -------------------------------
+// Same arithmetic and same candidate order as world_query<false, false>; what changes is the schedule.
+// A dependent fp64 operation takes ~24 cycles on gfx950 and that pass runs about one wave per SIMD, so
+// the one-sphere-at-a-time loop is a chain of ~10 dependent steps per sphere plus sqrt and two
+// divisions whenever any lane's line meets the sphere.  Here four (two for rotated spheres)
+// independent spheres are evaluated side by side, and the roots are taken for a group at once.
+//  * A sphere with bb > 0 and cc >= 0 (origin outside, moving away) is skipped without roots: then
+//    4*aa*cc >= 0, so delta <= fl(bb*bb), sqrt(delta) <= sqrt(fl(bb*bb)) = bb exactly (radix 2, no
+//    underflow: guarded by bb > 1e-100), hence both of the reference's computed roots are <= 0 < tmin.
+//  * The far roots of a group are computed when some lane's near root fails its range test (the
+//    reference does so per ray; a far root nobody selects changes nothing).
+struct LatCand {
+  double aa, bb, cc, delta;
+};
+#define PT_LAT_NEED(C) (active && (C).delta > 0.0 && !((C).bb > 1e-100 && (C).cc >= 0.0))
+#define PT_LAT_ROOTS(C, T1, T2)                       \
+  do {                                                \
+    const double sd_ = sqrt((C).delta);               \
+    const double den_ = 2.0 * (C).aa;                 \
+    T1 = (-(C).bb - sd_) / den_;                      \
+    T2 = (-(C).bb + sd_) / den_;                      \
+  } while (0)
+#define PT_LAT_INRANGE(T) (((T) > tmin) && ((T) < tmax))
+#define PT_LAT_ROOT1(C, T1) T1 = (-(C).bb - sqrt((C).delta)) / (2.0 * (C).aa)
+#define PT_LAT_ROOT2(C, T2) T2 = (-(C).bb + sqrt((C).delta)) / (2.0 * (C).aa)
+#define PT_LAT_TAKE(NEED, T1, T2, SLOT)                                                      \
+  do {                                                                                       \
+    const bool ok1_ = ((T1) > tmin) && ((T1) < tmax);                                        \
+    const double t_ = ok1_ ? (T1) : (T2);                                                    \
+    const bool ok_ = ok1_ || (((T2) > tmin) && ((T2) < tmax));                               \
+    if ((NEED) && ok_ && (t_ < best_t || (t_ == best_t && tie_wins(a, (SLOT), best)))) {     \
+      best_t = t_;                                                                           \
+      best = (SLOT);                                                                         \
+    }                                                                                        \
+  } while (0)
+
+// roots and candidate update for one sphere, skipped wave-wide when no lane needs them
+#define PT_LAT_ONE(NEED, C, SLOT)                                             \
+  do {                                                                        \
+    if (__ballot(NEED) != 0ULL) {                                             \
+      double t1_, t2_ = 0.0;                                                  \
+      PT_LAT_ROOT1(C, t1_);                                                   \
+      if (__ballot((NEED) && !PT_LAT_INRANGE(t1_)) != 0ULL) PT_LAT_ROOT2(C, t2_); \
+      PT_LAT_TAKE(NEED, t1_, t2_, SLOT);                                      \
+    }                                                                         \
+  } while (0)
+
+PT_DEV LatCand lat_cand(double ox, double oy, double oz, double dx, double dy, double dz) {
+  LatCand c;
+  c.aa = dx * dx + dy * dy + dz * dz;
+  c.cc = (ox * ox + oy * oy + oz * oz) - 1.0;
+  c.bb = 2.0 * (ox * dx + oy * dy + oz * dz);
+  c.delta = c.bb * c.bb - 4.0 * c.aa * c.cc;
+  return c;
+}
+
+PT_DEV int world_query_lat(const PtKArgs &a, const Ray &r, double &best_t, bool active) {
+  int best = -1;
+  best_t = INFINITY;
+  const double tmin = r.tmin, tmax = INFINITY;
+  const int nd = a.n_diag, ns = a.n_spheres, n = a.n_shapes;
+  int first_general = 0;
+
+  // one sphere through the full 3x4 product (shapes.py:102-121)
+  auto full = [&](int i) {
+    pt_kdouble m = PT_KD(a.recs[i].invm);
+    const double dx = r.d.x * m[0] + r.d.y * m[1] + r.d.z * m[2];
+    const double dy = r.d.x * m[4] + r.d.y * m[5] + r.d.z * m[6];
+    const double dz = r.d.x * m[8] + r.d.y * m[9] + r.d.z * m[10];
+    const double ox = r.o.x * m[0] + r.o.y * m[1] + r.o.z * m[2] + m[3];
+    const double oy = r.o.x * m[4] + r.o.y * m[5] + r.o.z * m[6] + m[7];
+    const double oz = r.o.x * m[8] + r.o.y * m[9] + r.o.z * m[10] + m[11];
+    return lat_cand(ox, oy, oz, dx, dy, dz);
+  };
+  // one scale+translate sphere (bit-identical to the full product under the wave guard)
+  auto diag = [&](int i) {
+    pt_kdouble h = PT_KD(&a.diag[i]);
+    return lat_cand(r.o.x * h[0] + h[3], r.o.y * h[1] + h[4], r.o.z * h[2] + h[5], r.d.x * h[0], r.d.y * h[1], r.d.z * h[2]);
+  };
+
+  if (nd > 0) {
+    const WaveGuard g = wave_guard<false>(r, active);
+    if (g.fast) {
+      first_general = nd;
+      int i = 0;
+      for (; i + 4 <= nd; i += 4) {
+        // a zero o*s product could meet a zero translation in one of the four: full products for them
+        const unsigned tnz = (unsigned)(*PT_KI(&a.diag[i].tnz) & *PT_KI(&a.diag[i + 1].tnz) & *PT_KI(&a.diag[i + 2].tnz) &
+                                        *PT_KI(&a.diag[i + 3].tnz));
+        LatCand c0, c1, c2, c3;
+        if ((g.ozmask & ~tnz) == 0u) {
+          c0 = diag(i);
+          c1 = diag(i + 1);
+          c2 = diag(i + 2);
+          c3 = diag(i + 3);
+        } else {
+          c0 = full(i);
+          c1 = full(i + 1);
+          c2 = full(i + 2);
+          c3 = full(i + 3);
+        }
+        const bool n0 = PT_LAT_NEED(c0), n1 = PT_LAT_NEED(c1), n2 = PT_LAT_NEED(c2), n3 = PT_LAT_NEED(c3);
+        if (__ballot(n0 || n1 || n2 || n3) == 0ULL) continue;
+        PT_LAT_ONE(n0, c0, i);
+        PT_LAT_ONE(n1, c1, i + 1);
+        PT_LAT_ONE(n2, c2, i + 2);
+        PT_LAT_ONE(n3, c3, i + 3);
+      }
+      for (; i < nd; ++i) {
+        const unsigned tnz = (unsigned)*PT_KI(&a.diag[i].tnz);
+        const LatCand c0 = ((g.ozmask & ~tnz) == 0u) ? diag(i) : full(i);
+        const bool n0 = PT_LAT_NEED(c0);
+        if (__ballot(n0) == 0ULL) continue;
+        double a1, a2;
+        PT_LAT_ROOTS(c0, a1, a2);
+        PT_LAT_TAKE(n0, a1, a2, i);
+      }
+    }
+  }
+  // ---- spheres, full product, two at a time ----
+  int i = first_general;
+  for (; i + 2 <= ns; i += 2) {
+    const LatCand c0 = full(i), c1 = full(i + 1);
+    const bool n0 = PT_LAT_NEED(c0), n1 = PT_LAT_NEED(c1);
+    if (__ballot(n0 || n1) == 0ULL) continue;
+    PT_LAT_ONE(n0, c0, i);
+    PT_LAT_ONE(n1, c1, i + 1);
+  }
+  for (; i < ns; ++i) {
+    const LatCand c0 = full(i);
+    const bool n0 = PT_LAT_NEED(c0);
+    if (__ballot(n0) == 0ULL) continue;
+    double a1, a2;
+    PT_LAT_ROOTS(c0, a1, a2);
+    PT_LAT_TAKE(n0, a1, a2, i);
+  }
+  // ---- planes: shapes.py:168-175, only the z row of the object-space ray decides ----
+  constexpr bool ANYHIT = false;  // (for PT_PLANE_HIT)
+  for (int k = ns; k < n; ++k) {
+    pt_kdouble m = PT_KD(a.recs[k].invm);
+    const double dz = r.d.x * m[8] + r.d.y * m[9] + r.d.z * m[10];
+    const double oz = r.o.x * m[8] + r.o.y * m[9] + r.o.z * m[10] + m[11];
+    PT_PLANE_HIT(k);
+  }
+  return best;
+}
+
 // ---- the closest hit's HitRecord (shapes.py:123-131, 177-189; world.py:66-67) ----------------------
 // Computed once per ray for the winner only; every value is a pure function of (ray, shape, t), so
 // it equals what the reference computed for that candidate.
@@ -1153,18 +1300,25 @@ __global__ void pt_region_sort(const unsigned char *keys, int n, int *order) {
   __shared__ int offs[256];
   for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
   __syncthreads();
-  for (int i = threadIdx.x; i < n; i += blockDim.x) atomicAdd(&hist[keys[i]], 1);
+  // (regions with key 0 -- usually most of the frame -- are never visited and get no place at all)
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int k = keys[i];
+    if (k) atomicAdd(&hist[k], 1);
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
     int run = 0;
-    for (int k = 255; k >= 0; --k) {
+    for (int k = 255; k >= 1; --k) {
       offs[k] = run;
       run += hist[k];
     }
-    order[n] = n - hist[0];
+    order[n] = run;
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < n; i += blockDim.x) order[atomicAdd(&offs[keys[i]], 1)] = i;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int k = keys[i];
+    if (k) order[atomicAdd(&offs[k], 1)] = i;
+  }
 }
 
 #ifdef PT_DEBUG_TIME
@@ -1541,7 +1695,7 @@ PT_DEV void path_trace(const PtKArgs &a) {
     }
     if (do_s) {
       double ts;
-      const int hs = world_query<false, false>(a, ray, INFINITY, ts, scat);
+      const int hs = LAT ? world_query_lat(a, ray, ts, scat) : world_query<false, false>(a, ray, INFINITY, ts, scat);
       if (scat) {
         hit = hs;
         best_t = ts;
