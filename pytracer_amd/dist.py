@@ -29,12 +29,13 @@ def max_shard_rows(height: int, row_block: int, world_size: int) -> int:
 
 
 def gather_image(local: torch.Tensor, height: int, row_block: int, group=None, dst: int = 0,
-                 out: Optional[torch.Tensor] = None, scratch: Optional[List[torch.Tensor]] = None
-                 ) -> Optional[torch.Tensor]:
+                 out: Optional[torch.Tensor] = None, scratch: Optional[List[torch.Tensor]] = None,
+                 row_index: Optional[List[torch.Tensor]] = None) -> Optional[torch.Tensor]:
     """Gather the ranks' compact row shards to ``dst`` and de-interleave them into ``[H, W, 3]``.
 
     ``local`` is ``[max_shard_rows, W, 3]`` (shards padded to a uniform size).  Returns the full
-    image on ``dst`` and ``None`` elsewhere."""
+    image on ``dst`` and ``None`` elsewhere.  ``row_index[r]`` (optional, on the device) caches rank r's
+    global row numbers so a frame loop does not rebuild and upload them every frame."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     if world == 1:
@@ -47,7 +48,8 @@ def gather_image(local: torch.Tensor, height: int, row_block: int, group=None, d
         if out is None:
             out = torch.empty((height,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         for r in range(world):
-            idx = torch.as_tensor(shard_rows(height, row_block, world, r), dtype=torch.long, device=local.device)
+            idx = row_index[r] if row_index is not None else torch.as_tensor(
+                shard_rows(height, row_block, world, r), dtype=torch.long, device=local.device)
             out.index_copy_(0, idx, scratch[r][: idx.numel()])
         return out
     dist.gather(local, None, dst=dst, group=group)
@@ -99,27 +101,31 @@ class ShardedFrameLoop:
         self.comm = torch.cuda.Stream() if self.world > 1 else None
         self.scratch = None
         self.full = None
+        self.row_index = None
         if self.world > 1 and self.rank == 0:
             self.scratch = [[torch.empty_like(self.bufs[0]) for _ in range(self.world)] for _ in range(2)]
             self.full = [torch.empty((self.height, self.width, 3), dtype=dt, device=self.device) for _ in range(2)]
+            self.row_index = [torch.as_tensor(shard_rows(self.height, row_block, self.world, r), dtype=torch.long,
+                                              device=self.device) for r in range(self.world)]
         self._free = [None, None]  # event: the gather that last read buffer b is done
         self.last = 0
 
-    def step(self, i: int) -> None:
+    def step(self, i: int, gather: bool = True) -> None:
+        """Render frame ``i`` into this rank's buffer; with ``gather`` also assemble it on rank 0."""
         b = i & 1
         if self._free[b] is not None:
             self.stream.wait_event(self._free[b])
         self.scene.render_into(self.cam, self.params, self.bufs[b].data_ptr(), self.nbytes,
                                self.stream.cuda_stream)
         self.last = b
-        if self.world > 1:
+        if self.world > 1 and gather:
             rendered = torch.cuda.Event()
             rendered.record(self.stream)
             with torch.cuda.stream(self.comm):
                 self.comm.wait_event(rendered)
                 gather_image(self.bufs[b], self.height, self.row_block, group=self.group, dst=0,
                              out=self.full[b] if self.rank == 0 else None,
-                             scratch=self.scratch[b] if self.rank == 0 else None)
+                             scratch=self.scratch[b] if self.rank == 0 else None, row_index=self.row_index)
                 done = torch.cuda.Event()
                 done.record(self.comm)
                 self._free[b] = done
