@@ -723,6 +723,74 @@ __global__ void pt_prep_hoist(const PtShapeRec *recs, PtHoist *hoist, PtHoistDia
 }
 
 // ---- OnOff / Flat / PointLight: one world query per sample (+ shadow rays) ----------------------------
+// ---- PointLightRenderer (render.py:157-193): ambient + emitted + the lights the hit point sees --------
+// `bg` is what a miss returns; shadow rays handed to the world are counted in `nrays`.
+PT_DEV V3 pointlight_shade(const PtKArgs &a, const Ray &ray, int hit, double best_t, bool active, V3 bg,
+                           unsigned long long &nrays) {
+  const V3 c = bg;
+  const bool lit = active && hit >= 0;
+  Hit h;
+  h.wp = {0.0, 0.0, 0.0};
+  h.n = {0.0, 0.0, 1.0};
+  h.u = 0.0;
+  h.v = 0.0;
+  pt_kargs ca = cold_args(a);
+  const PtShapeAux *ax = ca->aux + (hit >= 0 ? hit : 0);
+  V3 res = c;
+  if (lit) {
+    hit_details(a.recs + hit, ax, ray, best_t, h, ax->needs_uv != 0);
+    const V3 em = emitted_pigment(a, ax, h.u, h.v);
+    res.x = ca->ambient[0] + em.x;
+    res.y = ca->ambient[1] + em.y;
+    res.z = ca->ambient[2] + em.z;
+  }
+  const int n_lights = ca->n_lights;
+  const PtLight *lights = ca->lights;
+  for (int l = 0; l < n_lights; ++l) {
+    pt_kdouble L = PT_KD(&lights[l]);
+    const V3 lp = {L[0], L[1], L[2]};
+    // world.py:71-80: shadow ray from the hit point towards the light, any-hit in (1e-2/|d|, 1)
+    Ray sh;
+    sh.o = lit ? h.wp : lp;
+    sh.d.x = lp.x - sh.o.x;
+    sh.d.y = lp.y - sh.o.y;
+    sh.d.z = lp.z - sh.o.z;
+    const double dn = sqrt(sh.d.x * sh.d.x + sh.d.y * sh.d.y + sh.d.z * sh.d.z);
+    sh.tmin = 1e-2 / dn;
+    double tlim;
+    const int blocked = world_query<true, false>(a, sh, 1.0, tlim, lit);
+    if (lit) nrays++;
+    if (lit && blocked < 0) {
+      const V3 dv = {h.wp.x - lp.x, h.wp.y - lp.y, h.wp.z - lp.z};
+      const double dist = sqrt(dv.x * dv.x + dv.y * dv.y + dv.z * dv.z);
+      const double inv = 1.0 / dist;
+      const V3 in_dir = {inv * dv.x, inv * dv.y, inv * dv.z};
+      const V3 neg_in = {-in_dir.x, -in_dir.y, -in_dir.z};
+      const double cos_theta = max2(0.0, dot3(normalize3(neg_in), normalize3(h.n)));
+      const double lr = L[6];
+      const double q = lr / dist;
+      const double df = (lr > 0) ? q * q : 1.0;
+      V3 bc = {0.0, 0.0, 0.0};
+      if (ax->brdf_kind == PT_BRDF_DIFFUSE) {  // materials.py:129-130
+        const V3 pc = brdf_pigment(a, ax, h.u, h.v);
+        const double k = 1.0 / PT_PI;
+        bc.x = pc.x * k;
+        bc.y = pc.y * k;
+        bc.z = pc.z * k;
+      } else {  // materials.py:164-173
+        const V3 out_dir = {-ray.d.x, -ray.d.y, -ray.d.z};
+        const double th_in = pt_acos(dot3(normalize3(h.n), normalize3(in_dir)));
+        const double th_out = pt_acos(dot3(normalize3(h.n), normalize3(out_dir)));
+        if (fabs(th_in - th_out) < ax->brdf_param) bc = brdf_pigment(a, ax, h.u, h.v);
+      }
+      res.x = res.x + bc.x * L[3] * cos_theta * df;
+      res.y = res.y + bc.y * L[4] * cos_theta * df;
+      res.z = res.z + bc.z * L[5] * cos_theta * df;
+    }
+  }
+  return res;
+}
+
 template <int RENDERER, bool HOIST>
 __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAVES_SIMPLE, 8))) void pt_simple_kernel(const PtKArgs a) {
   const int S = cold_args(a)->S;
@@ -783,67 +851,7 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAV
           c.z = p1.z + p2.z;
         }
       } else {  // PointLight, render.py:157-193
-        const bool lit = active && hit >= 0;
-        Hit h;
-        h.wp = {0.0, 0.0, 0.0};
-        h.n = {0.0, 0.0, 1.0};
-        h.u = 0.0;
-        h.v = 0.0;
-        pt_kargs ca = cold_args(a);
-        const PtShapeAux *ax = ca->aux + (hit >= 0 ? hit : 0);
-        V3 res = c;
-        if (lit) {
-          hit_details(a.recs + hit, ax, ray, best_t, h, ax->needs_uv != 0);
-          const V3 em = emitted_pigment(a, ax, h.u, h.v);
-          res.x = ca->ambient[0] + em.x;
-          res.y = ca->ambient[1] + em.y;
-          res.z = ca->ambient[2] + em.z;
-        }
-        const int n_lights = ca->n_lights;
-        const PtLight *lights = ca->lights;
-        for (int l = 0; l < n_lights; ++l) {
-          pt_kdouble L = PT_KD(&lights[l]);
-          const V3 lp = {L[0], L[1], L[2]};
-          // world.py:71-80: shadow ray from the hit point towards the light, any-hit in (1e-2/|d|, 1)
-          Ray sh;
-          sh.o = lit ? h.wp : lp;
-          sh.d.x = lp.x - sh.o.x;
-          sh.d.y = lp.y - sh.o.y;
-          sh.d.z = lp.z - sh.o.z;
-          const double dn = sqrt(sh.d.x * sh.d.x + sh.d.y * sh.d.y + sh.d.z * sh.d.z);
-          sh.tmin = 1e-2 / dn;
-          double tlim;
-          const int blocked = world_query<true, false>(a, sh, 1.0, tlim, lit);
-          if (lit) nrays++;
-          if (lit && blocked < 0) {
-            const V3 dv = {h.wp.x - lp.x, h.wp.y - lp.y, h.wp.z - lp.z};
-            const double dist = sqrt(dv.x * dv.x + dv.y * dv.y + dv.z * dv.z);
-            const double inv = 1.0 / dist;
-            const V3 in_dir = {inv * dv.x, inv * dv.y, inv * dv.z};
-            const V3 neg_in = {-in_dir.x, -in_dir.y, -in_dir.z};
-            const double cos_theta = max2(0.0, dot3(normalize3(neg_in), normalize3(h.n)));
-            const double lr = L[6];
-            const double q = lr / dist;
-            const double df = (lr > 0) ? q * q : 1.0;
-            V3 bc = {0.0, 0.0, 0.0};
-            if (ax->brdf_kind == PT_BRDF_DIFFUSE) {  // materials.py:129-130
-              const V3 pc = brdf_pigment(a, ax, h.u, h.v);
-              const double k = 1.0 / PT_PI;
-              bc.x = pc.x * k;
-              bc.y = pc.y * k;
-              bc.z = pc.z * k;
-            } else {  // materials.py:164-173
-              const V3 out_dir = {-ray.d.x, -ray.d.y, -ray.d.z};
-              const double th_in = pt_acos(dot3(normalize3(h.n), normalize3(in_dir)));
-              const double th_out = pt_acos(dot3(normalize3(h.n), normalize3(out_dir)));
-              if (fabs(th_in - th_out) < ax->brdf_param) bc = brdf_pigment(a, ax, h.u, h.v);
-            }
-            res.x = res.x + bc.x * L[3] * cos_theta * df;
-            res.y = res.y + bc.y * L[4] * cos_theta * df;
-            res.z = res.z + bc.z * L[5] * cos_theta * df;
-          }
-        }
-        c = res;
+        c = pointlight_shade(a, ray, hit, best_t, active, c, nrays);
       }
       if (S > 0) {
         cum.x = cum.x + c.x;
@@ -1218,6 +1226,10 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
           c.y = ca->onoff[1];
           c.z = ca->onoff[2];
         }
+      } else if (RENDERER == PT_RENDERER_POINTLIGHT) {
+        unsigned long long shadow_rays = 0;
+        c = pointlight_shade(a, ray, hit, best_t, alive, c, shadow_rays);
+        pix_rays += (int)shadow_rays;
       } else if (RENDERER == PT_RENDERER_PATHTRACER) {  // render.py:103-139 at depth 0, no recursion
         if (hit >= 0) {
           pt_kargs ca = cold_args(a);

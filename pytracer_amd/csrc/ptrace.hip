@@ -530,9 +530,10 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
                           s->n_shapes > 0 && env_cull != 0;
   const bool hoist = cam->kind == PT_CAMERA_PERSPECTIVE && s->n_shapes > 0 &&
                      (p->renderer != PT_RENDERER_PATHTRACER || path_tiled);
-  // 8x8 tiles with culled shape lists: primary rays of a perspective camera (OnOff, Flat)
+  // 8x8 tiles with culled shape lists: primary rays of a perspective camera (OnOff, Flat, PointLight)
   const bool tile = hoist && env_cull != 0 && s->n_shapes >= 4 &&
-                    (p->renderer == PT_RENDERER_ONOFF || p->renderer == PT_RENDERER_FLAT);
+                    (p->renderer == PT_RENDERER_ONOFF || p->renderer == PT_RENDERER_FLAT ||
+                     p->renderer == PT_RENDERER_POINTLIGHT);
   int grid = (int)std::max<long long>(1, std::min(want, cap));
   if (tile) {
     static const int env_twg = getenv("PTRACE_TILE_WG_PER_CU") ? atoi(getenv("PTRACE_TILE_WG_PER_CU")) : 0;
@@ -690,12 +691,16 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
         hipLaunchKernelGGL((pt_tile_kernel<PT_RENDERER_ONOFF, 4, true>), dim3(tgrid), dim3(PT_BLOCK), lds, st, a, 0);
       else if (p->renderer == PT_RENDERER_FLAT)
         hipLaunchKernelGGL((pt_tile_kernel<PT_RENDERER_FLAT, 4, true>), dim3(tgrid), dim3(PT_BLOCK), lds, st, a, 0);
+      else if (p->renderer == PT_RENDERER_POINTLIGHT)
+        hipLaunchKernelGGL((pt_tile_kernel<PT_RENDERER_POINTLIGHT, 4, true>), dim3(tgrid), dim3(PT_BLOCK), lds, st, a, 0);
       else
         hipLaunchKernelGGL((pt_tile_kernel<PT_RENDERER_PATHTRACER, 4, true>), dim3(tgrid), dim3(PT_BLOCK), lds, st, a, grid);
     } else if (p->renderer == PT_RENDERER_ONOFF)
       hipLaunchKernelGGL((pt_tile_kernel<PT_RENDERER_ONOFF, 4, false>), dim3(tgrid), dim3(PT_BLOCK), lds, st, a, 0);
     else if (p->renderer == PT_RENDERER_FLAT)
       hipLaunchKernelGGL((pt_tile_kernel<PT_RENDERER_FLAT, 4, false>), dim3(tgrid), dim3(PT_BLOCK), lds, st, a, 0);
+    else if (p->renderer == PT_RENDERER_POINTLIGHT)
+      hipLaunchKernelGGL((pt_tile_kernel<PT_RENDERER_POINTLIGHT, 4, false>), dim3(tgrid), dim3(PT_BLOCK), lds, st, a, 0);
     else
       hipLaunchKernelGGL((pt_tile_kernel<PT_RENDERER_PATHTRACER, 4, false>), dim3(tgrid), dim3(PT_BLOCK), lds, st, a, grid);
     if (path_tiled) {

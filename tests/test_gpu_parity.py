@@ -185,6 +185,8 @@ def _cluster_world(n, spread, seed, rotated=False):
     (40, 0.2, False, 64, 64, 3, abi.RENDERER_FLAT),
     (400, 1.5, True, 203, 117, 2, abi.RENDERER_FLAT),      # > 256 shapes: two-level culling (cells, then tiles)
     (400, 1.0, False, 160, 96, 0, abi.RENDERER_ONOFF),
+    (120, 0.6, False, 120, 72, 0, abi.RENDERER_POINTLIGHT),  # primary rays culled, shadow rays see every shape
+    (300, 1.0, False, 96, 64, 2, abi.RENDERER_POINTLIGHT),
 ])
 def test_tile_culling_is_invisible(dev, oracle, n, spread, rotated, W, H, S, renderer):
     """The culled tile kernel must equal the oracle bit for bit (uniform pigments on the spheres,
@@ -192,6 +194,9 @@ def test_tile_culling_is_invisible(dev, oracle, n, spread, rotated, W, H, S, ren
     from pytracer_amd import flatten, hostmodel as hm
 
     world = _cluster_world(n, spread, seed=11 + n, rotated=rotated)
+    if renderer == abi.RENDERER_POINTLIGHT:
+        world.add_light(hm.PointLight(hm.Vec(-2.0, 3.0, 6.0), hm.Color(1.0, 0.9, 0.8), 0.0))
+        world.add_light(hm.PointLight(hm.Vec(1.0, -4.0, 5.0), hm.Color(0.2, 0.3, 0.9), 2.0))
     scene = flatten.flatten_world(world)
     cam = flatten.flatten_camera(hm.PerspectiveCamera(1.0, W / H, hm.translation(hm.Vec(-1.0, 0.0, 1.0))))
     par = abi.make_params(W, H, renderer, samples_per_side=S, path_state=5, path_seq=77)

@@ -44,6 +44,8 @@ CONFIGS = {
     "c4crop": (256, False, True, 960, 540, dict(renderer=abi.RENDERER_PATHTRACER, samples_per_side=4, num_of_rays=1,
                                                 max_depth=5, rr_limit=3, path_state=45, path_seq=54)),
     "c5": (10000, False, True, 1280, 720, dict(renderer=abi.RENDERER_FLAT)),
+    "pl": (32, True, False, 1280, 720, dict(renderer=abi.RENDERER_POINTLIGHT, lights=2)),
+    "pl5": (10000, False, True, 1280, 720, dict(renderer=abi.RENDERER_POINTLIGHT, lights=1)),
     "c5small": (10000, False, True, 320, 180, dict(renderer=abi.RENDERER_FLAT)),
 }
 
@@ -56,7 +58,12 @@ def main():
     args = ap.parse_args()
     for name in args.names:
         ns, plane, wide, W, H, kw = CONFIGS[name]
-        flat = flatten.flatten_world(scenes.synthetic_world(ns, with_plane=plane, wide=wide))
+        kw = dict(kw)
+        world = scenes.synthetic_world(ns, with_plane=plane, wide=wide)
+        for l in range(kw.pop("lights", 0)):
+            from pytracer_amd import hostmodel as hm
+            world.add_light(hm.PointLight(hm.Vec(-3.0 + 4.0 * l, 6.0 - 9.0 * l, 8.0), hm.Color(1.0, 0.9, 0.8), 0.0))
+        flat = flatten.flatten_world(world)
         cam = flatten.flatten_camera(scenes.synthetic_camera(W, H))
         par = abi.make_params(W, H, out_format=abi.OUT_F64 if args.f64 else abi.OUT_F32, **kw)
         ds = DeviceScene(flat)
