@@ -891,6 +891,9 @@ struct TileCone {
   float cos_t, sin_t;
   float oabs;        // max |apex component| (error scale of C - O)
   bool all;          // wide cone / degenerate: keep everything
+  float kx, ky, kz;  // THIS lane's corner direction (corner lane & 3), un-normalised
+  float dmax2;       // upper bound of |d|^2 over the tile (|d|^2 is convex: max at a corner)
+  float dmin;        // lower bound of |d| over the tile (axis . d is affine: min at a corner)
 };
 
 // Rows of the tile are [grow0, grow1] (global image rows, inclusive), columns [x0, x1): the tile's
@@ -939,6 +942,16 @@ PT_DEV TileCone tile_cone(const ConeCam &k, int x0, int x1, int grow0, int grow1
   cs = fminf(cs, __shfl_xor(cs, 1, 64));
   cs = fminf(cs, __shfl_xor(cs, 2, 64));
   cs -= 4e-6f;  // fp32 evaluation of the directions (~3e-7 relative) + of the dot product
+  tc.kx = kx;
+  tc.ky = ky;
+  tc.kz = kz;
+  float k2 = kx * kx + ky * ky + kz * kz, pj = tc.ax * kx + tc.ay * ky + tc.az * kz;
+  k2 = fmaxf(k2, __shfl_xor(k2, 1, 64));
+  k2 = fmaxf(k2, __shfl_xor(k2, 2, 64));
+  pj = fminf(pj, __shfl_xor(pj, 1, 64));
+  pj = fminf(pj, __shfl_xor(pj, 2, 64));
+  tc.dmax2 = k2 * (1.0f + 1e-5f);
+  tc.dmin = pj * (1.0f - 1e-5f);
   tc.all = !(cs > 0.05f);  // also catches NaN
   tc.cos_t = cs;
   tc.sin_t = __fsqrt_rn(fmaxf(0.0f, 1.0f - cs * cs)) * (1.0f + 1e-5f) + 1e-7f;
@@ -967,6 +980,35 @@ PT_DEV bool cone_keeps(const TileCone &tc, float4 b) {
   const float q = perp * tc.cos_t - d * tc.sin_t;
   const float R = b.w * (1.0f + 1e-5f) + 4e-5f * (fabsf(d) + perp) + 3.0f * eps_abs;
   return !(q > R);  // also keeps NaN
+}
+
+// May a plane be hit by some ray of the tile?  (conservative: true when in doubt.)  shapes.py:168-175
+// hits only when t = -o'.z / d'.z is positive, i.e. when o'.z and d'.z have opposite signs.  o'.z is
+// the same for every primary ray (hoisted, exact); d'.z = row2(invm) . d is affine in the pixel
+// position, so if it has the sign of o'.z -- by a margin of 1e-4 |row2| |d|, ~100 times the fp32
+// error of this evaluation -- at the four corner directions it has that sign for every ray of the
+// tile and none of them can hit.  Called by the whole wave (it gathers the corners from lanes 0..3).
+PT_DEV bool plane_keeps(const PtKArgs &a, const TileCone &tc, int slot, bool isplane) {
+  float cxs[4], cys[4], czs[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    cxs[q] = __shfl(tc.kx, q, 64);
+    cys[q] = __shfl(tc.ky, q, 64);
+    czs[q] = __shfl(tc.kz, q, 64);
+  }
+  if (!isplane || tc.all) return true;
+  const double *m = a.recs[slot].invm;
+  const float rx = (float)m[8], ry = (float)m[9], rz = (float)m[10];
+  const double oz = a.hoist[slot].oz;
+  const float rn = __fsqrt_rn(rx * rx + ry * ry + rz * rz);
+  bool away = true;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float dz = rx * cxs[q] + ry * cys[q] + rz * czs[q];
+    const float thr = 1e-4f * rn * __fsqrt_rn(cxs[q] * cxs[q] + cys[q] * cys[q] + czs[q] * czs[q]);
+    away = away && ((oz > 0.0) ? (dz > thr) : ((oz < 0.0) ? (dz < -thr) : false));  // NaN: false
+  }
+  return !away;
 }
 
 // The survivor masks live in LDS and are always addressed through this array (never through a generic
@@ -1158,6 +1200,7 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
     PT_TSTAMP(1);
     int tpass = npass;
     const unsigned int *list = nullptr;
+    int nsurv = 0, only = 0;  // survivors of this tile; the slot of the last one (wave-uniform)
     if (HIER) {
       // the tile's 8 rows are consecutive global rows starting at a multiple of 8 (the host checks
       // row_block % 8 == 0), so they lie in one cell row
@@ -1168,23 +1211,113 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
       for (int p = 0; p < tpass; ++p) {
         const int idx = p * 64 + lane;
         bool keep = false;
-        if (idx < cnt) keep = cone_keeps(tc, a.bounds[list[idx]]);
+        int slot = 0;
+        if (idx < cnt) {
+          slot = (int)list[idx];
+          keep = cone_keeps(tc, a.bounds[slot]);
+        }
+        const bool isplane = idx < cnt && slot >= a.n_spheres;
+        if (__any(isplane)) {
+          const bool pk = plane_keeps(a, tc, slot, isplane);
+          if (isplane) keep = pk;
+        }
         const unsigned long long m = __ballot(keep);
         if (lane == 0) pt_lds_masks[mbase + p] = m;
+        nsurv += __popcll(m);
+        if (m) only = (int)list[p * 64 + (__ffsll((long long)m) - 1)];
       }
     } else {
       for (int p = 0; p < npass; ++p) {
         const int slot = p * 64 + lane;
         bool keep = false;
         if (slot < a.n_shapes) keep = cone_keeps(tc, p == 0 ? b_first : a.bounds[slot]);  // 16 B per lane, coalesced
+        const bool isplane = slot >= a.n_spheres && slot < a.n_shapes;
+        if (__any(isplane)) {
+          const bool pk = plane_keeps(a, tc, slot, isplane);
+          if (isplane) keep = pk;
+        }
         const unsigned long long m = __ballot(keep);
         if (lane == 0) pt_lds_masks[mbase + p] = m;
+        nsurv += __popcll(m);
+        if (m) only = p * 64 + (__ffsll((long long)m) - 1);
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     PT_TSTAMP(2);
+
+    // ---- one survivor that every ray of the tile is certain to hit (the sky dome): no rays needed ----
+    // The only shape that can be hit at all is a sphere with the camera well inside it (hoisted
+    // c = |o'|^2 - 1 < -0.5).  Then for every primary ray delta = bb^2 + 4 aa |c| > 0 and the far root
+    // is >= (1 - |o'|) / |d'| >= 0.29 / sqrt(|invm|_F^2 |d|^2) > 2.9e-4 > tmin (the product is
+    // checked < 1e6; pt_scene_upload stores |invm|_F^2 = +inf for shapes whose scale is not within
+    // 1e-6 .. 1e6, and |d| >= 1e-6 is checked, so nothing under- or overflows): the reference finds
+    // exactly this hit for every sample.  With uniform pigments its colour does not depend on the hit
+    // point, so each sample's value is known without generating the ray or drawing its jitter.
+    if (nsurv == 1 && only < a.n_spheres) {
+      only = __builtin_amdgcn_readfirstlane(only);
+      pt_kargs ca = cold_args(a);
+      const PtShapeAux *ax = ca->aux + only;
+      const double hc_ = (only < a.n_diag) ? PT_KD(&a.hoist_diag[only])[6] : PT_KD(&a.hoist[only])[3];
+      const float fro2 = (float)PT_KD(&a.recs[only])[13];  // PtShapeRec::fro2
+      if (hc_ < -0.5 && fro2 * tc.dmax2 < 1e6f && tc.dmin > 1e-6f && !tc.all && ax->needs_uv == 0) {
+        V3 c;
+        bool settled = true;
+        if (RENDERER == PT_RENDERER_ONOFF) {
+          c.x = ca->onoff[0];
+          c.y = ca->onoff[1];
+          c.z = ca->onoff[2];
+        } else if (RENDERER == PT_RENDERER_FLAT) {
+          const V3 p1 = brdf_pigment(a, ax, 0.0, 0.0), p2 = emitted_pigment(a, ax, 0.0, 0.0);
+          c.x = p1.x + p2.x;
+          c.y = p1.y + p2.y;
+          c.z = p1.z + p2.z;
+        } else if (RENDERER == PT_RENDERER_PATHTRACER) {
+          const V3 hc = brdf_pigment(a, ax, 0.0, 0.0), em = emitted_pigment(a, ax, 0.0, 0.0);
+          const double lum = max2(max2(hc.x, hc.y), hc.z);
+          settled = !(ca->rr <= 0 || lum > 0.0);  // else every pixel goes to the second pass
+          const double invN = 1.0 / (double)ca->N;
+          c.x = em.x + 0.0 * invN;
+          c.y = em.y + 0.0 * invN;
+          c.z = em.z + 0.0 * invN;
+        } else {
+          settled = false;  // PointLight needs the hit point: the ordinary path
+        }
+        if (RENDERER != PT_RENDERER_POINTLIGHT) {
+          if (settled) {
+            V3 cum = c;
+            if (S > 0) {  // imagetracer.py:83-101: the same additions, the same final scaling
+              cum.x = 0.0;
+              cum.y = 0.0;
+              cum.z = 0.0;
+              for (int s = 0; s < nsamp; ++s) {
+                cum.x = cum.x + c.x;
+                cum.y = cum.y + c.y;
+                cum.z = cum.z + c.z;
+              }
+              const double k = 1.0 / (double)(S * S);
+              cum.x = cum.x * k;
+              cum.y = cum.y * k;
+              cum.z = cum.z * k;
+            }
+            if (active) {
+              store_pixel(a, pix, cum);
+              nrays += (unsigned long long)nsamp;
+            }
+          }
+          if (RENDERER == PT_RENDERER_PATHTRACER) {
+            const unsigned long long todo = settled ? 0ULL : __ballot(active);
+            if (lane == 0) {
+              ca->region_mask[tile] = todo;
+              ca->region_keys[tile] = (unsigned char)__popcll(todo);
+            }
+          }
+          __builtin_amdgcn_wave_barrier();  // the next tile overwrites this wave's mask slice
+          continue;
+        }
+      }
+    }
 
     Pcg pcg;
     unsigned long long gpix = 0;

@@ -18,7 +18,8 @@ struct alignas(128) PtShapeRec {
   int32_t kind;     // PT_SHAPE_*
   int32_t index;    // position in World.shapes (records are grouped spheres-first; ties between
                     // equal t go to the lower index, world.py:62)
-  double _pad[3];
+  double fro2;      // spheres: upper bound of |invm 3x3|_F^2, +inf unless the scale is within 1e-6 .. 1e6
+  double _pad[2];
 };
 static_assert(sizeof(PtShapeRec) == 128, "PtShapeRec must be 128 B");
 

@@ -271,6 +271,27 @@ extern "C" int pt_scene_upload(const pt_scene_desc *d, int device, pt_scene **ou
     x.emi_tex = d->emi_tex[i];
     x.needs_uv = (d->pig_kind[i] != PT_PIGMENT_UNIFORM || d->emi_kind[i] != PT_PIGMENT_UNIFORM) ? 1 : 0;
     r.index = i;
+    // |invm|_F^2 for the "camera inside this sphere" shortcut of the tile kernel; +inf disables it unless
+    // every singular value of invm's 3x3 block is within 1e-6 .. 1e6 (Gershgorin bounds of invm^T invm)
+    r.fro2 = INFINITY;
+    if (r.kind == PT_SHAPE_SPHERE) {
+      double A[3][3], fro2 = 0.0;
+      for (int p = 0; p < 3; ++p)
+        for (int q = 0; q < 3; ++q) {
+          A[p][q] = 0.0;
+          for (int k = 0; k < 3; ++k) A[p][q] += r.invm[k * 4 + p] * r.invm[k * 4 + q];
+        }
+      double lmin = INFINITY, lmax = 0.0;
+      for (int p = 0; p < 3; ++p) {
+        double off = 0.0;
+        for (int q = 0; q < 3; ++q)
+          if (q != p) off += std::fabs(A[p][q]);
+        lmin = std::min(lmin, A[p][p] - off);
+        lmax = std::max(lmax, A[p][p] + off);
+        fro2 += A[p][p];
+      }
+      if (std::isfinite(fro2) && lmin >= 1e-12 && lmax <= 1e12) r.fro2 = fro2 * (1.0 + 1e-9);
+    }
   }
   std::vector<PtLight> lights(d->n_lights);
   for (int l = 0; l < d->n_lights; ++l) {
