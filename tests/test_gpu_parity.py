@@ -216,6 +216,75 @@ def test_tile_culling_is_invisible(dev, oracle, n, spread, rotated, W, H, S, ren
             assert util.bits_equal(got, ora)
 
 
+def _dome_world(dome, dome_material, n_small, seed, planes=()):
+    """A dome around the camera, a few small spheres that leave most tiles to the dome alone, planes."""
+    from pytracer_amd import hostmodel as hm
+
+    g = hm.PCG(seed, 9)
+    r = g.random_float
+    w = hm.World()
+    w.add_shape(hm.Sphere(dome, dome_material))
+    for _ in range(n_small):
+        rad = 0.05 + 0.1 * r()
+        w.add_shape(hm.Sphere(hm.translation(hm.Vec(2.0 + 3.0 * r(), 4.0 * (r() - 0.5), 1.0 + 2.0 * (r() - 0.5))) *
+                              hm.scaling(hm.Vec(rad, rad, rad)),
+                              hm.Material(hm.DiffuseBRDF(hm.UniformPigment(hm.Color(r(), r(), r()))),
+                                          hm.UniformPigment(hm.Color(0.1 * r(), 0.0, 0.0)))))
+    for t in planes:
+        w.add_shape(hm.Plane(t, hm.Material(hm.DiffuseBRDF(hm.CheckeredPigment(hm.Color(0.3, 0.5, 0.1), hm.Color(0.1, 0.2, 0.5), 2)))))
+    return w
+
+
+def _dome_cases():
+    from pytracer_amd import hostmodel as hm
+
+    sky = hm.Material(hm.DiffuseBRDF(hm.UniformPigment(hm.BLACK)), hm.UniformPigment(hm.Color(0.7, 0.5, 1.0)))
+    lit = hm.Material(hm.DiffuseBRDF(hm.UniformPigment(hm.Color(0.4, 0.3, 0.2))), hm.UniformPigment(hm.Color(0.2, 0.3, 0.4)))
+    chk = hm.Material(hm.DiffuseBRDF(hm.CheckeredPigment(hm.Color(0.9, 0.1, 0.1), hm.Color(0.1, 0.9, 0.1), 8)),
+                      hm.UniformPigment(hm.BLACK))
+    V, T, S_, RX, RZ = hm.Vec, hm.translation, hm.scaling, hm.rotation_x, hm.rotation_z
+    # the camera sits at (-1, 0, 1): |o'|^2 in the dome's frame decides whether the shortcut may run
+    return {
+        "sky50": (S_(V(50.0, 50.0, 50.0)), sky, ()),                                   # |o'|^2 = 8e-4
+        "ellipsoid": (T(V(0.5, -0.3, 0.8)) * RZ(25.0) * RX(40.0) * S_(V(9.0, 14.0, 7.0)), lit, ()),
+        "near_wall_in": (T(V(-1.0 + 6.2, 0.0, 1.0)) * S_(V(10.0, 10.0, 10.0)), sky, ()),   # |o'|^2 = 0.384: shortcut
+        "near_wall_out": (T(V(-1.0 + 7.5, 0.0, 1.0)) * S_(V(10.0, 10.0, 10.0)), sky, ()),  # |o'|^2 = 0.5625: no shortcut
+        "checkered": (S_(V(30.0, 30.0, 30.0)), chk, ()),                                # needs (u, v): no shortcut
+        "huge": (S_(V(1e7, 1e7, 1e7)), sky, ()),                                        # scale outside 1e-6..1e6
+        "planes": (S_(V(50.0, 50.0, 50.0)), sky,
+                   (T(V(0.0, 0.0, -0.25)), T(V(0.0, 0.0, 3.0)) * RX(180.0), T(V(8.0, 0.0, 0.0)) * RZ(20.0) * RX(80.0),
+                    T(V(0.0, 0.0, 1.0)), T(V(0.0, 6.0, 0.0)) * RX(93.0))),                 # 4th: the camera lies ON it
+    }
+
+
+@pytest.mark.parametrize("case", ["sky50", "ellipsoid", "near_wall_in", "near_wall_out", "checkered", "huge", "planes"])
+def test_dome_shortcut_and_plane_culling_are_invisible(dev, oracle, case):
+    """Tiles whose only survivor is a dome around the camera skip ray generation; planes are culled per
+    tile by the sign of d'.z at the tile corners.  Neither may change a bit, for any renderer."""
+    from pytracer_amd import flatten, hostmodel as hm
+
+    dome, material, planes = _dome_cases()[case]
+    world = _dome_world(dome, material, 6, seed=5, planes=planes)
+    scene = flatten.flatten_world(world)
+    W, H = 136, 88
+    cam = flatten.flatten_camera(hm.PerspectiveCamera(1.0, W / H, hm.translation(hm.Vec(-1.0, 0.0, 1.0))))
+    with dev.DeviceScene(scene) as ds:
+        for renderer, S in ((abi.RENDERER_FLAT, 0), (abi.RENDERER_FLAT, 3), (abi.RENDERER_ONOFF, 2)):
+            par = abi.make_params(W, H, renderer, samples_per_side=S, path_state=7, path_seq=11)
+            ora, n_rays = oracle.render(scene, cam, par, sqr_mode=oracle.SQR_MUL)
+            out = ds.render(cam, par)
+            assert ds.stats().lds_bytes > 0, "expected the tile kernel"
+            assert util.bits_equal(out, ora), f"{case} renderer {renderer} S={S}: max rel {util.rel_err(out, ora).max()}"
+            assert ds.stats().n_rays == n_rays
+        if case != "checkered":  # (sin/cos/atan2 of the device differ from libm in the last bit: not bit-exact)
+            par = abi.make_params(W, H, abi.RENDERER_PATHTRACER, samples_per_side=2, num_of_rays=2, max_depth=2,
+                                  rr_limit=1, path_state=45, path_seq=54)
+            ora, _ = oracle.render(scene, cam, par, sqr_mode=oracle.SQR_MUL)
+            out = ds.render(cam, par)
+            assert np.all(util.rel_err(out, ora) <= TOL)
+    oracle.set_sqr_mode(oracle.SQR_POW)
+
+
 @pytest.mark.parametrize("n_rays,depth,S,mode", [(1, 3, 4, abi.PCG_PIXEL), (2, 2, 2, abi.PCG_PIXEL),
                                                  (1, 5, 2, abi.PCG_SAMPLE), (3, 3, 0, abi.PCG_PIXEL)])
 def test_c3_pathtracer_vs_oracle(dev, oracle, n_rays, depth, S, mode):
