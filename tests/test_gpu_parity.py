@@ -345,6 +345,29 @@ def test_full_size_partition_invariance_and_determinism(dev):
     assert math.isfinite(float(full.sum())) and float(full.min()) >= 0.0
 
 
+def test_full_size_many_spheres_partition_invariance(dev):
+    """C5 (10 000 spheres, two-level culling): the cells are cut in GLOBAL pixels, so every partition
+    must give the frame of a single rank, bit for bit; fp32 output is the rounded fp64 output."""
+    scene, cam = _synthetic(10000, False, True, 1280, 720)
+    par = abi.make_params(1280, 720, abi.RENDERER_FLAT)
+    with dev.DeviceScene(scene) as ds:
+        full = ds.render(cam, par)
+        assert ds.stats().n_rays == 1280 * 720
+        for n_ranks, rb in ((2, 8), (8, 16), (5, 24), (3, 7)):  # (3, 7): blocks not multiples of 8 -> one-level culling
+            got = np.zeros_like(full)
+            n_rays = 0
+            for rank in range(n_ranks):
+                p = abi.copy_params(par, n_ranks=n_ranks, rank=rank, row_block=rb)
+                got[abi.rows_for_rank(720, rb, n_ranks, rank)] = ds.render(cam, p)
+                n_rays += ds.stats().n_rays
+            assert util.bits_equal(got, full), f"{n_ranks} ranks, blocks of {rb} rows"
+            assert n_rays == 1280 * 720
+        onoff = ds.render(cam, abi.copy_params(par, renderer=abi.RENDERER_ONOFF))
+        assert np.all(onoff == 1.0)
+        f32 = ds.render(cam, abi.copy_params(par, out_format=abi.OUT_F32))
+        assert np.array_equal(f32, full.astype(np.float32))
+
+
 def test_full_size_pathtracer_partition_invariance(dev):
     scene, cam = _synthetic(32, False, False, 1280, 720)
     par = abi.make_params(1280, 720, abi.RENDERER_PATHTRACER, samples_per_side=2, num_of_rays=1, max_depth=3,
