@@ -339,53 +339,19 @@ PT_DEV int world_query(const PtKArgs &a, const Ray &r, double tmax, double &best
   return best;
 }
 
-// ---- closest hit for the latency-bound second pass of the path tracer -------------------------------
-// Same arithmetic and same candidate order as world_query<false, false>; what changes is the schedule.
-// A dependent fp64 operation takes ~24 cycles on gfx950 and that pass runs about one wave per SIMD, so
-// the one-sphere-at-a-time loop is a chain of ~10 dependent steps per sphere plus sqrt and two
-// divisions whenever any lane's line meets the sphere.  Here four (two for rotated spheres)
-// independent spheres are evaluated side by side, and the roots are taken for a group at once.
+// ---- pieces of the scattered-ray query of the path tracer's second pass (world_query_lanes) ----------
+// Same arithmetic as world_query<false, false>; what changes is which spheres are looked at and when.
 //  * A sphere with bb > 0 and cc >= 0 (origin outside, moving away) is skipped without roots: then
 //    4*aa*cc >= 0, so delta <= fl(bb*bb), sqrt(delta) <= sqrt(fl(bb*bb)) = bb exactly (radix 2, no
 //    underflow: guarded by bb > 1e-100), hence both of the reference's computed roots are <= 0 < tmin.
-//  * The far roots of a group are computed when some lane's near root fails its range test (the
-//    reference does so per ray; a far root nobody selects changes nothing).
+//  * The far root is computed when some lane's near root fails its range test (the reference does so
+//    per ray; a far root nobody selects changes nothing).
 struct LatCand {
   double aa, bb, cc, delta;
 };
-#define PT_LAT_NEED(C) (active && (C).delta > 0.0 && !((C).bb > 1e-100 && (C).cc >= 0.0))
-#define PT_LAT_ROOTS(C, T1, T2)                       \
-  do {                                                \
-    const double sd_ = sqrt((C).delta);               \
-    const double den_ = 2.0 * (C).aa;                 \
-    T1 = (-(C).bb - sd_) / den_;                      \
-    T2 = (-(C).bb + sd_) / den_;                      \
-  } while (0)
 #define PT_LAT_INRANGE(T) (((T) > tmin) && ((T) < tmax))
 #define PT_LAT_ROOT1(C, T1) T1 = (-(C).bb - sqrt((C).delta)) / (2.0 * (C).aa)
 #define PT_LAT_ROOT2(C, T2) T2 = (-(C).bb + sqrt((C).delta)) / (2.0 * (C).aa)
-#define PT_LAT_TAKE(NEED, T1, T2, SLOT)                                                      \
-  do {                                                                                       \
-    const bool ok1_ = ((T1) > tmin) && ((T1) < tmax);                                        \
-    const double t_ = ok1_ ? (T1) : (T2);                                                    \
-    const bool ok_ = ok1_ || (((T2) > tmin) && ((T2) < tmax));                               \
-    if ((NEED) && ok_ && (t_ < best_t || (t_ == best_t && tie_wins(a, (SLOT), best)))) {     \
-      best_t = t_;                                                                           \
-      best = (SLOT);                                                                         \
-    }                                                                                        \
-  } while (0)
-
-// roots and candidate update for one sphere, skipped wave-wide when no lane needs them
-#define PT_LAT_ONE(NEED, C, SLOT)                                             \
-  do {                                                                        \
-    if (__ballot(NEED) != 0ULL) {                                             \
-      double t1_, t2_ = 0.0;                                                  \
-      PT_LAT_ROOT1(C, t1_);                                                   \
-      if (__ballot((NEED) && !PT_LAT_INRANGE(t1_)) != 0ULL) PT_LAT_ROOT2(C, t2_); \
-      PT_LAT_TAKE(NEED, t1_, t2_, SLOT);                                      \
-    }                                                                         \
-  } while (0)
-
 PT_DEV LatCand lat_cand(double ox, double oy, double oz, double dx, double dy, double dz) {
   LatCand c;
   c.aa = dx * dx + dy * dy + dz * dz;
@@ -395,88 +361,192 @@ PT_DEV LatCand lat_cand(double ox, double oy, double oz, double dx, double dy, d
   return c;
 }
 
-PT_DEV int world_query_lat(const PtKArgs &a, const Ray &r, double &best_t, bool active) {
+#ifdef PT_DEBUG_TIME
+__device__ unsigned long long pt_dbg[8];  // world_query_lanes: prefilter cycles, walk cycles, iterations, calls
+#endif
+// (the kernels' one dynamic LDS block, viewed as 64-bit words and as doubles; see pt_tile_kernel, path_trace)
+extern __shared__ unsigned long long pt_lds_masks[];
+extern __shared__ double pt_lds_f64[];
+
+// ---- closest hit, every lane on its own candidate list ---------------------------------------------------
+// The scattered rays of a wave point everywhere: for almost every sphere SOME lane's line meets it, so
+// a wave-uniform loop runs the fp64 candidate (and mostly the roots) for all of them.  Here each lane
+// first marks, in a 64-bit mask per 64 spheres, the spheres ITS ray can touch at all -- a conservative
+// test against the bounding spheres in packed fp32 (two spheres per v_pk instruction) -- and then
+// walks its own mask, fetching the records by lane-private index.  The exact arithmetic of a visited
+// sphere is the reference's; a sphere that is not visited has delta <= 0 or both roots negative:
+//  * line test: |v x d|^2 > (R'^2 + 8e-6 |v|^2) |d|^2 with v = C - o.  R' is the bounding radius
+//    inflated at upload for the fp32 rounding of C (and 1e-5 relative), 1e-6 |o| covers the rounding
+//    of the origin, 8e-6 |v|^2 the fp32 evaluation, the rounding of d and the slack the fp64 test
+//    itself has around delta = 0 (~16 ulp of |v|^2).
+//  * behind test: v.d < 0 and (v.d)^2 > 1.001 R'^2 |d|^2 + the same slack: the whole ball lies behind
+//    the origin, both roots are negative by a margin far above fp64 rounding.
+// NaN/inf on either side keep the sphere.  Order of visits differs from the list order only in WHEN a
+// candidate is seen; ties in t go to the lower World.shapes index as everywhere.
+PT_DEV int world_query_lanes(const PtKArgs &a, const Ray &r, double &best_t, bool active, int diag_lds) {
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  typedef const __attribute__((address_space(4))) float *pt_kfloat;
   int best = -1;
   best_t = INFINITY;
   const double tmin = r.tmin, tmax = INFINITY;
   const int nd = a.n_diag, ns = a.n_spheres, n = a.n_shapes;
-  int first_general = 0;
-
-  // one sphere through the full 3x4 product (shapes.py:102-121)
-  auto full = [&](int i) {
-    pt_kdouble m = PT_KD(a.recs[i].invm);
-    const double dx = r.d.x * m[0] + r.d.y * m[1] + r.d.z * m[2];
-    const double dy = r.d.x * m[4] + r.d.y * m[5] + r.d.z * m[6];
-    const double dz = r.d.x * m[8] + r.d.y * m[9] + r.d.z * m[10];
-    const double ox = r.o.x * m[0] + r.o.y * m[1] + r.o.z * m[2] + m[3];
-    const double oy = r.o.x * m[4] + r.o.y * m[5] + r.o.z * m[6] + m[7];
-    const double oz = r.o.x * m[8] + r.o.y * m[9] + r.o.z * m[10] + m[11];
-    return lat_cand(ox, oy, oz, dx, dy, dz);
-  };
-  // one scale+translate sphere (bit-identical to the full product under the wave guard)
-  auto diag = [&](int i) {
-    pt_kdouble h = PT_KD(&a.diag[i]);
-    return lat_cand(r.o.x * h[0] + h[3], r.o.y * h[1] + h[4], r.o.z * h[2] + h[5], r.d.x * h[0], r.d.y * h[1], r.d.z * h[2]);
-  };
-
-  if (nd > 0) {
-    const WaveGuard g = wave_guard<false>(r, active);
-    if (g.fast) {
-      first_general = nd;
-      int i = 0;
-      for (; i + 4 <= nd; i += 4) {
-        // a zero o*s product could meet a zero translation in one of the four: full products for them
-        const unsigned tnz = (unsigned)(*PT_KI(&a.diag[i].tnz) & *PT_KI(&a.diag[i + 1].tnz) & *PT_KI(&a.diag[i + 2].tnz) &
-                                        *PT_KI(&a.diag[i + 3].tnz));
-        LatCand c0, c1, c2, c3;
-        if ((g.ozmask & ~tnz) == 0u) {
-          c0 = diag(i);
-          c1 = diag(i + 1);
-          c2 = diag(i + 2);
-          c3 = diag(i + 3);
-        } else {
-          c0 = full(i);
-          c1 = full(i + 1);
-          c2 = full(i + 2);
-          c3 = full(i + 3);
-        }
-        const bool n0 = PT_LAT_NEED(c0), n1 = PT_LAT_NEED(c1), n2 = PT_LAT_NEED(c2), n3 = PT_LAT_NEED(c3);
-        if (__ballot(n0 || n1 || n2 || n3) == 0ULL) continue;
-        PT_LAT_ONE(n0, c0, i);
-        PT_LAT_ONE(n1, c1, i + 1);
-        PT_LAT_ONE(n2, c2, i + 2);
-        PT_LAT_ONE(n3, c3, i + 3);
-      }
-      for (; i < nd; ++i) {
-        const unsigned tnz = (unsigned)*PT_KI(&a.diag[i].tnz);
-        const LatCand c0 = ((g.ozmask & ~tnz) == 0u) ? diag(i) : full(i);
-        const bool n0 = PT_LAT_NEED(c0);
-        if (__ballot(n0) == 0ULL) continue;
-        double a1, a2;
-        PT_LAT_ROOTS(c0, a1, a2);
-        PT_LAT_TAKE(n0, a1, a2, i);
-      }
-    }
-  }
-  // ---- spheres, full product, two at a time ----
-  int i = first_general;
-  for (; i + 2 <= ns; i += 2) {
-    const LatCand c0 = full(i), c1 = full(i + 1);
-    const bool n0 = PT_LAT_NEED(c0), n1 = PT_LAT_NEED(c1);
-    if (__ballot(n0 || n1) == 0ULL) continue;
-    PT_LAT_ONE(n0, c0, i);
-    PT_LAT_ONE(n1, c1, i + 1);
-  }
-  for (; i < ns; ++i) {
-    const LatCand c0 = full(i);
-    const bool n0 = PT_LAT_NEED(c0);
-    if (__ballot(n0) == 0ULL) continue;
-    double a1, a2;
-    PT_LAT_ROOTS(c0, a1, a2);
-    PT_LAT_TAKE(n0, a1, a2, i);
-  }
-  // ---- planes: shapes.py:168-175, only the z row of the object-space ray decides ----
   constexpr bool ANYHIT = false;  // (for PT_PLANE_HIT)
+
+  const float ofx = (float)r.o.x, ofy = (float)r.o.y, ofz = (float)r.o.z;
+  const float dfx = (float)r.d.x, dfy = (float)r.d.y, dfz = (float)r.d.z;
+  const float dd = dfx * dfx + dfy * dfy + dfz * dfz;
+  const float eo = 1e-6f * fmaxf(fmaxf(fabsf(ofx), fabsf(ofy)), fabsf(ofz));
+  const float dd8 = 8e-6f * dd;
+  pt_kfloat bsx = (pt_kfloat)(const void *)a.bsoa, bsy = bsx + a.bs_stride, bsz = bsy + a.bs_stride, bsr = bsz + a.bs_stride;
+
+  // this lane may use o*s + t, d*s for a scale+translate sphere whose translation absorbs its zero products
+  const double lo = 1e-100, hi = 1e100;
+  const double adx = fabs(r.d.x), ady = fabs(r.d.y), adz = fabs(r.d.z);
+  const double aox = fabs(r.o.x), aoy = fabs(r.o.y), aoz = fabs(r.o.z);
+  const bool lane_fast = adx >= lo && adx <= hi && ady >= lo && ady <= hi && adz >= lo && adz <= hi && aox <= hi && aoy <= hi &&
+                         aoz <= hi;
+  const unsigned ozmask = (aox < lo ? 1u : 0u) | (aoy < lo ? 2u : 0u) | (aoz < lo ? 4u : 0u);
+
+#ifdef PT_DEBUG_TIME
+  unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime(), dbg_pre = 0, dbg_walk = 0, dbg_it = 0;
+#endif
+  for (int base = 0; base < ns; base += 64) {
+    const int cnt = ns - base < 64 ? ns - base : 64;
+    unsigned long long mask = 0ULL;
+    for (int j = 0; j < cnt; j += 8) {  // eight spheres per round of scalar loads (the arrays are padded)
+      typedef float f8 __attribute__((ext_vector_type(8)));
+      typedef const __attribute__((address_space(4))) f8 *pt_kf8;
+      const f8 X = *(pt_kf8)(bsx + base + j), Y = *(pt_kf8)(bsy + base + j), Z = *(pt_kf8)(bsz + base + j),
+               R = *(pt_kf8)(bsr + base + j);
+      unsigned m8 = 0u;
+#pragma unroll
+      for (int k = 0; k < 8; k += 2) {
+        const f2 cx = {X[k], X[k + 1]}, cy = {Y[k], Y[k + 1]}, cz = {Z[k], Z[k + 1]}, cr = {R[k], R[k + 1]};
+        const f2 vx = cx - ofx, vy = cy - ofy, vz = cz - ofz;
+        const f2 vd = vx * dfx + vy * dfy + vz * dfz;
+        const f2 vv = vx * vx + vy * vy + vz * vz;
+        const f2 t = vd * vd;
+        const f2 q = vv * dd - t;  // |v x d|^2 = dist^2 |d|^2
+        const f2 rk = cr + eo;
+        const f2 rdd = (rk * rk) * dd;
+        const f2 slack = vv * dd8;
+        const f2 rhs = rdd + slack, rhs_b = rdd * 1.001f + slack;
+        const bool rej0 = (q.x > rhs.x) || (vd.x < 0.0f && t.x > rhs_b.x);
+        const bool rej1 = (q.y > rhs.y) || (vd.y < 0.0f && t.y > rhs_b.y);
+        m8 |= (rej0 ? 0u : 1u << k) | (rej1 ? 0u : 2u << k);
+      }
+      mask |= (unsigned long long)m8 << j;
+    }
+    if (cnt < 64) mask &= (1ULL << cnt) - 1ULL;
+    if (!active) mask = 0ULL;
+#ifdef PT_DEBUG_TIME
+    {
+      const unsigned long long tn = __builtin_amdgcn_s_memtime();
+      dbg_pre += tn - dbg_t0;
+      dbg_t0 = tn;
+    }
+#endif
+    // walk the mask; the record of the NEXT candidate is requested before the current one is evaluated
+    struct DiagL {
+      double s0, s1, s2, t0, t1, t2;
+      int tnz;
+    };
+    auto fetch = [&](int slot) {
+      DiagL g;
+      g.s0 = g.s1 = g.s2 = g.t0 = g.t1 = g.t2 = 0.0;
+      g.tnz = 0;
+      if (slot < nd) {
+        if (diag_lds >= 0) {  // the table was staged in LDS by the kernel (path_trace)
+          const int o = diag_lds + slot * 8;
+          g.s0 = pt_lds_f64[o];
+          g.s1 = pt_lds_f64[o + 1];
+          g.s2 = pt_lds_f64[o + 2];
+          g.t0 = pt_lds_f64[o + 3];
+          g.t1 = pt_lds_f64[o + 4];
+          g.t2 = pt_lds_f64[o + 5];
+          g.tnz = (int)(unsigned)pt_lds_masks[o + 6];
+        } else {
+          const PtDiagRec *q = a.diag + slot;
+          g.s0 = q->s[0];
+          g.s1 = q->s[1];
+          g.s2 = q->s[2];
+          g.t0 = q->t[0];
+          g.t1 = q->t[1];
+          g.t2 = q->t[2];
+          g.tnz = q->tnz;
+        }
+      }
+      return g;
+    };
+    bool has = mask != 0ULL;
+    int slot = base + (has ? __ffsll((long long)mask) - 1 : 0);
+    mask &= mask - 1ULL;
+    DiagL g = fetch(slot);
+    while (__ballot(has) != 0ULL) {
+      const bool has_next = mask != 0ULL;
+      const int slot_next = base + (has_next ? __ffsll((long long)mask) - 1 : 0);
+      mask &= mask - 1ULL;
+      const DiagL g_next = fetch(slot_next);
+      // the object-space ray: shapes.py:102, full product or (bit-identical under the guard) o*s + t, d*s
+      double ox, oy, oz, dx, dy, dz;
+      if (!has || (slot < nd && lane_fast && (ozmask & ~(unsigned)g.tnz) == 0u)) {  // (!has: values unused)
+        dx = r.d.x * g.s0;
+        dy = r.d.y * g.s1;
+        dz = r.d.z * g.s2;
+        ox = r.o.x * g.s0 + g.t0;
+        oy = r.o.y * g.s1 + g.t1;
+        oz = r.o.z * g.s2 + g.t2;
+      } else {
+        const double *m = a.recs[slot].invm;
+        dx = r.d.x * m[0] + r.d.y * m[1] + r.d.z * m[2];
+        dy = r.d.x * m[4] + r.d.y * m[5] + r.d.z * m[6];
+        dz = r.d.x * m[8] + r.d.y * m[9] + r.d.z * m[10];
+        ox = r.o.x * m[0] + r.o.y * m[1] + r.o.z * m[2] + m[3];
+        oy = r.o.x * m[4] + r.o.y * m[5] + r.o.z * m[6] + m[7];
+        oz = r.o.x * m[8] + r.o.y * m[9] + r.o.z * m[10] + m[11];
+      }
+      const LatCand c = lat_cand(ox, oy, oz, dx, dy, dz);
+      const bool need = has && c.delta > 0.0 && !(c.bb > 1e-100 && c.cc >= 0.0);
+      if (__ballot(need) != 0ULL) {
+        double t1, t2 = 0.0;
+        PT_LAT_ROOT1(c, t1);
+        if (__ballot(need && !PT_LAT_INRANGE(t1)) != 0ULL) PT_LAT_ROOT2(c, t2);
+        const bool ok1 = PT_LAT_INRANGE(t1);
+        const double t = ok1 ? t1 : t2;
+        const bool ok = ok1 || PT_LAT_INRANGE(t2);
+        if (need && ok) {
+          bool take = t < best_t;
+          if (!take && t == best_t && best >= 0) take = a.recs[slot].index < a.recs[best].index;
+          if (take) {
+            best_t = t;
+            best = slot;
+          }
+        }
+      }
+      g = g_next;
+      slot = slot_next;
+      has = has_next;
+#ifdef PT_DEBUG_TIME
+      dbg_it++;
+#endif
+    }
+#ifdef PT_DEBUG_TIME
+    {
+      const unsigned long long tn = __builtin_amdgcn_s_memtime();
+      dbg_walk += tn - dbg_t0;
+      dbg_t0 = tn;
+    }
+#endif
+  }
+#ifdef PT_DEBUG_TIME
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&pt_dbg[0], dbg_pre);
+    atomicAdd(&pt_dbg[1], dbg_walk);
+    atomicAdd(&pt_dbg[2], dbg_it);
+    atomicAdd(&pt_dbg[3], 1ULL);
+  }
+#endif
+  // ---- planes: shapes.py:168-175, only the z row of the object-space ray decides (wave-uniform loop) ----
   for (int k = ns; k < n; ++k) {
     pt_kdouble m = PT_KD(a.recs[k].invm);
     const double dz = r.d.x * m[8] + r.d.y * m[9] + r.d.z * m[10];
@@ -1540,7 +1610,7 @@ PT_DEV long long next_pixel(const PtKArgs &a, bool need, long long npix) {
 template <bool TILED, bool LDSF, bool LAT>
 PT_DEV void path_trace(const PtKArgs &a) {
   PathCtx w;
-  int S, nsamp, N, W = 0, rows_local = 0, npass = 0, D = 0, rr = 0;
+  int S, nsamp, N, W = 0, rows_local = 0, npass = 0, D = 0, rr = 0, diag_lds = -1;
   {
     pt_kargs c = cold_args(a);
     w.ws = c->ws;
@@ -1549,6 +1619,7 @@ PT_DEV void path_trace(const PtKArgs &a) {
     w.gtid = blockIdx.x * PT_BLOCK + threadIdx.x;
     w.lds_frame = c->frame_doubles;
     w.lds_base = TILED ? 4 * c->npass : 0;  // behind the four waves' survivor masks (8-byte units)
+    diag_lds = c->diag_lds;
     S = c->S;
     N = c->N;
     W = c->W;
@@ -1556,6 +1627,12 @@ PT_DEV void path_trace(const PtKArgs &a) {
     npass = c->npass;
     D = c->D;
     rr = c->rr;
+  }
+  if (LAT && diag_lds >= 0) {
+    // scale+translate records into LDS: world_query_lanes fetches them by lane-private index
+    const unsigned long long *src = (const unsigned long long *)a.diag;
+    for (int k = threadIdx.x; k < a.n_diag * 8; k += PT_BLOCK) pt_lds_masks[diag_lds + k] = src[k];
+    __syncthreads();
   }
   nsamp = S > 0 ? S * S : 1;
   const double invN = 1.0 / (double)N;
@@ -1840,7 +1917,7 @@ PT_DEV void path_trace(const PtKArgs &a) {
     }
     if (do_s) {
       double ts;
-      const int hs = LAT ? world_query_lat(a, ray, ts, scat) : world_query<false, false>(a, ray, INFINITY, ts, scat);
+      const int hs = LAT ? world_query_lanes(a, ray, ts, scat, diag_lds) : world_query<false, false>(a, ray, INFINITY, ts, scat);
       if (scat) {
         hit = hs;
         best_t = ts;

@@ -86,6 +86,9 @@ struct PtKArgs {
   const PtDiagRec *diag;            // [n_diag], parallel to recs[0..n_diag)
   const PtHoistDiag *hoist_diag;    // [n_diag]
   const float4 *bounds;             // [n_shapes], slot order: (cx, cy, cz, r)
+  const float *bsoa;                // the same as four arrays x[], y[], z[], r'[] of bs_stride floats (per-ray prefilter)
+  int bs_stride;
+  int diag_lds;                     // second path-tracer pass: where its copy of diag[] starts in LDS (8-byte words), -1 = not staged
   const PtLight *lights;
   const PtTex *tex;
   const double *tex_data;

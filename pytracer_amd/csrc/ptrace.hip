@@ -48,6 +48,8 @@ struct pt_scene {
   PtDiagRec *diag = nullptr;
   PtHoistDiag *hoist_diag = nullptr;
   float4 *bounds = nullptr;
+  float *bsoa = nullptr;  // bounds as x[], y[], z[], r'[] (bs_stride floats each)
+  int bs_stride = 0;
   int n_diag = 0;
   PtLight *lights = nullptr;
   PtTex *tex = nullptr;
@@ -167,6 +169,7 @@ extern "C" void pt_scene_free(pt_scene *s) {
   (void)hipFree(s->diag);
   (void)hipFree(s->hoist_diag);
   (void)hipFree(s->bounds);
+  (void)hipFree(s->bsoa);
   (void)hipFree(s->lights);
   (void)hipFree(s->tex);
   (void)hipFree(s->tex_data);
@@ -385,8 +388,29 @@ extern "C" int pt_scene_upload(const pt_scene_desc *d, int device, pt_scene **ou
     f.w = (b.r >= 0.0 && std::isfinite(rw) && rw < 1e37 && cabs < 1e37) ? (float)rw * (1.0f + 1e-6f) : -1.0f;
     bounds[slot] = f;
   }
+  // ... and as structure-of-arrays for the per-ray prefilter of scattered rays (world_query_lanes): two
+  // neighbouring spheres per packed fp32 instruction.  r' = r*(1 + 1e-5) + 1e-6*max|c| rounded up;
+  // +inf where there is no bound (the test then always keeps the shape).
+  s->bs_stride = (n + 8 + 7) / 8 * 8;  // 8 floats of slack: the prefilter reads eight at a time, 32-byte aligned
+  std::vector<float> bsoa((size_t)4 * s->bs_stride, 0.0f);
+  for (int slot = 0; slot < s->bs_stride; ++slot) {
+    float rk = INFINITY;
+    if (slot < n) {
+      const float4 f = bounds[slot];
+      bsoa[slot] = f.x;
+      bsoa[(size_t)s->bs_stride + slot] = f.y;
+      bsoa[(size_t)2 * s->bs_stride + slot] = f.z;
+      if (f.w >= 0.0f) {
+        const double cabs = std::max(std::fabs((double)f.x), std::max(std::fabs((double)f.y), std::fabs((double)f.z)));
+        const double v = (double)f.w * (1.0 + 1e-5) + 1e-6 * cabs;
+        rk = std::nextafter((float)v, INFINITY);
+      }
+    }
+    bsoa[(size_t)3 * s->bs_stride + slot] = rk;
+  }
   UP(upload(&s->recs, recs));
   UP(upload(&s->bounds, bounds));
+  UP(upload(&s->bsoa, bsoa));
   UP(upload(&s->diag, diag));
   {
     std::vector<PtHoistDiag> hd(std::max(s->n_diag, 1));
@@ -476,6 +500,8 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
   a.hoist_diag = s->hoist_diag;
   a.queue = s->queue;
   a.bounds = s->bounds;
+  a.bsoa = s->bsoa;
+  a.bs_stride = s->bs_stride;
   a.n_diag = s->n_diag;
   a.lights = s->lights;
   a.tex = s->tex;
@@ -528,7 +554,7 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
   const long long want = (a.npix + PT_BLOCK - 1) / PT_BLOCK;
   long long cap = (long long)s->n_cu * 8;  // 8 x 256-thread workgroups per CU = 32 waves/CU
   static const int env_cull = getenv("PTRACE_CULL") ? atoi(getenv("PTRACE_CULL")) : 1;
-  size_t frame_lds = 0;
+  size_t frame_lds = 0, diag_lds_bytes = 0;
   bool lds_frames = false;  // path tracer: the frame stack fits in LDS
   if (p->renderer == PT_RENDERER_PATHTRACER) {
     // The path tracer hands pixels out dynamically; fewer resident lanes than pixels lets a lane
@@ -543,7 +569,18 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
     frame_lds = (size_t)std::max(p->max_depth, 1) * a.frame_doubles * PT_BLOCK * sizeof(double);
     const size_t mask_lds = (cam->kind == PT_CAMERA_PERSPECTIVE && env_cull != 0) ? (size_t)4 * a.npass * sizeof(unsigned long long) : 0;
     lds_frames = env_ldsf != 0 && frame_lds + mask_lds <= PT_LDS_BUDGET;
-    if (lds_frames) wg_per_cu = std::min<int>(wg_per_cu, (int)(PT_LDS_BUDGET / (frame_lds + mask_lds)));
+    // the scale+translate records ride along in LDS when they fit (world_query_lanes gathers them per lane)
+    const size_t base_lds = mask_lds + (lds_frames ? frame_lds : 0);
+    diag_lds_bytes = (size_t)s->n_diag * sizeof(PtDiagRec);
+    a.diag_lds = -1;
+    if (regions && s->n_diag > 0 && base_lds + diag_lds_bytes <= PT_LDS_BUDGET &&
+        diag_lds_bytes <= 48 * 1024) {
+      a.diag_lds = (int)(base_lds / 8);
+    } else {
+      diag_lds_bytes = 0;
+    }
+    if (lds_frames || diag_lds_bytes)
+      wg_per_cu = std::min<int>(wg_per_cu, (int)(PT_LDS_BUDGET / std::max<size_t>(1, base_lds + diag_lds_bytes)));
     cap = (long long)s->n_cu * wg_per_cu;
   }
   // the tiled path tracer (perspective camera): primary rays use the hoisted, culled tile query
@@ -728,10 +765,11 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
       // second pass: the pixels the first one flagged, fullest regions first
       hipLaunchKernelGGL(pt_region_sort, dim3(1), dim3(1024), 0, st, s->region_keys, nregions, s->region_order);
       if (lds_frames) {
-        HIP_TRY(path_lds_limit((const void *)pt_path_regions_kernel<true>, lds + frame_lds));
-        hipLaunchKernelGGL((pt_path_regions_kernel<true>), dim3(grid), dim3(PT_BLOCK), lds + frame_lds, st, a);
+        HIP_TRY(path_lds_limit((const void *)pt_path_regions_kernel<true>, lds + frame_lds + diag_lds_bytes));
+        hipLaunchKernelGGL((pt_path_regions_kernel<true>), dim3(grid), dim3(PT_BLOCK), lds + frame_lds + diag_lds_bytes, st, a);
       } else {
-        hipLaunchKernelGGL((pt_path_regions_kernel<false>), dim3(grid), dim3(PT_BLOCK), lds, st, a);
+        HIP_TRY(path_lds_limit((const void *)pt_path_regions_kernel<false>, lds + diag_lds_bytes));
+        hipLaunchKernelGGL((pt_path_regions_kernel<false>), dim3(grid), dim3(PT_BLOCK), lds + diag_lds_bytes, st, a);
       }
     }
   } else
@@ -1037,6 +1075,15 @@ extern "C" int pt_debug_read_queue(pt_scene *s, unsigned long long *out16) {
 }
 
 #ifdef PT_DEBUG_TIME
+extern "C" int pt_debug_read_dbg(unsigned long long *out8, int reset) {
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpyFromSymbol(out8, HIP_SYMBOL(pt_dbg), 8 * sizeof(unsigned long long)));
+  if (reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(pt_dbg), z, sizeof z));
+  }
+  return PT_OK;
+}
 extern "C" int pt_debug_read_trace(unsigned long long *out, int n) {
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(pt_trace), (size_t)std::min(n, PT_TRACE_LEN) * sizeof(unsigned long long)));

@@ -36,3 +36,10 @@ if os.environ.get("DBG_TRACE"):
     for k in sorted(agg):
         print(f"stamp {k}: n={agg[k][0]} total={agg[k][1]} ticks avg={agg[k][1]/agg[k][0]:.1f}")
     print("first 80:", " ".join(f"{k}:{t}({npth})" for t, npth, k in rows[:80]))
+
+if os.environ.get("DBG_LANES"):
+    d = (C.c_ulonglong * 8)()
+    _lib.lib().pt_debug_read_dbg(d, 1)
+    calls = max(1, d[3])
+    print(f"world_query_lanes: calls {d[3]}, prefilter {d[0]/calls:.0f} cycles/call, walk {d[1]/calls:.0f} cycles/call, "
+          f"iterations {d[2]/calls:.2f}/call -> {d[1]/max(1,d[2]):.0f} cycles/iteration")
