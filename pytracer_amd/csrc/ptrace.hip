@@ -651,10 +651,14 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
   }
   if (p->renderer == PT_RENDERER_PATHTRACER) {
     HIP_TRY(hipMemsetAsync(s->queue, 0, 16 * sizeof(unsigned long long), st));
-    static const int env_pmax = getenv("PTRACE_P_MAXPATH") ? atoi(getenv("PTRACE_P_MAXPATH")) : 8;
-    static const int env_smin = getenv("PTRACE_S_MIN") ? atoi(getenv("PTRACE_S_MIN")) : 16;
-    a.p_max_path = env_pmax;
-    a.s_min_path = env_smin;
+    // step batching (path_trace): the second pass by regions never mixes the two kinds of step (a P step
+    // waits until no lane holds a ray: its lanes then move sample by sample); the one-queue kernel, which
+    // also carries the cheap background pixels, starts samples while fewer than 48 lanes hold a ray and
+    // queries scattered rays once 16 wait
+    static const int env_pmax = getenv("PTRACE_P_MAXPATH") ? atoi(getenv("PTRACE_P_MAXPATH")) : 0;
+    static const int env_smin = getenv("PTRACE_S_MIN") ? atoi(getenv("PTRACE_S_MIN")) : 0;
+    a.p_max_path = env_pmax > 0 ? env_pmax : (path_tiled ? 1 : 48);
+    a.s_min_path = env_smin > 0 ? env_smin : (path_tiled ? 1 : 16);
     const size_t need = (size_t)std::max(p->max_depth, 1) * a.frame_doubles * (size_t)a.nthreads * sizeof(double);
     if (!lds_frames && need > s->ws_bytes) {
       HIP_TRY(hipStreamSynchronize(st));
