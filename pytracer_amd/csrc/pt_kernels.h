@@ -1054,11 +1054,13 @@ PT_DEV bool cone_keeps(const TileCone &tc, float4 b) {
 
 // May a plane be hit by some ray of the tile?  (conservative: true when in doubt.)  shapes.py:168-175
 // hits only when t = -o'.z / d'.z is positive, i.e. when o'.z and d'.z have opposite signs.  o'.z is
-// the same for every primary ray (hoisted, exact); d'.z = row2(invm) . d is affine in the pixel
+// the same for every primary ray (its sign is taken from an fp32 evaluation, and only when the value
+// is 1e-4 clear of zero relative to its terms); d'.z = row2(invm) . d is affine in the pixel
 // position, so if it has the sign of o'.z -- by a margin of 1e-4 |row2| |d|, ~100 times the fp32
 // error of this evaluation -- at the four corner directions it has that sign for every ray of the
 // tile and none of them can hit.  Called by the whole wave (it gathers the corners from lanes 0..3).
-PT_DEV bool plane_keeps(const PtKArgs &a, const TileCone &tc, int slot, bool isplane) {
+PT_DEV bool plane_keeps(const TileCone &tc, float4 b, bool isplane) {
+  // b = (row2(invm) as fp32, invm[11] as fp32): the plane slots of the bounds table (pt_scene_upload)
   float cxs[4], cys[4], czs[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -1067,16 +1069,17 @@ PT_DEV bool plane_keeps(const PtKArgs &a, const TileCone &tc, int slot, bool isp
     czs[q] = __shfl(tc.kz, q, 64);
   }
   if (!isplane || tc.all) return true;
-  const double *m = a.recs[slot].invm;
-  const float rx = (float)m[8], ry = (float)m[9], rz = (float)m[10];
-  const double oz = a.hoist[slot].oz;
+  const float rx = b.x, ry = b.y, rz = b.z;
   const float rn = __fsqrt_rn(rx * rx + ry * ry + rz * rz);
+  // the sign of o'.z from fp32: trusted only when |o'.z| stands clear of the rounding (else keep)
+  const float oz = rx * tc.ox + ry * tc.oy + rz * tc.oz + b.w;
+  if (!(fabsf(oz) > 1e-4f * (2.0f * rn * tc.oabs + fabsf(b.w)))) return true;  // also NaN
   bool away = true;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const float dz = rx * cxs[q] + ry * cys[q] + rz * czs[q];
     const float thr = 1e-4f * rn * __fsqrt_rn(cxs[q] * cxs[q] + cys[q] * cys[q] + czs[q] * czs[q]);
-    away = away && ((oz > 0.0) ? (dz > thr) : ((oz < 0.0) ? (dz < -thr) : false));  // NaN: false
+    away = away && ((oz > 0.0f) ? (dz > thr) : (dz < -thr));  // NaN: false
   }
   return !away;
 }
@@ -1189,11 +1192,12 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_cell_kernel(const PtKArgs a, int 
     const bool in = slot < s1;
     const float4 b = b_next;
     b_next = a.bounds[slot + PT_BLOCK < s1 ? slot + PT_BLOCK : 0];
-    if (!__ballot(in && cone_keeps(tg, b))) continue;
+    const bool isplane = slot >= a.n_spheres;  // planes carry no bounding sphere: every cell keeps them
+    if (!__ballot(in && (isplane || cone_keeps(tg, b)))) continue;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       if (cell[k] < 0) continue;
-      const unsigned long long m = __ballot(in && cone_keeps(tc[k], b));
+      const unsigned long long m = __ballot(in && (isplane || cone_keeps(tc[k], b)));
       if (!m) continue;
       int base = 0;
       if (lane == 0) base = atomicAdd(&nfound[k], __popcll(m));  // ds_add_rtn
@@ -1282,13 +1286,15 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
         const int idx = p * 64 + lane;
         bool keep = false;
         int slot = 0;
+        float4 b = {0.0f, 0.0f, 0.0f, -1.0f};
         if (idx < cnt) {
           slot = (int)list[idx];
-          keep = cone_keeps(tc, a.bounds[slot]);
+          b = a.bounds[slot];
         }
         const bool isplane = idx < cnt && slot >= a.n_spheres;
+        if (idx < cnt && !isplane) keep = cone_keeps(tc, b);
         if (__any(isplane)) {
-          const bool pk = plane_keeps(a, tc, slot, isplane);
+          const bool pk = plane_keeps(tc, b, isplane);
           if (isplane) keep = pk;
         }
         const unsigned long long m = __ballot(keep);
@@ -1300,10 +1306,12 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
       for (int p = 0; p < npass; ++p) {
         const int slot = p * 64 + lane;
         bool keep = false;
-        if (slot < a.n_shapes) keep = cone_keeps(tc, p == 0 ? b_first : a.bounds[slot]);  // 16 B per lane, coalesced
+        float4 b = {0.0f, 0.0f, 0.0f, -1.0f};
+        if (slot < a.n_shapes) b = p == 0 ? b_first : a.bounds[slot];  // 16 B per lane, coalesced
         const bool isplane = slot >= a.n_spheres && slot < a.n_shapes;
+        if (slot < a.n_spheres) keep = cone_keeps(tc, b);
         if (__any(isplane)) {
-          const bool pk = plane_keeps(a, tc, slot, isplane);
+          const bool pk = plane_keeps(tc, b, isplane);
           if (isplane) keep = pk;
         }
         const unsigned long long m = __ballot(keep);
@@ -1860,7 +1868,7 @@ PT_DEV void path_trace(const PtKArgs &a) {
         for (int p = 0; p < npass; ++p) {
           const int slot = p * 64 + lane;
           bool keep = false;
-          if (slot < a.n_shapes) keep = cone_keeps(tc, a.bounds[slot]);
+          if (slot < a.n_shapes) keep = slot >= a.n_spheres || cone_keeps(tc, a.bounds[slot]);  // planes: always
           const unsigned long long m = __ballot(keep);
           if (lane == 0) pt_lds_masks[mbase + p] = m;
         }

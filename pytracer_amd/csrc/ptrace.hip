@@ -386,6 +386,15 @@ extern "C" int pt_scene_upload(const pt_scene_desc *d, int device, pt_scene **ou
     const double cabs = std::max(std::fabs(b.cx), std::max(std::fabs(b.cy), std::fabs(b.cz)));
     const double rw = b.r * (1.0 + 1e-6) + 2e-7 * cabs;
     f.w = (b.r >= 0.0 && std::isfinite(rw) && rw < 1e37 && cabs < 1e37) ? (float)rw * (1.0f + 1e-6f) : -1.0f;
+    if (recs[slot].kind == PT_SHAPE_PLANE) {
+      // planes have no bounding sphere; their slot carries what plane_keeps() needs instead: the z row of
+      // invm (object-space d.z = row . d, o.z = row . o + invm[11]) rounded to fp32
+      const double *im = recs[slot].invm;
+      f.x = (float)im[8];
+      f.y = (float)im[9];
+      f.z = (float)im[10];
+      f.w = (float)im[11];
+    }
     bounds[slot] = f;
   }
   // ... and as structure-of-arrays for the per-ray prefilter of scattered rays (world_query_lanes): two
@@ -400,7 +409,7 @@ extern "C" int pt_scene_upload(const pt_scene_desc *d, int device, pt_scene **ou
       bsoa[slot] = f.x;
       bsoa[(size_t)s->bs_stride + slot] = f.y;
       bsoa[(size_t)2 * s->bs_stride + slot] = f.z;
-      if (f.w >= 0.0f) {
+      if (slot < s->n_spheres && f.w >= 0.0f) {
         const double cabs = std::max(std::fabs((double)f.x), std::max(std::fabs((double)f.y), std::fabs((double)f.z)));
         const double v = (double)f.w * (1.0 + 1e-5) + 1e-6 * cabs;
         rk = std::nextafter((float)v, INFINITY);
