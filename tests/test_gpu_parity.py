@@ -9,6 +9,7 @@ elsewhere (fp64 output, so the floor is libm-vs-ocml last-ulp differences, SURVE
 libm transcendental is involved the device must equal the oracle's ``x*x`` mode bit for bit.
 """
 import math
+import os
 
 import numpy as np
 import pytest
@@ -319,6 +320,85 @@ def test_pathtracer_many_spheres_vs_oracle(dev, oracle):
     err = util.rel_err(out, ora)
     assert err.max() <= TOL, f"max rel err {err.max():.3e}"
     assert abs(n_dev - n_rays) <= n_rays // 1000  # (a last-bit libm difference may flip a Russian-roulette draw)
+
+
+def _random_world(seed):
+    """Random spheres (scale+translate and rotated ellipsoids, some enclosing the camera), tilted planes,
+    mixed materials: a scene generator with no regard for what the culling code finds convenient."""
+    from pytracer_amd import hostmodel as hm
+
+    g = hm.PCG(1000 + seed, 17)
+    r = g.random_float
+    V = hm.Vec
+    w = hm.World()
+
+    def material(allow_pattern=True):
+        kind = r()
+        col = hm.Color(r(), r(), r())
+        pig = hm.UniformPigment(col)
+        if allow_pattern and kind < 0.2:
+            pig = hm.CheckeredPigment(col, hm.Color(r(), r(), r()), 1 + int(6 * r()))
+        brdf = hm.SpecularBRDF(pig) if r() < 0.2 else hm.DiffuseBRDF(pig)
+        emit = hm.UniformPigment(hm.Color(0.5 * r(), 0.5 * r(), 0.5 * r()) if r() < 0.3 else hm.BLACK)
+        return hm.Material(brdf, emit)
+
+    if r() < 0.7:  # a dome: centred near the camera or not, black or not
+        sc = 5.0 + 60.0 * r()
+        t = hm.translation(V(6.0 * (r() - 0.5), 6.0 * (r() - 0.5), 3.0 * (r() - 0.5)))
+        dome = t * hm.scaling(V(sc, sc * (0.6 + 0.8 * r()), sc))
+        black = r() < 0.5
+        w.add_shape(hm.Sphere(dome, hm.Material(hm.DiffuseBRDF(hm.UniformPigment(hm.BLACK if black else hm.Color(r(), r(), r()))),
+                                                hm.UniformPigment(hm.Color(0.3 + r(), 0.3 + r(), 0.3 + r())))))
+    n = 3 + int(r() * r() * 400)
+    spread = 1.0 + 8.0 * r()
+    for i in range(n):
+        rad = 0.02 + 0.5 * r() * r()
+        t = hm.translation(V(0.5 + 10.0 * r(), spread * (r() - 0.5), 1.0 + 0.5 * spread * (r() - 0.5)))
+        if r() < 0.3:
+            T = t * hm.rotation_z(360 * r()) * hm.rotation_y(360 * r()) * hm.scaling(V(rad, rad * (0.3 + 2 * r()), rad * (0.3 + 2 * r())))
+        else:
+            T = t * hm.scaling(V(rad, rad, rad))
+        w.add_shape(hm.Sphere(T, material(allow_pattern=False)))
+    for _ in range(int(3.5 * r())):
+        T = hm.translation(V(4.0 * r(), 4.0 * (r() - 0.5), 3.0 * (r() - 0.6))) * hm.rotation_x(180.0 * r() * (r() < 0.5)) * \
+            hm.rotation_y(60.0 * (r() - 0.5))
+        w.add_shape(hm.Plane(T, material()))
+    if r() < 0.5:
+        w.add_light(hm.PointLight(V(-2.0 + 4 * r(), 6.0 * (r() - 0.5), 4.0 + 4 * r()), hm.Color(1.0, 0.9, 0.8), 3.0 * r() * (r() < 0.5)))
+    cam_t = hm.translation(V(-1.0 - 2 * r(), r() - 0.5, 0.5 + r())) * hm.rotation_z(40.0 * (r() - 0.5)) * hm.rotation_y(30.0 * (r() - 0.5))
+    W, H = 40 + 8 * int(12 * r()), 24 + 8 * int(8 * r())
+    cam = hm.PerspectiveCamera(0.5 + 1.5 * r(), W / H, cam_t) if r() < 0.85 else hm.OrthogonalCamera(W / H, cam_t)
+    return w, cam, W, H
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("PT_FUZZ_SEEDS", "24"))))
+def test_random_scenes_match_oracle(dev, oracle, seed):
+    """Differential test over random scenes: OnOff / Flat / PointLight bit for bit (no libm on these
+    scenes' paths except specular PointLight), PathTracer within 1e-5; ray counts equal."""
+    from pytracer_amd import flatten
+
+    world, camera, W, H = _random_world(seed)
+    scene = flatten.flatten_world(world)
+    cam = flatten.flatten_camera(camera)
+    with dev.DeviceScene(scene) as ds:
+        for renderer, S in ((abi.RENDERER_ONOFF, 0), (abi.RENDERER_FLAT, 0), (abi.RENDERER_FLAT, 2), (abi.RENDERER_POINTLIGHT, 0)):
+            par = abi.make_params(W, H, renderer, samples_per_side=S, path_state=3 + seed, path_seq=21)
+            ora, n_rays = oracle.render(scene, cam, par, sqr_mode=oracle.SQR_MUL)
+            out = ds.render(cam, par)
+            if _uses_libm(scene, par):
+                assert np.all(util.rel_err(out, ora) <= TOL), f"seed {seed} renderer {renderer}"
+            else:
+                assert util.bits_equal(out, ora), f"seed {seed} renderer {renderer} S={S}: max rel {util.rel_err(out, ora).max()}"
+                assert ds.stats().n_rays == n_rays
+        par = abi.make_params(W, H, abi.RENDERER_PATHTRACER, samples_per_side=2, num_of_rays=1 + seed % 3, max_depth=1 + seed % 4,
+                              rr_limit=seed % 3, path_state=45 + seed, path_seq=54)
+        ora, n_rays = oracle.render(scene, cam, par, sqr_mode=oracle.SQR_MUL)
+        out = ds.render(cam, par)
+        err = util.rel_err(out, ora)
+        bad = int((err > TOL).any(axis=-1).sum())
+        # a last-bit difference in sin/cos can flip a Russian-roulette decision or a checker cell for one pixel
+        assert bad <= max(1, (W * H) // 2000), f"seed {seed}: {bad} pixels off, max rel {err.max():.3e}"
+    oracle.set_sqr_mode(oracle.SQR_POW)
 
 
 def test_furnace(dev):
