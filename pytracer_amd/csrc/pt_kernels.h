@@ -383,14 +383,18 @@ extern __shared__ double pt_lds_f64[];
 //    the origin, both roots are negative by a margin far above fp64 rounding.
 // NaN/inf on either side keep the sphere.  Order of visits differs from the list order only in WHEN a
 // candidate is seen; ties in t go to the lower World.shapes index as everywhere.
-PT_DEV int world_query_lanes(const PtKArgs &a, const Ray &r, double &best_t, bool active, int diag_lds) {
+// ANYHIT (shadow rays, world.py:71-80 / shapes.py:133-151): a lane stops at its first sphere with a root in
+// (tmin, tmax); with a finite tmax the prefilter also drops balls that lie entirely beyond the end
+// point ((v - tmax d).d > 0 and its square > 1.001 R'^2 |d|^2 + slack).
+template <bool ANYHIT>
+PT_DEV int world_query_lanes(const PtKArgs &a, const Ray &r, double tmax, double &best_t, bool active, int diag_lds) {
   typedef float f2 __attribute__((ext_vector_type(2)));
   typedef const __attribute__((address_space(4))) float *pt_kfloat;
   int best = -1;
   best_t = INFINITY;
-  const double tmin = r.tmin, tmax = INFINITY;
+  const double tmin = r.tmin;
   const int nd = a.n_diag, ns = a.n_spheres, n = a.n_shapes;
-  constexpr bool ANYHIT = false;  // (for PT_PLANE_HIT)
+  const float tmaxf_dd = (float)tmax;  // (multiplied by |d|^2 below)
 
   const float ofx = (float)r.o.x, ofy = (float)r.o.y, ofz = (float)r.o.z;
   const float dfx = (float)r.d.x, dfy = (float)r.d.y, dfz = (float)r.d.z;
@@ -431,14 +435,20 @@ PT_DEV int world_query_lanes(const PtKArgs &a, const Ray &r, double &best_t, boo
         const f2 rdd = (rk * rk) * dd;
         const f2 slack = vv * dd8;
         const f2 rhs = rdd + slack, rhs_b = rdd * 1.001f + slack;
-        const bool rej0 = (q.x > rhs.x) || (vd.x < 0.0f && t.x > rhs_b.x);
-        const bool rej1 = (q.y > rhs.y) || (vd.y < 0.0f && t.y > rhs_b.y);
+        bool rej0 = (q.x > rhs.x) || (vd.x < 0.0f && t.x > rhs_b.x);
+        bool rej1 = (q.y > rhs.y) || (vd.y < 0.0f && t.y > rhs_b.y);
+        if (ANYHIT) {  // entirely beyond the end of the segment (tmax = inf: wd = -inf or NaN, no reject)
+          const f2 wd = vd - tmaxf_dd * dd;
+          const f2 wd2 = wd * wd;
+          rej0 = rej0 || (wd.x > 0.0f && wd2.x > rhs_b.x);
+          rej1 = rej1 || (wd.y > 0.0f && wd2.y > rhs_b.y);
+        }
         m8 |= (rej0 ? 0u : 1u << k) | (rej1 ? 0u : 2u << k);
       }
       mask |= (unsigned long long)m8 << j;
     }
     if (cnt < 64) mask &= (1ULL << cnt) - 1ULL;
-    if (!active) mask = 0ULL;
+    if (!active || (ANYHIT && best >= 0)) mask = 0ULL;
 #ifdef PT_DEBUG_TIME
     {
       const unsigned long long tn = __builtin_amdgcn_s_memtime();
@@ -516,7 +526,7 @@ PT_DEV int world_query_lanes(const PtKArgs &a, const Ray &r, double &best_t, boo
         const bool ok = ok1 || PT_LAT_INRANGE(t2);
         if (need && ok) {
           bool take = t < best_t;
-          if (!take && t == best_t && best >= 0) take = a.recs[slot].index < a.recs[best].index;
+          if (!ANYHIT && !take && t == best_t && best >= 0) take = a.recs[slot].index < a.recs[best].index;
           if (take) {
             best_t = t;
             best = slot;
@@ -526,6 +536,10 @@ PT_DEV int world_query_lanes(const PtKArgs &a, const Ray &r, double &best_t, boo
       g = g_next;
       slot = slot_next;
       has = has_next;
+      if (ANYHIT && best >= 0) {  // this lane is blocked: nothing more to look at
+        has = false;
+        mask = 0ULL;
+      }
 #ifdef PT_DEBUG_TIME
       dbg_it++;
 #endif
@@ -828,7 +842,7 @@ PT_DEV V3 pointlight_shade(const PtKArgs &a, const Ray &ray, int hit, double bes
     const double dn = sqrt(sh.d.x * sh.d.x + sh.d.y * sh.d.y + sh.d.z * sh.d.z);
     sh.tmin = 1e-2 / dn;
     double tlim;
-    const int blocked = world_query<true, false>(a, sh, 1.0, tlim, lit);
+    const int blocked = world_query_lanes<true>(a, sh, 1.0, tlim, lit, -1);
     if (lit) nrays++;
     if (lit && blocked < 0) {
       const V3 dv = {h.wp.x - lp.x, h.wp.y - lp.y, h.wp.z - lp.z};
@@ -1925,7 +1939,7 @@ PT_DEV void path_trace(const PtKArgs &a) {
     }
     if (do_s) {
       double ts;
-      const int hs = LAT ? world_query_lanes(a, ray, ts, scat, diag_lds) : world_query<false, false>(a, ray, INFINITY, ts, scat);
+      const int hs = LAT ? world_query_lanes<false>(a, ray, INFINITY, ts, scat, diag_lds) : world_query<false, false>(a, ray, INFINITY, ts, scat);
       if (scat) {
         hit = hs;
         best_t = ts;
