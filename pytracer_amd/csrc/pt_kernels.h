@@ -414,41 +414,67 @@ PT_DEV int world_query_lanes(const PtKArgs &a, const Ray &r, double tmax, double
 #ifdef PT_DEBUG_TIME
   unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime(), dbg_pre = 0, dbg_walk = 0, dbg_it = 0;
 #endif
+  typedef float f8 __attribute__((ext_vector_type(8)));
+  typedef const __attribute__((address_space(4))) f8 *pt_kf8;
+  // may this lane's ray touch the balls (cx, cy, cz | radius cr), two at a time?
+  auto reject2 = [&](f2 cx, f2 cy, f2 cz, f2 cr, bool &rej0, bool &rej1) {
+    const f2 vx = cx - ofx, vy = cy - ofy, vz = cz - ofz;
+    const f2 vd = vx * dfx + vy * dfy + vz * dfz;
+    const f2 vv = vx * vx + vy * vy + vz * vz;
+    const f2 t = vd * vd;
+    const f2 q = vv * dd - t;  // |v x d|^2 = dist^2 |d|^2
+    const f2 rk = cr + eo;
+    const f2 rdd = (rk * rk) * dd;
+    const f2 slack = vv * dd8;
+    const f2 rhs = rdd + slack, rhs_b = rdd * 1.001f + slack;
+    rej0 = (q.x > rhs.x) || (vd.x < 0.0f && t.x > rhs_b.x);
+    rej1 = (q.y > rhs.y) || (vd.y < 0.0f && t.y > rhs_b.y);
+    if (ANYHIT) {  // entirely beyond the end of the segment (tmax = inf: wd = -inf or NaN, no reject)
+      const f2 wd = vd - tmaxf_dd * dd;
+      const f2 wd2 = wd * wd;
+      rej0 = rej0 || (wd.x > 0.0f && wd2.x > rhs_b.x);
+      rej1 = rej1 || (wd.y > 0.0f && wd2.y > rhs_b.y);
+    }
+  };
+  // Scenes of >= 128 spheres: the slots are in Morton order (pt_scene_upload), every 8 consecutive
+  // spheres have a ball around their bounding spheres and so have every 64; a chunk or a group that no
+  // lane's ray can touch is skipped whole.
+  const int levels = a.bs_levels;
+  pt_kfloat gsx = bsr + a.bs_stride, gsy = gsx + a.gs_stride, gsz = gsy + a.gs_stride, gsr = gsz + a.gs_stride;
+  pt_kfloat csx = gsr + a.gs_stride, csy = csx + a.cs_stride, csz = csy + a.cs_stride, csr = csz + a.cs_stride;
   for (int base = 0; base < ns; base += 64) {
     const int cnt = ns - base < 64 ? ns - base : 64;
     unsigned long long mask = 0ULL;
+    unsigned gtouch = 0xffu;  // groups of the chunk some lane may touch (wave-uniform)
+    const bool live = active && !(ANYHIT && best >= 0);
+    if (levels) {
+      const int c = base >> 6;
+      bool r0, r1;
+      reject2((f2){csx[c], csx[c]}, (f2){csy[c], csy[c]}, (f2){csz[c], csz[c]}, (f2){csr[c], csr[c]}, r0, r1);
+      if (__ballot(live && !r0) == 0ULL) continue;
+      const f8 X = *(pt_kf8)(gsx + c * 8), Y = *(pt_kf8)(gsy + c * 8), Z = *(pt_kf8)(gsz + c * 8), R = *(pt_kf8)(gsr + c * 8);
+      gtouch = 0u;
+#pragma unroll
+      for (int k = 0; k < 8; k += 2) {
+        reject2((f2){X[k], X[k + 1]}, (f2){Y[k], Y[k + 1]}, (f2){Z[k], Z[k + 1]}, (f2){R[k], R[k + 1]}, r0, r1);
+        gtouch |= (__ballot(live && !r0) != 0ULL ? 1u << k : 0u) | (__ballot(live && !r1) != 0ULL ? 2u << k : 0u);
+      }
+    }
     for (int j = 0; j < cnt; j += 8) {  // eight spheres per round of scalar loads (the arrays are padded)
-      typedef float f8 __attribute__((ext_vector_type(8)));
-      typedef const __attribute__((address_space(4))) f8 *pt_kf8;
+      if (!((gtouch >> (j >> 3)) & 1u)) continue;
       const f8 X = *(pt_kf8)(bsx + base + j), Y = *(pt_kf8)(bsy + base + j), Z = *(pt_kf8)(bsz + base + j),
                R = *(pt_kf8)(bsr + base + j);
       unsigned m8 = 0u;
 #pragma unroll
       for (int k = 0; k < 8; k += 2) {
-        const f2 cx = {X[k], X[k + 1]}, cy = {Y[k], Y[k + 1]}, cz = {Z[k], Z[k + 1]}, cr = {R[k], R[k + 1]};
-        const f2 vx = cx - ofx, vy = cy - ofy, vz = cz - ofz;
-        const f2 vd = vx * dfx + vy * dfy + vz * dfz;
-        const f2 vv = vx * vx + vy * vy + vz * vz;
-        const f2 t = vd * vd;
-        const f2 q = vv * dd - t;  // |v x d|^2 = dist^2 |d|^2
-        const f2 rk = cr + eo;
-        const f2 rdd = (rk * rk) * dd;
-        const f2 slack = vv * dd8;
-        const f2 rhs = rdd + slack, rhs_b = rdd * 1.001f + slack;
-        bool rej0 = (q.x > rhs.x) || (vd.x < 0.0f && t.x > rhs_b.x);
-        bool rej1 = (q.y > rhs.y) || (vd.y < 0.0f && t.y > rhs_b.y);
-        if (ANYHIT) {  // entirely beyond the end of the segment (tmax = inf: wd = -inf or NaN, no reject)
-          const f2 wd = vd - tmaxf_dd * dd;
-          const f2 wd2 = wd * wd;
-          rej0 = rej0 || (wd.x > 0.0f && wd2.x > rhs_b.x);
-          rej1 = rej1 || (wd.y > 0.0f && wd2.y > rhs_b.y);
-        }
+        bool rej0, rej1;
+        reject2((f2){X[k], X[k + 1]}, (f2){Y[k], Y[k + 1]}, (f2){Z[k], Z[k + 1]}, (f2){R[k], R[k + 1]}, rej0, rej1);
         m8 |= (rej0 ? 0u : 1u << k) | (rej1 ? 0u : 2u << k);
       }
       mask |= (unsigned long long)m8 << j;
     }
     if (cnt < 64) mask &= (1ULL << cnt) - 1ULL;
-    if (!active || (ANYHIT && best >= 0)) mask = 0ULL;
+    if (!live) mask = 0ULL;
 #ifdef PT_DEBUG_TIME
     {
       const unsigned long long tn = __builtin_amdgcn_s_memtime();
@@ -876,7 +902,8 @@ PT_DEV V3 pointlight_shade(const PtKArgs &a, const Ray &ray, int hit, double bes
 }
 
 template <int RENDERER, bool HOIST>
-__global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAVES_SIMPLE, 8))) void pt_simple_kernel(const PtKArgs a) {
+__global__ __launch_bounds__(PT_BLOCK)
+    __attribute__((amdgpu_waves_per_eu(RENDERER == PT_RENDERER_POINTLIGHT ? 3 : PT_WAVES_SIMPLE, 8))) void pt_simple_kernel(const PtKArgs a) {
   const int S = cold_args(a)->S;
   const int nsamp = S > 0 ? S * S : 1;
   unsigned long long nrays = 0;

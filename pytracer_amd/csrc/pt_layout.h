@@ -86,8 +86,10 @@ struct PtKArgs {
   const PtDiagRec *diag;            // [n_diag], parallel to recs[0..n_diag)
   const PtHoistDiag *hoist_diag;    // [n_diag]
   const float4 *bounds;             // [n_shapes], slot order: (cx, cy, cz, r)
-  const float *bsoa;                // the same as four arrays x[], y[], z[], r'[] of bs_stride floats (per-ray prefilter)
-  int bs_stride;
+  const float *bsoa;                // the same as four arrays x[], y[], z[], r'[] of bs_stride floats (per-ray prefilter),
+                                    // then the balls around every 8 (gs_stride) and every 64 (cs_stride) sphere slots
+  int bs_stride, gs_stride, cs_stride;
+  int bs_levels;                    // 1: the group/chunk balls are meaningful (>= 128 spheres, slots in Morton order)
   int diag_lds;                     // second path-tracer pass: where its copy of diag[] starts in LDS (8-byte words), -1 = not staged
   const PtLight *lights;
   const PtTex *tex;

@@ -48,8 +48,8 @@ struct pt_scene {
   PtDiagRec *diag = nullptr;
   PtHoistDiag *hoist_diag = nullptr;
   float4 *bounds = nullptr;
-  float *bsoa = nullptr;  // bounds as x[], y[], z[], r'[] (bs_stride floats each)
-  int bs_stride = 0;
+  float *bsoa = nullptr;  // bounds as x[], y[], z[], r'[] (bs_stride floats each), then group and chunk balls
+  int bs_stride = 0, gs_stride = 0, cs_stride = 0, bs_levels = 0;
   int n_diag = 0;
   PtLight *lights = nullptr;
   PtTex *tex = nullptr;
@@ -245,6 +245,62 @@ extern "C" int pt_scene_upload(const pt_scene_desc *d, int device, pt_scene **ou
   s->n_spheres = (int)order.size();
   for (int i = 0; i < n; ++i)
     if (d->kind[i] != PT_SHAPE_SPHERE) order.push_back(i);
+  // Large scenes: within each sphere group the slots follow a Morton curve through the centres (the few
+  // spheres much larger than the rest first), so that 8 and 64 consecutive slots are close in space and
+  // a ball around them is tight (per-ray prefilter of scattered and shadow rays, world_query_lanes).
+  // Any slot order gives the same image: ties in t go to the lower World.shapes index (r.index).
+  s->bs_levels = s->n_spheres >= 128 ? 1 : 0;
+  if (s->bs_levels) {
+    auto centre = [&](int i, int k) { return d->m[(size_t)(3 + 4 * k) * n + i]; };
+    auto radius2 = [&](int i) {  // squared Frobenius norm of M's 3x3 block: a size, not a bound
+      double v = 0.0;
+      for (int r_ = 0; r_ < 3; ++r_)
+        for (int c_ = 0; c_ < 3; ++c_) v += d->m[(size_t)(r_ * 4 + c_) * n + i] * d->m[(size_t)(r_ * 4 + c_) * n + i];
+      return v;
+    };
+    std::vector<double> sizes;
+    for (int k = 0; k < s->n_spheres; ++k) sizes.push_back(radius2(order[k]));
+    std::vector<double> sorted_sizes = sizes;
+    std::nth_element(sorted_sizes.begin(), sorted_sizes.begin() + sorted_sizes.size() / 2, sorted_sizes.end());
+    const double big = 64.0 * sorted_sizes[sorted_sizes.size() / 2];  // 8x the median radius
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int k = 0; k < s->n_spheres; ++k) {
+      if (!(sizes[k] <= big)) continue;
+      for (int c_ = 0; c_ < 3; ++c_) {
+        const double v = centre(order[k], c_);
+        if (std::isfinite(v)) {
+          lo[c_] = std::min(lo[c_], v);
+          hi[c_] = std::max(hi[c_], v);
+        }
+      }
+    }
+    auto morton = [&](int i) {
+      uint64_t code = 0;
+      uint32_t q[3];
+      for (int c_ = 0; c_ < 3; ++c_) {
+        const double v = centre(i, c_), span = hi[c_] - lo[c_];
+        double u = (span > 0.0 && std::isfinite(v)) ? (v - lo[c_]) / span : 0.0;
+        u = std::min(1.0, std::max(0.0, u));
+        q[c_] = (uint32_t)(u * 2097151.0);  // 21 bits
+      }
+      for (int b = 20; b >= 0; --b)
+        for (int c_ = 0; c_ < 3; ++c_) code = (code << 1) | ((q[c_] >> b) & 1u);
+      return code;
+    };
+    auto sort_range = [&](int a0, int a1) {
+      std::vector<std::pair<std::pair<int, uint64_t>, int>> keyed;  // ((small?, code), shape)
+      for (int k = a0; k < a1; ++k) {
+        const bool small_ = sizes[k] <= big;
+        // large spheres first, largest leading; then the Morton order of the rest
+        const uint64_t code = small_ ? morton(order[k]) : (uint64_t)(k - a0);
+        keyed.push_back({{small_ ? 1 : 0, code}, order[k]});
+      }
+      std::stable_sort(keyed.begin(), keyed.end(), [](const auto &x, const auto &y) { return x.first < y.first; });
+      for (int k = a0; k < a1; ++k) order[k] = keyed[k - a0].second;
+    };
+    sort_range(0, s->n_diag);
+    sort_range(s->n_diag, s->n_spheres);
+  }
   std::vector<PtShapeRec> recs(n);
   std::vector<PtShapeAux> aux(n);
   for (int slot = 0; slot < n; ++slot) {
@@ -401,7 +457,10 @@ extern "C" int pt_scene_upload(const pt_scene_desc *d, int device, pt_scene **ou
   // neighbouring spheres per packed fp32 instruction.  r' = r*(1 + 1e-5) + 1e-6*max|c| rounded up;
   // +inf where there is no bound (the test then always keeps the shape).
   s->bs_stride = (n + 8 + 7) / 8 * 8;  // 8 floats of slack: the prefilter reads eight at a time, 32-byte aligned
-  std::vector<float> bsoa((size_t)4 * s->bs_stride, 0.0f);
+  const int n_groups = (s->n_spheres + 7) / 8, n_chunks = (s->n_spheres + 63) / 64;
+  s->gs_stride = (n_chunks * 8 + 8 + 7) / 8 * 8;  // eight groups per chunk, read eight at a time
+  s->cs_stride = (n_chunks + 8 + 7) / 8 * 8;
+  std::vector<float> bsoa((size_t)4 * (s->bs_stride + s->gs_stride + s->cs_stride), 0.0f);
   for (int slot = 0; slot < s->bs_stride; ++slot) {
     float rk = INFINITY;
     if (slot < n) {
@@ -416,6 +475,54 @@ extern "C" int pt_scene_upload(const pt_scene_desc *d, int device, pt_scene **ou
       }
     }
     bsoa[(size_t)3 * s->bs_stride + slot] = rk;
+  }
+  // a ball around the (already inflated) balls of slots [a0, a1): centre = middle of the centres' box,
+  // radius = max_i(|c_i - centre| + r'_i), rounded up; +inf as soon as one member has no bound
+  auto ball_around = [&](int a0, int a1, float *out4) {
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    bool bounded = a1 > a0;
+    for (int k = a0; k < a1; ++k) {
+      bounded = bounded && std::isfinite(bsoa[(size_t)3 * s->bs_stride + k]);
+      for (int c_ = 0; c_ < 3; ++c_) {
+        const double v = bsoa[(size_t)c_ * s->bs_stride + k];
+        lo[c_] = std::min(lo[c_], v);
+        hi[c_] = std::max(hi[c_], v);
+      }
+    }
+    out4[0] = out4[1] = out4[2] = 0.0f;
+    out4[3] = INFINITY;
+    if (!bounded) return;
+    float c[3];
+    for (int c_ = 0; c_ < 3; ++c_) c[c_] = (float)(0.5 * (lo[c_] + hi[c_]));
+    double rad = 0.0;
+    for (int k = a0; k < a1; ++k) {
+      double d2 = 0.0;
+      for (int c_ = 0; c_ < 3; ++c_) {
+        const double dv = (double)bsoa[(size_t)c_ * s->bs_stride + k] - (double)c[c_];
+        d2 += dv * dv;
+      }
+      rad = std::max(rad, std::sqrt(d2) * (1.0 + 1e-12) + (double)bsoa[(size_t)3 * s->bs_stride + k]);
+    }
+    const double cabs = std::max(std::fabs((double)c[0]), std::max(std::fabs((double)c[1]), std::fabs((double)c[2])));
+    const double v = rad * (1.0 + 1e-5) + 1e-6 * cabs;
+    if (!std::isfinite(v) || v > 1e37) return;
+    out4[0] = c[0];
+    out4[1] = c[1];
+    out4[2] = c[2];
+    out4[3] = std::nextafter((float)v, INFINITY);
+  };
+  {
+    float *gs = bsoa.data() + (size_t)4 * s->bs_stride, *cs = gs + (size_t)4 * s->gs_stride;
+    for (int k = 0; k < s->gs_stride; ++k) {
+      float b4[4] = {0.0f, 0.0f, 0.0f, INFINITY};
+      if (k < n_groups) ball_around(k * 8, std::min(k * 8 + 8, s->n_spheres), b4);
+      for (int c_ = 0; c_ < 4; ++c_) gs[(size_t)c_ * s->gs_stride + k] = b4[c_];
+    }
+    for (int k = 0; k < s->cs_stride; ++k) {
+      float b4[4] = {0.0f, 0.0f, 0.0f, INFINITY};
+      if (k < n_chunks) ball_around(k * 64, std::min(k * 64 + 64, s->n_spheres), b4);
+      for (int c_ = 0; c_ < 4; ++c_) cs[(size_t)c_ * s->cs_stride + k] = b4[c_];
+    }
   }
   UP(upload(&s->recs, recs));
   UP(upload(&s->bounds, bounds));
@@ -511,6 +618,9 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
   a.bounds = s->bounds;
   a.bsoa = s->bsoa;
   a.bs_stride = s->bs_stride;
+  a.gs_stride = s->gs_stride;
+  a.cs_stride = s->cs_stride;
+  a.bs_levels = s->bs_levels;
   a.n_diag = s->n_diag;
   a.lights = s->lights;
   a.tex = s->tex;
@@ -763,7 +873,7 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
       else if (p->renderer == PT_RENDERER_FLAT)
         hipLaunchKernelGGL((pt_tile_kernel<PT_RENDERER_FLAT, 4, true>), dim3(tgrid), dim3(PT_BLOCK), lds, st, a, 0);
       else if (p->renderer == PT_RENDERER_POINTLIGHT)
-        hipLaunchKernelGGL((pt_tile_kernel<PT_RENDERER_POINTLIGHT, 4, true>), dim3(tgrid), dim3(PT_BLOCK), lds, st, a, 0);
+        hipLaunchKernelGGL((pt_tile_kernel<PT_RENDERER_POINTLIGHT, 3, true>), dim3(tgrid), dim3(PT_BLOCK), lds, st, a, 0);
       else
         hipLaunchKernelGGL((pt_tile_kernel<PT_RENDERER_PATHTRACER, 4, true>), dim3(tgrid), dim3(PT_BLOCK), lds, st, a, grid);
     } else if (p->renderer == PT_RENDERER_ONOFF)
@@ -771,7 +881,7 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
     else if (p->renderer == PT_RENDERER_FLAT)
       hipLaunchKernelGGL((pt_tile_kernel<PT_RENDERER_FLAT, 4, false>), dim3(tgrid), dim3(PT_BLOCK), lds, st, a, 0);
     else if (p->renderer == PT_RENDERER_POINTLIGHT)
-      hipLaunchKernelGGL((pt_tile_kernel<PT_RENDERER_POINTLIGHT, 4, false>), dim3(tgrid), dim3(PT_BLOCK), lds, st, a, 0);
+      hipLaunchKernelGGL((pt_tile_kernel<PT_RENDERER_POINTLIGHT, 3, false>), dim3(tgrid), dim3(PT_BLOCK), lds, st, a, 0);
     else
       hipLaunchKernelGGL((pt_tile_kernel<PT_RENDERER_PATHTRACER, 4, false>), dim3(tgrid), dim3(PT_BLOCK), lds, st, a, grid);
     if (path_tiled) {
