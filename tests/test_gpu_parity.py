@@ -498,6 +498,58 @@ def test_errors(dev):
             ds.render(cam, abi.make_params(16, 9, 7))
 
 
+def test_degenerate_sizes_and_parameters(dev, oracle):
+    """Edges of the parameter space: an empty world, one-pixel and one-row frames, many samples, depth 0 and 1,
+    Russian roulette from depth 0, more ranks than row blocks -- all against the oracle."""
+    from pytracer_amd import flatten, hostmodel as hm, scenes
+
+    cases = []
+    empty = flatten.flatten_world(hm.World())
+    cam_for = lambda w, h: flatten.flatten_camera(scenes.synthetic_camera(w, h))  # noqa: E731
+    for renderer in (abi.RENDERER_ONOFF, abi.RENDERER_FLAT, abi.RENDERER_PATHTRACER, abi.RENDERER_POINTLIGHT):
+        cases.append((empty, 24, 10, dict(renderer=renderer, samples_per_side=2)))
+    c2 = flatten.flatten_world(scenes.synthetic_world(32, with_plane=True))
+    for W, H in ((1, 1), (1, 37), (53, 1), (9, 8), (7, 9)):
+        cases.append((c2, W, H, dict(renderer=abi.RENDERER_FLAT)))
+        cases.append((c2, W, H, dict(renderer=abi.RENDERER_ONOFF, samples_per_side=3)))
+    cases.append((c2, 40, 24, dict(renderer=abi.RENDERER_FLAT, samples_per_side=8)))
+    two = flatten.flatten_world(scenes.synthetic_world(3))  # < 4 shapes: the one-lane-per-pixel kernel
+    cases.append((two, 33, 17, dict(renderer=abi.RENDERER_FLAT, samples_per_side=2)))
+    for scene, W, H, kw in cases:
+        cam = cam_for(W, H)
+        par = abi.make_params(W, H, background=(0.25, 0.5, 0.125), **kw)
+        ora, n_rays = oracle.render(scene, cam, par, sqr_mode=oracle.SQR_MUL)
+        with dev.DeviceScene(scene) as ds:
+            out = ds.render(cam, par)
+            assert util.bits_equal(out, ora), f"{W}x{H} {kw}"
+            assert ds.stats().n_rays == n_rays
+    # path tracer corners (tolerance: sin/cos)
+    c3 = flatten.flatten_world(scenes.synthetic_world(32))
+    cam = cam_for(48, 27)
+    with dev.DeviceScene(c3) as ds:
+        for kw in (dict(max_depth=0), dict(max_depth=1, num_of_rays=3), dict(max_depth=2, rr_limit=0, num_of_rays=2),
+                   dict(max_depth=6, rr_limit=1, num_of_rays=1, samples_per_side=3), dict(max_depth=-1)):
+            base = dict(renderer=abi.RENDERER_PATHTRACER, samples_per_side=2, num_of_rays=1, max_depth=3, rr_limit=3,
+                        path_state=45, path_seq=54)
+            base.update(kw)
+            par = abi.make_params(48, 27, **base)
+            ora, _ = oracle.render(c3, cam, par, sqr_mode=oracle.SQR_MUL)
+            out = ds.render(cam, par)
+            assert np.all(util.rel_err(out, ora) <= TOL), f"path tracer {kw}: {util.rel_err(out, ora).max():.3e}"
+        # more ranks than 8-row blocks: some ranks own nothing
+        par = abi.make_params(48, 27, abi.RENDERER_FLAT)
+        full = ds.render(cam, par)
+        got = np.zeros_like(full)
+        for rank in range(6):
+            rows = abi.rows_for_rank(27, 8, 6, rank)
+            part = ds.render(cam, abi.copy_params(par, n_ranks=6, rank=rank, row_block=8))
+            assert part.shape[0] == len(rows)
+            if rows:
+                got[rows] = part
+        assert util.bits_equal(got, full)
+    oracle.set_sqr_mode(oracle.SQR_POW)
+
+
 # ---- the Python drop-in surface ----------------------------------------------------------------------------------------
 def test_gpu_image_tracer_dropin(dev, oracle):
     from pytracer_amd import flatten, hostmodel as hm, scenes

@@ -44,6 +44,8 @@ CONFIGS = {
     "c4crop": (256, False, True, 960, 540, dict(renderer=abi.RENDERER_PATHTRACER, samples_per_side=4, num_of_rays=1,
                                                 max_depth=5, rr_limit=3, path_state=45, path_seq=54)),
     "c5": (10000, False, True, 1280, 720, dict(renderer=abi.RENDERER_FLAT)),
+    "c5pt": (10000, False, True, 1280, 720, dict(renderer=abi.RENDERER_PATHTRACER, samples_per_side=2, num_of_rays=1,
+                                                 max_depth=3, rr_limit=3, path_state=45, path_seq=54)),
     "pl": (32, True, False, 1280, 720, dict(renderer=abi.RENDERER_POINTLIGHT, lights=2)),
     "pl5": (10000, False, True, 1280, 720, dict(renderer=abi.RENDERER_POINTLIGHT, lights=1)),
     "c5small": (10000, False, True, 320, 180, dict(renderer=abi.RENDERER_FLAT)),
