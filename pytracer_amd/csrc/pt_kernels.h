@@ -1559,9 +1559,10 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
 // sort last and are never visited (order[n] = number of regions with work).  The order only changes
 // WHEN a region is rendered, never its pixels.
 // one workgroup: histogram (256 bins) -> descending offsets -> scatter
-__global__ void pt_region_sort(const unsigned char *keys, int n, int *order) {
+__global__ void pt_region_sort(const unsigned char *keys, int n, int *order, unsigned long long *queue) {
   __shared__ int hist[256];
   __shared__ int offs[256];
+  if (threadIdx.x == 0) queue[0] = 0ULL;  // the second pass's region queue starts empty
   for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
   __syncthreads();
   // (regions with key 0 -- usually most of the frame -- are never visited and get no place at all)

@@ -769,7 +769,8 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
     return PT_OK;
   }
   if (p->renderer == PT_RENDERER_PATHTRACER) {
-    HIP_TRY(hipMemsetAsync(s->queue, 0, 16 * sizeof(unsigned long long), st));
+    // the queue head: zeroed by pt_region_sort between the two passes; by a memset for the one-queue kernel
+    if (!path_tiled) HIP_TRY(hipMemsetAsync(s->queue, 0, 16 * sizeof(unsigned long long), st));
     // step batching (path_trace): the second pass by regions never mixes the two kinds of step (a P step
     // waits until no lane holds a ray: its lanes then move sample by sample); the one-queue kernel, which
     // also carries the cheap background pixels, starts samples while fewer than 48 lanes hold a ray and
@@ -886,7 +887,7 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
       hipLaunchKernelGGL((pt_tile_kernel<PT_RENDERER_PATHTRACER, 4, false>), dim3(tgrid), dim3(PT_BLOCK), lds, st, a, grid);
     if (path_tiled) {
       // second pass: the pixels the first one flagged, fullest regions first
-      hipLaunchKernelGGL(pt_region_sort, dim3(1), dim3(1024), 0, st, s->region_keys, nregions, s->region_order);
+      hipLaunchKernelGGL(pt_region_sort, dim3(1), dim3(1024), 0, st, s->region_keys, nregions, s->region_order, s->queue);
       if (lds_frames) {
         HIP_TRY(path_lds_limit((const void *)pt_path_regions_kernel<true>, lds + frame_lds + diag_lds_bytes));
         hipLaunchKernelGGL((pt_path_regions_kernel<true>), dim3(grid), dim3(PT_BLOCK), lds + frame_lds + diag_lds_bytes, st, a);
