@@ -1005,6 +1005,9 @@ struct TileCone {
   float kx, ky, kz;  // THIS lane's corner direction (corner lane & 3), un-normalised
   float dmax2;       // upper bound of |d|^2 over the tile (|d|^2 is convex: max at a corner)
   float dmin;        // lower bound of |d| over the tile (axis . d is affine: min at a corner)
+  float rbeam;       // orthogonal camera: the tile's rays fill a beam of this radius around the axis line
+  bool ortho;        // ... then (ox, oy, oz) is a point of that line, cos_t = 1, sin_t = 0, and
+                     // (kx, ky, kz) is this lane's corner ORIGIN
 };
 
 // Rows of the tile are [grow0, grow1] (global image rows, inclusive), columns [x0, x1): the tile's
@@ -1012,8 +1015,11 @@ struct TileCone {
 // image plane; primary directions are affine in image position, so the convex cone spanned by the
 // four corner rays contains every ray of the tile.
 // the host folded camera.py:116-124 and imagetracer.py:56-58 into d(x, y) = d0 + x*dx + y*dy (fp32)
+// Orthogonal camera (camera.py:59-78): the roles swap -- the ORIGIN is affine in the image position,
+// o(x, y) = d0 + x*dx + y*dy, and `apex` holds the common direction.
 struct ConeCam {
   float d0[3], dx[3], dy[3], apex[3];
+  bool ortho;
 };
 
 PT_DEV ConeCam cone_cam(const PtKArgs &a) {
@@ -1025,6 +1031,7 @@ PT_DEV ConeCam cone_cam(const PtKArgs &a) {
     k.dy[i] = c->cone_dy[i];
     k.apex[i] = c->cone_apex[i];
   }
+  k.ortho = c->cam_kind != PT_CAMERA_PERSPECTIVE;
   return k;
 }
 
@@ -1034,6 +1041,43 @@ PT_DEV TileCone tile_cone(const ConeCam &k, int x0, int x1, int grow0, int grow1
   const float d0x = k.d0[0], d0y = k.d0[1], d0z = k.d0[2];
   const float dxx = k.dx[0], dxy = k.dx[1], dxz = k.dx[2];
   const float dyx = k.dy[0], dyy = k.dy[1], dyz = k.dy[2];
+  tc.ortho = k.ortho;
+  tc.rbeam = 0.0f;
+  if (k.ortho) {
+    // Parallel rays: every ray of the tile starts inside the parallelogram spanned by the four corner
+    // origins and runs along the common direction, i.e. inside the cylinder around the line through
+    // the parallelogram's centre whose radius is the largest corner distance from that line (the
+    // distance is convex in the image position).  cone_keeps() treats it as a cone with t = 0 whose
+    // spheres are widened by rbeam.  Spheres behind the image plane are simply kept.
+    const float fx0 = (float)x0, fx1 = (float)x1, fy0 = (float)grow0, fy1 = (float)(grow1 + 1);
+    const float xm = 0.5f * (fx0 + fx1), ym = 0.5f * (fy0 + fy1);
+    tc.ox = d0x + xm * dxx + ym * dyx;
+    tc.oy = d0y + xm * dxy + ym * dyy;
+    tc.oz = d0z + xm * dxz + ym * dyz;
+    const float xk = (lane & 1) ? fx1 : fx0, yk = (lane & 2) ? fy1 : fy0;
+    tc.kx = d0x + xk * dxx + yk * dyx;
+    tc.ky = d0y + xk * dxy + yk * dyy;
+    tc.kz = d0z + xk * dxz + yk * dyz;
+    const float rd = __frsqrt_rn(k.apex[0] * k.apex[0] + k.apex[1] * k.apex[1] + k.apex[2] * k.apex[2]);
+    tc.ax = k.apex[0] * rd;
+    tc.ay = k.apex[1] * rd;
+    tc.az = k.apex[2] * rd;
+    const float ex = tc.kx - tc.ox, ey = tc.ky - tc.oy, ez = tc.kz - tc.oz;
+    const float ep = ex * tc.ax + ey * tc.ay + ez * tc.az;
+    const float px = ex - ep * tc.ax, py = ey - ep * tc.ay, pz = ez - ep * tc.az;
+    float rb = __fsqrt_rn(px * px + py * py + pz * pz);
+    rb = fmaxf(rb, __shfl_xor(rb, 1, 64));
+    rb = fmaxf(rb, __shfl_xor(rb, 2, 64));
+    const float kabs = fmaxf(fmaxf(fabsf(tc.kx), fabsf(tc.ky)), fabsf(tc.kz));
+    tc.oabs = fmaxf(fmaxf(fmaxf(fabsf(tc.ox), fabsf(tc.oy)), fabsf(tc.oz)), kabs);
+    tc.rbeam = rb * (1.0f + 1e-4f) + 4e-6f * tc.oabs;  // fp32 model of the origins: ~3e-7 relative each
+    tc.cos_t = 1.0f;
+    tc.sin_t = 0.0f;
+    tc.dmax2 = 0.0f;
+    tc.dmin = 0.0f;  // (no dome shortcut for parallel rays)
+    tc.all = !(rd > 0.0f) || !(tc.rbeam >= 0.0f);  // degenerate direction or NaN: keep everything
+    return tc;
+  }
   tc.ox = k.apex[0];
   tc.oy = k.apex[1];
   tc.oz = k.apex[2];
@@ -1089,7 +1133,7 @@ PT_DEV bool cone_keeps(const TileCone &tc, float4 b) {
   const float wx = vx - d * tc.ax, wy = vy - d * tc.ay, wz = vz - d * tc.az;
   const float perp = __builtin_amdgcn_sqrtf(wx * wx + wy * wy + wz * wz);  // v_sqrt_f32, 1 ulp
   const float q = perp * tc.cos_t - d * tc.sin_t;
-  const float R = b.w * (1.0f + 1e-5f) + 4e-5f * (fabsf(d) + perp) + 3.0f * eps_abs;
+  const float R = b.w * (1.0f + 1e-5f) + 4e-5f * (fabsf(d) + perp) + 3.0f * eps_abs + tc.rbeam;
   return !(q > R);  // also keeps NaN
 }
 
@@ -1112,6 +1156,21 @@ PT_DEV bool plane_keeps(const TileCone &tc, float4 b, bool isplane) {
   if (!isplane || tc.all) return true;
   const float rx = b.x, ry = b.y, rz = b.z;
   const float rn = __fsqrt_rn(rx * rx + ry * ry + rz * rz);
+  if (tc.ortho) {
+    // parallel rays: d'.z = row . d is one number for the whole frame, o'.z = row . o + invm[11] is
+    // affine in the image position; no hit anywhere in the tile when o'.z has the sign of d'.z at the
+    // four corner origins (same margins)
+    const float dz = rx * tc.ax + ry * tc.ay + rz * tc.az;  // (along the unit direction: only the sign matters)
+    if (!(fabsf(dz) > 1e-4f * rn)) return true;
+    bool away = true;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float oz = rx * cxs[q] + ry * cys[q] + rz * czs[q] + b.w;
+      const float thr = 1e-4f * (rn * (fabsf(cxs[q]) + fabsf(cys[q]) + fabsf(czs[q])) + fabsf(b.w));
+      away = away && ((dz > 0.0f) ? (oz > thr) : (oz < -thr));
+    }
+    return !away;
+  }
   // the sign of o'.z from fp32: trusted only when |o'.z| stands clear of the rounding (else keep)
   const float oz = rx * tc.ox + ry * tc.oy + rz * tc.oz + b.w;
   if (!(fabsf(oz) > 1e-4f * (2.0f * rn * tc.oabs + fabsf(b.w)))) return true;  // also NaN
@@ -1130,14 +1189,15 @@ PT_DEV bool plane_keeps(const TileCone &tc, float4 b, bool isplane) {
 extern __shared__ unsigned long long pt_lds_masks[];
 
 // HIER: the mask bits index the tile's cell list (pt_cell_kernel), which holds the slots.
-template <bool ANYHIT, bool HIER = false>
+// HOISTED = false (orthogonal camera: no common origin): the object-space origin is computed per ray.
+template <bool ANYHIT, bool HIER = false, bool HOISTED = true>
 PT_DEV int world_query_tile(const PtKArgs &a, const Ray &r, int mbase, int npass, double &best_t, bool active,
                             const unsigned int *list = nullptr) {
   int best = -1;
   best_t = INFINITY;
   const double tmin = r.tmin, tmax = INFINITY;
   const int nd = a.n_diag, ns = a.n_spheres;
-  const WaveGuard g = wave_guard<true>(r, active);
+  const WaveGuard g = wave_guard<HOISTED>(r, active);
   for (int p = 0; p < npass; ++p) {
     const unsigned long long mv = pt_lds_masks[mbase + p];
     // readfirstlane returns a signed int: go through unsigned or bit 31 smears over the high half
@@ -1150,32 +1210,58 @@ PT_DEV int world_query_tile(const PtKArgs &a, const Ray &r, int mbase, int npass
       const int slot = HIER ? PT_KI(list)[idx] : idx;
       if (slot < ns) {
         double dx, dy, dz, ox, oy, oz, cc;
-        if (slot < nd && g.fast) {
-          pt_kdouble h = PT_KD(&a.hoist_diag[slot]);
-          dx = r.d.x * h[0];
-          dy = r.d.y * h[1];
-          dz = r.d.z * h[2];
-          ox = h[3];
-          oy = h[4];
-          oz = h[5];
-          cc = h[6];
+        if (HOISTED) {
+          if (slot < nd && g.fast) {
+            pt_kdouble h = PT_KD(&a.hoist_diag[slot]);
+            dx = r.d.x * h[0];
+            dy = r.d.y * h[1];
+            dz = r.d.z * h[2];
+            ox = h[3];
+            oy = h[4];
+            oz = h[5];
+            cc = h[6];
+          } else {
+            pt_kdouble m = PT_KD(a.recs[slot].invm);
+            pt_kdouble h = PT_KD(&a.hoist[slot]);
+            dx = r.d.x * m[0] + r.d.y * m[1] + r.d.z * m[2];
+            dy = r.d.x * m[4] + r.d.y * m[5] + r.d.z * m[6];
+            dz = r.d.x * m[8] + r.d.y * m[9] + r.d.z * m[10];
+            ox = h[0];
+            oy = h[1];
+            oz = h[2];
+            cc = h[3];
+          }
         } else {
-          pt_kdouble m = PT_KD(a.recs[slot].invm);
-          pt_kdouble h = PT_KD(&a.hoist[slot]);
-          dx = r.d.x * m[0] + r.d.y * m[1] + r.d.z * m[2];
-          dy = r.d.x * m[4] + r.d.y * m[5] + r.d.z * m[6];
-          dz = r.d.x * m[8] + r.d.y * m[9] + r.d.z * m[10];
-          ox = h[0];
-          oy = h[1];
-          oz = h[2];
-          cc = h[3];
+          bool done = false;
+          if (slot < nd && g.fast) {
+            pt_kdouble h = PT_KD(&a.diag[slot]);
+            if ((g.ozmask & ~(unsigned)*PT_KI(&a.diag[slot].tnz)) == 0u) {  // (see world_query)
+              dx = r.d.x * h[0];
+              dy = r.d.y * h[1];
+              dz = r.d.z * h[2];
+              ox = r.o.x * h[0] + h[3];
+              oy = r.o.y * h[1] + h[4];
+              oz = r.o.z * h[2] + h[5];
+              done = true;
+            }
+          }
+          if (!done) {
+            pt_kdouble m = PT_KD(a.recs[slot].invm);
+            dx = r.d.x * m[0] + r.d.y * m[1] + r.d.z * m[2];
+            dy = r.d.x * m[4] + r.d.y * m[5] + r.d.z * m[6];
+            dz = r.d.x * m[8] + r.d.y * m[9] + r.d.z * m[10];
+            ox = r.o.x * m[0] + r.o.y * m[1] + r.o.z * m[2] + m[3];
+            oy = r.o.x * m[4] + r.o.y * m[5] + r.o.z * m[6] + m[7];
+            oz = r.o.x * m[8] + r.o.y * m[9] + r.o.z * m[10] + m[11];
+          }
+          cc = (ox * ox + oy * oy + oz * oz) - 1.0;
         }
         const double aa = dx * dx + dy * dy + dz * dz;
         PT_SPHERE_ROOTS(slot);
       } else {
         pt_kdouble m = PT_KD(a.recs[slot].invm);
         const double dz = r.d.x * m[8] + r.d.y * m[9] + r.d.z * m[10];
-        const double oz = PT_KD(&a.hoist[slot])[2];
+        const double oz = HOISTED ? PT_KD(&a.hoist[slot])[2] : r.o.x * m[8] + r.o.y * m[9] + r.o.z * m[10] + m[11];
         PT_PLANE_HIT(slot);
       }
       PT_ANYHIT_EXIT();
@@ -1271,7 +1357,10 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_cell_kernel(const PtKArgs a, int 
 // numbers -- exactly what this loop does.  A pixel all of whose samples end like that (sky, lamps) is
 // finished here at Flat speed; a pixel that meets anything else is abandoned (nothing stored, its
 // rays not counted) and flagged in region_mask for pt_path_kernel, which renders it from its seed.
-template <int RENDERER, int WAVES, bool HIER>
+//
+// ORTHO: orthogonal camera -- the tile's rays fill a beam instead of a cone (tile_cone), nothing is
+// hoisted (HOISTED = false queries), no dome shortcut.
+template <int RENDERER, int WAVES, bool HIER, bool ORTHO = false>
 __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) void pt_tile_kernel(const PtKArgs a, int count_base) {
   int S, W, rows_local, npass;
   {
@@ -1374,7 +1463,7 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
     // 1e-6 .. 1e6, and |d| >= 1e-6 is checked, so nothing under- or overflows): the reference finds
     // exactly this hit for every sample.  With uniform pigments its colour does not depend on the hit
     // point, so each sample's value is known without generating the ray or drawing its jitter.
-    if (nsurv == 1 && only < a.n_spheres) {
+    if (!ORTHO && nsurv == 1 && only < a.n_spheres) {
       only = __builtin_amdgcn_readfirstlane(only);
       pt_kargs ca = cold_args(a);
       const PtShapeAux *ax = ca->aux + only;
@@ -1461,7 +1550,7 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
       const Ray ray = primary_ray(a, pcol, grow, up, vp);
       PT_TSTAMP(3);
       double best_t;
-      const int hit = world_query_tile<RENDERER == PT_RENDERER_ONOFF, HIER>(a, ray, mbase, tpass, best_t, alive, list);
+      const int hit = world_query_tile<RENDERER == PT_RENDERER_ONOFF, HIER, !ORTHO>(a, ray, mbase, tpass, best_t, alive, list);
       PT_TSTAMP(4);
       if (alive) pix_rays++;
       V3 c;
@@ -1661,6 +1750,7 @@ template <bool TILED, bool LDSF, bool LAT>
 PT_DEV void path_trace(const PtKArgs &a) {
   PathCtx w;
   int S, nsamp, N, W = 0, rows_local = 0, npass = 0, D = 0, rr = 0, diag_lds = -1;
+  bool ortho = false;
   {
     pt_kargs c = cold_args(a);
     w.ws = c->ws;
@@ -1669,6 +1759,7 @@ PT_DEV void path_trace(const PtKArgs &a) {
     w.gtid = blockIdx.x * PT_BLOCK + threadIdx.x;
     w.lds_frame = c->frame_doubles;
     w.lds_base = TILED ? 4 * c->npass : 0;  // behind the four waves' survivor masks (8-byte units)
+    ortho = c->cam_kind != PT_CAMERA_PERSPECTIVE;
     diag_lds = c->diag_lds;
     S = c->S;
     N = c->N;
@@ -1956,7 +2047,8 @@ PT_DEV void path_trace(const PtKArgs &a) {
       double tp = INFINITY;
       int hp;
       if (TILED)
-        hp = world_query_tile<false>(a, ray, mbase, npass, tp, prim);
+        hp = ortho ? world_query_tile<false, false, false>(a, ray, mbase, npass, tp, prim)
+                   : world_query_tile<false, false, true>(a, ray, mbase, npass, tp, prim);
       else
         hp = world_query<false, false>(a, ray, INFINITY, tp, prim);
       if (prim) {

@@ -641,6 +641,12 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
       a.cone_dx[r] = (float)(m[r * 4 + 1] * (-2.0 * asp / p->width));
       a.cone_dy[r] = (float)(m[r * 4 + 2] * (-2.0 / p->height));
       a.cone_apex[r] = (float)(m[r * 4 + 0] * -dist + m[r * 4 + 3]);
+      if (cam->kind != PT_CAMERA_PERSPECTIVE) {
+        // camera.py:59-78: o = M * (-1, (1 - 2x/W) * aspect, 1 - 2y/H) + t, d = M * (1, 0, 0): the same
+        // affine model describes the ORIGINS, and the "apex" slot carries the common direction
+        a.cone_d0[r] = (float)(-m[r * 4 + 0] + m[r * 4 + 1] * asp + m[r * 4 + 2] + m[r * 4 + 3]);
+        a.cone_apex[r] = (float)m[r * 4 + 0];
+      }
     }
   }
   a.W = p->width;
@@ -681,12 +687,12 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
     static const int env_wg = getenv("PTRACE_PATH_WG_PER_CU") ? atoi(getenv("PTRACE_PATH_WG_PER_CU")) : 0;
     static const int env_ldsf = getenv("PTRACE_LDS_FRAMES") ? atoi(getenv("PTRACE_LDS_FRAMES")) : 1;
     // one queue for all pixels: 152 VGPRs, 3 waves per SIMD; second pass by regions: built for 1-2
-    const bool regions = cam->kind == PT_CAMERA_PERSPECTIVE && s->n_shapes > 0 && env_cull != 0;
+    const bool regions = s->n_shapes > 0 && env_cull != 0;
     int wg_per_cu = env_wg > 0 ? env_wg : (regions ? 2 : 3);
     // a frame is pushed for depths 0 .. max_depth-1 only (a hit at max_depth spawns nothing that is traced)
     a.frame_doubles = p->num_of_rays > 1 ? 20 : 6;
     frame_lds = (size_t)std::max(p->max_depth, 1) * a.frame_doubles * PT_BLOCK * sizeof(double);
-    const size_t mask_lds = (cam->kind == PT_CAMERA_PERSPECTIVE && env_cull != 0) ? (size_t)4 * a.npass * sizeof(unsigned long long) : 0;
+    const size_t mask_lds = regions ? (size_t)4 * a.npass * sizeof(unsigned long long) : 0;
     lds_frames = env_ldsf != 0 && frame_lds + mask_lds <= PT_LDS_BUDGET;
     // the scale+translate records ride along in LDS when they fit (world_query_lanes gathers them per lane)
     const size_t base_lds = mask_lds + (lds_frames ? frame_lds : 0);
@@ -703,12 +709,12 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
     cap = (long long)s->n_cu * wg_per_cu;
   }
   // the tiled path tracer (perspective camera): primary rays use the hoisted, culled tile query
-  const bool path_tiled = p->renderer == PT_RENDERER_PATHTRACER && cam->kind == PT_CAMERA_PERSPECTIVE &&
-                          s->n_shapes > 0 && env_cull != 0;
-  const bool hoist = cam->kind == PT_CAMERA_PERSPECTIVE && s->n_shapes > 0 &&
-                     (p->renderer != PT_RENDERER_PATHTRACER || path_tiled);
-  // 8x8 tiles with culled shape lists: primary rays of a perspective camera (OnOff, Flat, PointLight)
-  const bool tile = hoist && env_cull != 0 && s->n_shapes >= 4 &&
+  const bool ortho = cam->kind != PT_CAMERA_PERSPECTIVE;
+  const bool path_tiled = p->renderer == PT_RENDERER_PATHTRACER && s->n_shapes > 0 && env_cull != 0;
+  // per-camera constants of the shapes (invm * origin): only a perspective camera has a common origin
+  const bool hoist = !ortho && s->n_shapes > 0 && (p->renderer != PT_RENDERER_PATHTRACER || path_tiled);
+  // 8x8 tiles with culled shape lists: primary rays (OnOff, Flat, PointLight)
+  const bool tile = s->n_shapes > 0 && env_cull != 0 && s->n_shapes >= 4 &&
                     (p->renderer == PT_RENDERER_ONOFF || p->renderer == PT_RENDERER_FLAT ||
                      p->renderer == PT_RENDERER_POINTLIGHT);
   int grid = (int)std::max<long long>(1, std::min(want, cap));
@@ -817,7 +823,7 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
   const int cells_x = (p->width + PT_CELL - 1) / PT_CELL, cells_y = (p->height + PT_CELL - 1) / PT_CELL;
   const int ncells = cells_x * cells_y;
   const int cell_stride = (s->n_shapes + 63) / 64 * 64;
-  const bool hier = (tile || path_tiled) && env_hier >= 0 && s->n_shapes > env_hier && (a.n_ranks == 1 || a.row_block % 8 == 0) &&
+  const bool hier = (tile || path_tiled) && !ortho && env_hier >= 0 && s->n_shapes > env_hier && (a.n_ranks == 1 || a.row_block % 8 == 0) &&
                     (size_t)ncells * cell_stride * sizeof(unsigned int) <= ((size_t)2 << 30);
   if (hier) {
     const size_t need = (size_t)ncells * cell_stride;
@@ -877,6 +883,15 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
         hipLaunchKernelGGL((pt_tile_kernel<PT_RENDERER_POINTLIGHT, 3, true>), dim3(tgrid), dim3(PT_BLOCK), lds, st, a, 0);
       else
         hipLaunchKernelGGL((pt_tile_kernel<PT_RENDERER_PATHTRACER, 4, true>), dim3(tgrid), dim3(PT_BLOCK), lds, st, a, grid);
+    } else if (ortho) {
+      if (p->renderer == PT_RENDERER_ONOFF)
+        hipLaunchKernelGGL((pt_tile_kernel<PT_RENDERER_ONOFF, 4, false, true>), dim3(tgrid), dim3(PT_BLOCK), lds, st, a, 0);
+      else if (p->renderer == PT_RENDERER_FLAT)
+        hipLaunchKernelGGL((pt_tile_kernel<PT_RENDERER_FLAT, 4, false, true>), dim3(tgrid), dim3(PT_BLOCK), lds, st, a, 0);
+      else if (p->renderer == PT_RENDERER_POINTLIGHT)
+        hipLaunchKernelGGL((pt_tile_kernel<PT_RENDERER_POINTLIGHT, 3, false, true>), dim3(tgrid), dim3(PT_BLOCK), lds, st, a, 0);
+      else
+        hipLaunchKernelGGL((pt_tile_kernel<PT_RENDERER_PATHTRACER, 4, false, true>), dim3(tgrid), dim3(PT_BLOCK), lds, st, a, grid);
     } else if (p->renderer == PT_RENDERER_ONOFF)
       hipLaunchKernelGGL((pt_tile_kernel<PT_RENDERER_ONOFF, 4, false>), dim3(tgrid), dim3(PT_BLOCK), lds, st, a, 0);
     else if (p->renderer == PT_RENDERER_FLAT)

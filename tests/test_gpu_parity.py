@@ -14,6 +14,8 @@ import os
 import numpy as np
 import pytest
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 from pytracer_amd import abi
 from tests import util
 
@@ -215,6 +217,76 @@ def test_tile_culling_is_invisible(dev, oracle, n, spread, rotated, W, H, S, ren
                 p = abi.copy_params(par, n_ranks=3, rank=rank, row_block=rb)
                 got[abi.rows_for_rank(H, rb, 3, rank)] = ds.render(cam, p)
             assert util.bits_equal(got, ora)
+
+
+@pytest.mark.parametrize("n,renderer,S", [(120, abi.RENDERER_FLAT, 0), (300, abi.RENDERER_ONOFF, 2),
+                                          (120, abi.RENDERER_POINTLIGHT, 0), (60, abi.RENDERER_FLAT, 3)])
+def test_orthogonal_camera_beam_culling_is_invisible(dev, oracle, n, renderer, S):
+    """Orthogonal camera: the tile's rays fill a beam; culling against it (spheres and planes) and the
+    un-hoisted tile query must reproduce the oracle bit for bit, whatever the row partition."""
+    from pytracer_amd import flatten, hostmodel as hm
+
+    world = _cluster_world(n, 1.2, seed=31 + n, rotated=True)
+    world.add_shape(hm.Plane(hm.translation(hm.Vec(6.0, 0.0, 0.0)) * hm.rotation_y(70.0),
+                             hm.Material(hm.DiffuseBRDF(hm.CheckeredPigment(hm.Color(0.9, 0.1, 0.1), hm.Color(0.1, 0.1, 0.9), 3)))))
+    if renderer == abi.RENDERER_POINTLIGHT:
+        world.add_light(hm.PointLight(hm.Vec(-2.0, 3.0, 6.0), hm.Color(1.0, 0.9, 0.8), 0.0))
+    scene = flatten.flatten_world(world)
+    W, H = 144, 96
+    camera = hm.OrthogonalCamera(W / H, hm.translation(hm.Vec(-1.0, 0.2, 1.0)) * hm.rotation_z(12.0) * hm.rotation_y(8.0) *
+                                 hm.scaling(hm.Vec(1.0, 2.5, 2.0)))
+    cam = flatten.flatten_camera(camera)
+    par = abi.make_params(W, H, renderer, samples_per_side=S, path_state=9, path_seq=3)
+    ora, n_rays = oracle.render(scene, cam, par, sqr_mode=oracle.SQR_MUL)
+    oracle.set_sqr_mode(oracle.SQR_POW)
+    with dev.DeviceScene(scene) as ds:
+        out = ds.render(cam, par)
+        assert ds.stats().lds_bytes > 0, "expected the tile kernel"
+        assert util.bits_equal(out, ora), f"max rel {util.rel_err(out, ora).max()}"
+        assert ds.stats().n_rays == n_rays
+        got = np.zeros_like(out)
+        for rank in range(3):
+            p = abi.copy_params(par, n_ranks=3, rank=rank, row_block=8)
+            got[abi.rows_for_rank(H, 8, 3, rank)] = ds.render(cam, p)
+        assert util.bits_equal(got, ora)
+
+
+def test_plain_kernels_without_culling(oracle):
+    """PTRACE_CULL=0 (read once per process, hence a child process): every renderer through the
+    one-lane-per-pixel kernels and the one-queue path tracer, both cameras, against the oracle."""
+    import subprocess
+    import sys
+
+    code = r'''
+import numpy as np
+from pytracer_amd import abi, flatten, hostmodel as hm, scenes, device
+from oracle import oracle
+from tests import util
+world = scenes.synthetic_world(24, with_plane=True)
+world.add_light(hm.PointLight(hm.Vec(-2.0, 3.0, 6.0), hm.Color(1.0, 0.9, 0.8), 0.0))
+scene = flatten.flatten_world(world)
+W, H = 72, 40
+for camera in (hm.PerspectiveCamera(1.0, W / H, hm.translation(hm.Vec(-1.0, 0.0, 1.0))),
+               hm.OrthogonalCamera(W / H, hm.translation(hm.Vec(-1.0, 0.0, 1.0)) * hm.scaling(hm.Vec(1.0, 3.0, 2.0)))):
+    cam = flatten.flatten_camera(camera)
+    with device.DeviceScene(scene) as ds:
+        for renderer, S in ((abi.RENDERER_ONOFF, 0), (abi.RENDERER_FLAT, 2), (abi.RENDERER_POINTLIGHT, 0)):
+            par = abi.make_params(W, H, renderer, samples_per_side=S)
+            ora, n_rays = oracle.render(scene, cam, par, sqr_mode=oracle.SQR_MUL)
+            out = ds.render(cam, par)
+            assert ds.stats().lds_bytes == 0, "culling should be off"
+            assert util.bits_equal(out, ora), (renderer, S)
+            assert ds.stats().n_rays == n_rays
+        par = abi.make_params(W, H, abi.RENDERER_PATHTRACER, samples_per_side=2, num_of_rays=2, max_depth=3, rr_limit=2,
+                              path_state=45, path_seq=54)
+        ora, _ = oracle.render(scene, cam, par, sqr_mode=oracle.SQR_MUL)
+        out = ds.render(cam, par)
+        assert np.all(util.rel_err(out, ora) <= 1e-5)
+print("plain kernels ok")
+'''
+    env = dict(os.environ, PTRACE_CULL="0")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "plain kernels ok" in r.stdout, r.stdout + r.stderr
 
 
 def _dome_world(dome, dome_material, n_small, seed, planes=()):

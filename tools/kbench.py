@@ -46,6 +46,9 @@ CONFIGS = {
     "c5": (10000, False, True, 1280, 720, dict(renderer=abi.RENDERER_FLAT)),
     "c5pt": (10000, False, True, 1280, 720, dict(renderer=abi.RENDERER_PATHTRACER, samples_per_side=2, num_of_rays=1,
                                                  max_depth=3, rr_limit=3, path_state=45, path_seq=54)),
+    "c2ortho": (32, True, False, 1280, 720, dict(renderer=abi.RENDERER_FLAT, ortho=True)),
+    "c3ortho": (32, False, False, 1280, 720, dict(renderer=abi.RENDERER_PATHTRACER, samples_per_side=4, num_of_rays=1,
+                                                  max_depth=3, rr_limit=3, path_state=45, path_seq=54, ortho=True)),
     "pl": (32, True, False, 1280, 720, dict(renderer=abi.RENDERER_POINTLIGHT, lights=2)),
     "pl5": (10000, False, True, 1280, 720, dict(renderer=abi.RENDERER_POINTLIGHT, lights=1)),
     "c5small": (10000, False, True, 320, 180, dict(renderer=abi.RENDERER_FLAT)),
@@ -66,7 +69,12 @@ def main():
             from pytracer_amd import hostmodel as hm
             world.add_light(hm.PointLight(hm.Vec(-3.0 + 4.0 * l, 6.0 - 9.0 * l, 8.0), hm.Color(1.0, 0.9, 0.8), 0.0))
         flat = flatten.flatten_world(world)
-        cam = flatten.flatten_camera(scenes.synthetic_camera(W, H))
+        if kw.pop("ortho", False):
+            from pytracer_amd import hostmodel as hm
+            cam = flatten.flatten_camera(hm.OrthogonalCamera(W / H, hm.translation(hm.Vec(-1.0, 0.0, 1.5)) *
+                                                             hm.scaling(hm.Vec(1.0, 3.0, 1.7))))
+        else:
+            cam = flatten.flatten_camera(scenes.synthetic_camera(W, H))
         par = abi.make_params(W, H, out_format=abi.OUT_F64 if args.f64 else abi.OUT_F32, **kw)
         ds = DeviceScene(flat)
         out = torch.empty((H, W, 3), dtype=torch.float64 if args.f64 else torch.float32, device="cuda")
