@@ -1463,13 +1463,36 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
     // 1e-6 .. 1e6, and |d| >= 1e-6 is checked, so nothing under- or overflows): the reference finds
     // exactly this hit for every sample.  With uniform pigments its colour does not depend on the hit
     // point, so each sample's value is known without generating the ray or drawing its jitter.
-    if (!ORTHO && nsurv == 1 && only < a.n_spheres) {
+    // Orthogonal camera: the origins differ, but |o'|^2 is convex in the image position, so it is below
+    // 0.5 for every ray when it is (by a margin, in fp32) at the tile's four corner origins; |d'| is one
+    // number for the frame.
+    if (nsurv == 1 && only < a.n_spheres) {
       only = __builtin_amdgcn_readfirstlane(only);
       pt_kargs ca = cold_args(a);
       const PtShapeAux *ax = ca->aux + only;
-      const double hc_ = (only < a.n_diag) ? PT_KD(&a.hoist_diag[only])[6] : PT_KD(&a.hoist[only])[3];
       const float fro2 = (float)PT_KD(&a.recs[only])[13];  // PtShapeRec::fro2
-      if (hc_ < -0.5 && fro2 * tc.dmax2 < 1e6f && tc.dmin > 1e-6f && !tc.all && ax->needs_uv == 0) {
+      double hc_;
+      float dmax2 = tc.dmax2, dmin = tc.dmin;
+      if (ORTHO) {
+        pt_kdouble m = PT_KD(a.recs[only].invm);
+        const float ox = (float)m[0] * tc.kx + (float)m[1] * tc.ky + (float)m[2] * tc.kz + (float)m[3];
+        const float oy = (float)m[4] * tc.kx + (float)m[5] * tc.ky + (float)m[6] * tc.kz + (float)m[7];
+        const float oz = (float)m[8] * tc.kx + (float)m[9] * tc.ky + (float)m[10] * tc.kz + (float)m[11];
+        float o2 = ox * ox + oy * oy + oz * oz;  // this lane's corner (lane & 3)
+        o2 = fmaxf(o2, __shfl_xor(o2, 1, 64));
+        o2 = fmaxf(o2, __shfl_xor(o2, 2, 64));
+        // fp32 evaluation: relative 1e-6 of the terms; |o'| <= |invm|_F (|k| + 1)-ish, hence the slack
+        const float slack = 1e-5f * (fro2 * (tc.oabs * tc.oabs * 3.0f + 1.0f) + 1.0f);
+        hc_ = (o2 + slack < 0.45f) ? -0.55 : 0.0;  // NaN: 0.0
+        pt_kargs cc_ = cold_args(a);
+        const float d2 = cc_->cone_apex[0] * cc_->cone_apex[0] + cc_->cone_apex[1] * cc_->cone_apex[1] +
+                         cc_->cone_apex[2] * cc_->cone_apex[2];
+        dmax2 = d2 * (1.0f + 1e-5f);
+        dmin = __fsqrt_rn(d2) * (1.0f - 1e-5f);
+      } else {
+        hc_ = (only < a.n_diag) ? PT_KD(&a.hoist_diag[only])[6] : PT_KD(&a.hoist[only])[3];
+      }
+      if (hc_ < -0.5 && fro2 * dmax2 < 1e6f && dmin > 1e-6f && !tc.all && ax->needs_uv == 0) {
         V3 c;
         bool settled = true;
         if (RENDERER == PT_RENDERER_ONOFF) {

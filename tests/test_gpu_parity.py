@@ -341,14 +341,17 @@ def test_dome_shortcut_and_plane_culling_are_invisible(dev, oracle, case):
     scene = flatten.flatten_world(world)
     W, H = 136, 88
     cam = flatten.flatten_camera(hm.PerspectiveCamera(1.0, W / H, hm.translation(hm.Vec(-1.0, 0.0, 1.0))))
+    cam_o = flatten.flatten_camera(hm.OrthogonalCamera(W / H, hm.translation(hm.Vec(-1.0, 0.0, 1.0)) * hm.rotation_z(10.0) *
+                                                       hm.scaling(hm.Vec(1.0, 2.0, 1.5))))
     with dev.DeviceScene(scene) as ds:
         for renderer, S in ((abi.RENDERER_FLAT, 0), (abi.RENDERER_FLAT, 3), (abi.RENDERER_ONOFF, 2)):
             par = abi.make_params(W, H, renderer, samples_per_side=S, path_state=7, path_seq=11)
-            ora, n_rays = oracle.render(scene, cam, par, sqr_mode=oracle.SQR_MUL)
-            out = ds.render(cam, par)
-            assert ds.stats().lds_bytes > 0, "expected the tile kernel"
-            assert util.bits_equal(out, ora), f"{case} renderer {renderer} S={S}: max rel {util.rel_err(out, ora).max()}"
-            assert ds.stats().n_rays == n_rays
+            for c in (cam, cam_o):  # (the orthogonal view: the dome test looks at the four corner origins)
+                ora, n_rays = oracle.render(scene, c, par, sqr_mode=oracle.SQR_MUL)
+                out = ds.render(c, par)
+                assert ds.stats().lds_bytes > 0, "expected the tile kernel"
+                assert util.bits_equal(out, ora), f"{case} renderer {renderer} S={S}: max rel {util.rel_err(out, ora).max()}"
+                assert ds.stats().n_rays == n_rays
         if case != "checkered":  # (sin/cos/atan2 of the device differ from libm in the last bit: not bit-exact)
             par = abi.make_params(W, H, abi.RENDERER_PATHTRACER, samples_per_side=2, num_of_rays=2, max_depth=2,
                                   rr_limit=1, path_state=45, path_seq=54)
