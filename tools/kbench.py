@@ -43,6 +43,10 @@ CONFIGS = {
                                                 max_depth=3, rr_limit=3, path_state=45, path_seq=54)),
     "c4crop": (256, False, True, 960, 540, dict(renderer=abi.RENDERER_PATHTRACER, samples_per_side=4, num_of_rays=1,
                                                 max_depth=5, rr_limit=3, path_state=45, path_seq=54)),
+    "c4": (256, False, True, 3840, 2160, dict(renderer=abi.RENDERER_PATHTRACER, samples_per_side=8, num_of_rays=1,
+                                              max_depth=5, rr_limit=3, path_state=45, path_seq=54)),
+    "c4rank": (256, False, True, 3840, 2160, dict(renderer=abi.RENDERER_PATHTRACER, samples_per_side=8, num_of_rays=1,
+                                                  max_depth=5, rr_limit=3, path_state=45, path_seq=54, n_ranks=8, rank=3, row_block=8)),
     "c5": (10000, False, True, 1280, 720, dict(renderer=abi.RENDERER_FLAT)),
     "c5pt": (10000, False, True, 1280, 720, dict(renderer=abi.RENDERER_PATHTRACER, samples_per_side=2, num_of_rays=1,
                                                  max_depth=3, rr_limit=3, path_state=45, path_seq=54)),
