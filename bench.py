@@ -126,6 +126,47 @@ def extra_rows(device: int):
     return rows
 
 
+def boundary_rows(flat, cam_for, device: int):
+    """the same C2 frame seen from the drop-in boundary -- ms per frame at the C-ABI with
+    caller-owned HOST buffers (`pt_render`: kernel + D2H), scene upload (flatten + H2D), and the Python
+    fill of a reference-style HdrImage (a list of W*H Color objects).  None of these is `value`."""
+    from pytracer_amd.tracer import _fill_image
+
+    W, H = 1280, 720
+    cam = cam_for(W, H)
+    t0 = time.perf_counter()
+    ds = DeviceScene(flat, device=device)
+    upload_ms = (time.perf_counter() - t0) * 1e3
+    rows = {"scene_upload_ms": upload_ms}
+    for name, fmt in (("pt_render_host_f64_ms", abi.OUT_F64), ("pt_render_host_f32_ms", abi.OUT_F32)):
+        par = abi.make_params(W, H, abi.RENDERER_FLAT, out_format=fmt)
+        ds.render(cam, par)
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            out = ds.render(cam, par)
+            ts.append((time.perf_counter() - t0) * 1e3)
+        rows[name] = float(np.median(ts))
+
+    class RefColor:  # the reference's Color: three attributes
+        __slots__ = ("r", "g", "b")
+
+        def __init__(self, r=0.0, g=0.0, b=0.0):
+            self.r, self.g, self.b = r, g, b
+
+    class RefImage:
+        def __init__(self, w, h):
+            self.width, self.height = w, h
+            self.pixels = [RefColor() for _ in range(w * h)]
+
+    img = RefImage(W, H)
+    t0 = time.perf_counter()
+    _fill_image(img, out.astype(np.float64))
+    rows["python_hdrimage_fill_ms"] = (time.perf_counter() - t0) * 1e3
+    ds.close()
+    return rows
+
+
 def measured_traffic():
     """HBM bytes per launch of the headline kernel from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE;
     collected separately, see profiles/): bench.py cannot read hardware counters itself."""
@@ -308,6 +349,7 @@ def main():
             result["roofline"]["traffic_source"] = tr["source"]
         if n == 1 and not args.no_extras:
             result["extra"] = extra_rows(local_rank)
+            result["boundary"] = boundary_rows(flat, cam_for, local_rank)
         if n == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(flat, cam_for)
         print(json.dumps(result), flush=True)
