@@ -1319,6 +1319,17 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_cell_kernel(const PtKArgs a, int 
     const bool in = slot < s1;
     const float4 b = b_next;
     b_next = a.bounds[slot + PT_BLOCK < s1 ? slot + PT_BLOCK : 0];
+    if (a.bs_levels) {
+      // Morton-ordered slots: this wave's 64 slots are one chunk of the ball hierarchy (pt_scene_upload);
+      // a chunk whose ball misses the group cone has nothing for any of the four cells
+      const int cb = __builtin_amdgcn_readfirstlane(slot) >> 6;
+      if ((cb + 1) * 64 <= a.n_spheres) {
+        typedef const __attribute__((address_space(4))) float *pt_kfloat;
+        pt_kfloat cs = (pt_kfloat)(const void *)a.bsoa + 4 * (a.bs_stride + a.gs_stride);
+        const float4 ball = {cs[cb], cs[a.cs_stride + cb], cs[2 * a.cs_stride + cb], cs[3 * a.cs_stride + cb]};
+        if (!cone_keeps(tg, ball)) continue;
+      }
+    }
     const bool isplane = slot >= a.n_spheres;  // planes carry no bounding sphere: every cell keeps them
     if (!__ballot(in && (isplane || cone_keeps(tg, b)))) continue;
 #pragma unroll
