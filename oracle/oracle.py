@@ -15,7 +15,9 @@ import numpy as np
 from pytracer_amd import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libpt_oracle.so")
+# PT_ORACLE_LIB: load another build of the oracle (tests/test_oracle_sanitized.py points it at the
+# ASan/UBSan build, `make -C oracle asan`, in a child process that preloads libasan)
+_LIB_PATH = os.environ.get("PT_ORACLE_LIB") or os.path.join(_HERE, "libpt_oracle.so")
 _lib = None
 
 _pd = C.POINTER(C.c_double)
