@@ -6,15 +6,15 @@ Mirrors ``python -m pytracer render`` (main.py:76-214): same options, same defau
 (a PFM file and a tone-mapped PNG), with the per-pixel loop running on the MI355X.  The scene-file
 language is parsed by pytracer's own parser when pytracer is importable (the parser is out of scope
 for this path and stays the reference's); ``SCENE`` may also name a built-in scene —
-``builtin:demo`` (the scene of examples/demo.txt), ``builtin:c2``, ``builtin:c3``, ``builtin:c5`` —
+``builtin:demo`` (the scene of examples/demo.txt), ``builtin:c2`` ... ``builtin:c5`` —
 so the driver also runs where pytracer is not installed.
 """
 from __future__ import annotations
 
 import sys
-from math import sqrt
+from math import isqrt
 from time import perf_counter
-from typing import Dict, List
+from typing import Dict, Iterable
 
 import click
 
@@ -25,51 +25,59 @@ from .tracer import GpuImageTracer
 RENDERERS = ["onoff", "flat", "pathtracing", "pointlight"]
 
 
-def build_variable_table(definitions: List[str]) -> Dict[str, float]:
-    """``-d NAME:VALUE`` switches -> {name: value} (main.py:48-70)."""
-    variables = {}
-    for declaration in definitions:
-        parts = declaration.split(":")
-        if len(parts) != 2:
-            print(f"error, the definition «{declaration}» does not follow the pattern NAME:VALUE")
-            sys.exit(1)
-        name, value = parts
+class UsageError(Exception):
+    """A command-line value the driver cannot use; reported on stderr, exit status 2."""
+
+
+def parse_float_overrides(switches: Iterable[str]) -> Dict[str, float]:
+    """Every ``-d NAME:VALUE`` switch becomes one entry of the scene parser's variable table (the contract of
+    main.py:48-70 and scene_file.py:640-675: float variables that override the scene file's own ``float`` lines).
+    A switch without exactly one colon, with an empty name, or whose value is not a float is refused."""
+    table: Dict[str, float] = {}
+    for switch in switches:
+        name, colon, text = switch.partition(":")
+        if not colon or not name or ":" in text:
+            raise UsageError(f"-d expects NAME:VALUE, got {switch!r}")
         try:
-            variables[name] = float(value)
+            table[name] = float(text)
         except ValueError:
-            print(f"invalid floating-point value «{value}» in definition «{declaration}»")
-            sys.exit(1)
-    return variables
+            raise UsageError(f"-d {name}: {text!r} is not a floating-point number") from None
+    return table
+
+
+BUILTIN_SCENES = {  # name -> (spheres, ground plane, "wide" recipe) of SURVEY.md 8(d)
+    "c2": (32, True, False), "c3": (32, False, False), "c4": (256, False, True), "c5": (10000, False, True)}
 
 
 def _load_scene(name: str, variables: Dict[str, float], width: int, height: int):
-    """-> (world, camera, classes): ``classes`` supplies the renderer / PCG types matching the world."""
+    """-> (world, camera, classes): ``classes`` supplies the renderer / PCG types matching the world.
+
+    ``builtin:NAME`` builds one of this repository's scene recipes from parameter-holder classes; anything
+    else is a scene file in pytracer's language and goes through pytracer's own parser (out of scope for this
+    path: it stays the reference's, scene_file.py:640-697), whose objects the flattener reads directly."""
     if name.startswith("builtin:"):
-        which = name.split(":", 1)[1]
+        which = name[len("builtin:"):]
         if which == "demo":
-            world, camera = scenes.demo_world(clock=variables.get("clock", 150.0))
-        elif which in ("c2", "c3", "c5"):
-            n, plane, wide = {"c2": (32, True, False), "c3": (32, False, False), "c5": (10000, False, True)}[which]
-            world, camera = scenes.synthetic_world(n, with_plane=plane, wide=wide), scenes.synthetic_camera(width, height)
-        else:
-            print(f"unknown built-in scene «{which}» (demo, c2, c3, c5)")
-            sys.exit(1)
-        return world, camera, hm
+            return (*scenes.demo_world(clock=variables.get("clock", 150.0)), hm)
+        if which in BUILTIN_SCENES:
+            n, plane, wide = BUILTIN_SCENES[which]
+            return scenes.synthetic_world(n, with_plane=plane, wide=wide), scenes.synthetic_camera(width, height), hm
+        raise UsageError(f"no built-in scene {which!r} (have: demo, {', '.join(sorted(BUILTIN_SCENES))})")
     try:
-        from pytracer import render as ref_render  # the reference's renderer classes (parameter holders here)
+        from pytracer import render as ref_render
         from pytracer.pcg import PCG as RefPCG
         from pytracer.scene_file import GrammarError, InputStream, parse_scene
     except ImportError:
-        print("pytracer is not importable: its scene-file parser is needed to read scene files "
-              "(or use builtin:demo, builtin:c2, builtin:c3, builtin:c5)")
-        sys.exit(1)
-    with open(name, "rt") as f:
-        try:
+        raise UsageError(f"{name}: reading a scene file needs pytracer's parser, and pytracer is not importable "
+                         "here; the built-in scenes (builtin:demo, builtin:c2, ...) need nothing") from None
+    try:
+        with open(name, "rt") as f:
             scene = parse_scene(input_file=InputStream(stream=f, file_name=name), variables=variables)
-        except GrammarError as e:
-            loc = e.location
-            print(f"{loc.file_name}:{loc.line_num}:{loc.col_num}: {e.message}")
-            sys.exit(1)
+    except OSError as e:
+        raise UsageError(f"{name}: {e.strerror}") from None
+    except GrammarError as e:
+        at = e.location
+        raise UsageError(f"{at.file_name}, line {at.line_num}, column {at.col_num}: {e.message}") from None
 
     class Ref:  # the reference's own classes, so the flattener sees exactly what main.py would build
         OnOffRenderer, FlatRenderer = ref_render.OnOffRenderer, ref_render.FlatRenderer
@@ -77,6 +85,31 @@ def _load_scene(name: str, variables: Dict[str, float], width: int, height: int)
         PCG = RefPCG
 
     return scene.world, scene.camera, Ref
+
+
+class RenderJob:
+    """Everything `render` needs before a GPU is touched: scene objects and the renderer parameter holder."""
+
+    def __init__(self, world, camera, renderer, samples_per_side):
+        self.world, self.camera, self.renderer, self.samples_per_side = world, camera, renderer, samples_per_side
+
+
+def plan_render(width, height, algorithm, num_of_rays, max_depth, init_state, init_seq, samples_per_pixel,
+                declare_float, input_scene_name) -> RenderJob:
+    """Options -> scene + renderer (main.py:144-191 in effect): the sample count must be a perfect square; the
+    four algorithms map onto the four renderer classes, only the path tracer takes the ray/depth/seed options."""
+    side = isqrt(samples_per_pixel) if samples_per_pixel >= 0 else -1
+    if side * side != samples_per_pixel:
+        raise UsageError(f"--samples-per-pixel {samples_per_pixel}: must be a perfect square (1, 4, 9, 16, ...)")
+    world, camera, K = _load_scene(input_scene_name, parse_float_overrides(declare_float), width, height)
+    make = {
+        "onoff": lambda: K.OnOffRenderer(world=world),
+        "flat": lambda: K.FlatRenderer(world=world),
+        "pathtracing": lambda: K.PathTracer(world=world, pcg=K.PCG(init_state=init_state, init_seq=init_seq),
+                                            num_of_rays=num_of_rays, max_depth=max_depth),
+        "pointlight": lambda: K.PointLightRenderer(world=world),
+    }
+    return RenderJob(world, camera, make[algorithm](), side)
 
 
 @click.group()
@@ -101,47 +134,29 @@ def cli():
 @click.argument("input_scene_name", type=str)
 def render(width, height, algorithm, pfm_output, png_output, num_of_rays, max_depth, init_state, init_seq,
            samples_per_pixel, declare_float, device, input_scene_name):
-    samples_per_side = int(sqrt(samples_per_pixel))
-    if samples_per_side ** 2 != samples_per_pixel:
-        print(f"Error, the number of samples per pixel ({samples_per_pixel}) must be a perfect square")
-        return
-    variables = build_variable_table(list(declare_float))
-    world, camera, K = _load_scene(input_scene_name, variables, width, height)
-
+    try:
+        job = plan_render(width, height, algorithm, num_of_rays, max_depth, init_state, init_seq, samples_per_pixel,
+                          declare_float, input_scene_name)
+    except UsageError as e:
+        click.echo(f"pytracer_amd render: {e}", err=True)
+        sys.exit(2)
+    click.echo(f"{width}x{height} px, {algorithm}, {job.samples_per_side ** 2} sample(s) per pixel, "
+               f"{len(job.world.shapes)} shape(s), GPU {device}")
     image = hm.HdrImage(width, height)
-    print(f"Generating a {width}×{height} image")
-    tracer = GpuImageTracer(image=image, camera=camera, samples_per_side=samples_per_side, device=device)
-    if algorithm == "onoff":
-        print("Using on/off renderer")
-        renderer = K.OnOffRenderer(world=world)
-    elif algorithm == "flat":
-        print("Using flat renderer")
-        renderer = K.FlatRenderer(world=world)
-    elif algorithm == "pathtracing":
-        print("Using a path tracer")
-        renderer = K.PathTracer(world=world, pcg=K.PCG(init_state=init_state, init_seq=init_seq),
-                                num_of_rays=num_of_rays, max_depth=max_depth)
-    else:
-        print("Using a point-light tracer")
-        renderer = K.PointLightRenderer(world=world)
-
-    def print_progress(row, col):
-        print(f"Rendering row {row + 1}/{image.height}\r", end="")
-
-    start = perf_counter()
-    tracer.fire_all_rays(renderer, callback=print_progress)
-    elapsed = perf_counter() - start
+    tracer = GpuImageTracer(image=image, camera=job.camera, samples_per_side=job.samples_per_side, device=device)
+    started = perf_counter()
+    tracer.fire_all_rays(job.renderer, callback=lambda col, row: click.echo(f"  row {row + 1} of {height}\r", nl=False))
+    wall = perf_counter() - started
     st = tracer.last_stats
-    print(f"Rendering completed in {elapsed:.3f} s (kernel {st.kernel_ms:.3f} ms, {st.n_rays} rays)")
-
-    with open(pfm_output, "wb") as outf:  # main.py:203-204
-        image.write_pfm(outf)
-    print(f"HDR demo image written to {pfm_output}")
-    image.normalize_image(factor=1.0)  # main.py:208-209
+    click.echo(f"frame done: {wall:.3f} s wall, {st.kernel_ms:.3f} ms in kernels, {st.n_rays} rays")
+    # what main.py:203-213 leaves behind: the PFM of the raw frame, then a PNG of the tone-mapped one
+    with open(pfm_output, "wb") as f:
+        image.write_pfm(f)
+    image.normalize_image(factor=1.0)
     image.clamp_image()
-    with open(png_output, "wb") as outf:  # main.py:212-213
-        image.write_ldr_image(outf, "PNG")
-    print(f"PNG demo image written to {png_output}")
+    with open(png_output, "wb") as f:
+        image.write_ldr_image(f, "PNG")
+    click.echo(f"wrote {pfm_output} and {png_output}")
     tracer.close()
 
 

@@ -170,6 +170,12 @@ RENDERER_KINDS = {
 }
 
 
+def is_device_renderer(func) -> bool:
+    """True for the reference's renderer objects (by class name, render.py:42-193): what the device path
+    renders.  Anything else handed to ``fire_all_rays`` is an opaque callable."""
+    return _cls(func) in RENDERER_KINDS and hasattr(func, "world") and hasattr(func, "background_color")
+
+
 def renderer_params(renderer, width: int, height: int, samples_per_side: int = 0,
                     tracer_pcg=None, pcg_mode: int = abi.PCG_PIXEL,
                     out_format: int = abi.OUT_F64) -> abi.Params:

@@ -4,24 +4,40 @@ Same constructor, ``fire_ray`` and ``fire_all_rays`` signatures.  ``fire_all_ray
 flattens ``renderer.world`` / the camera (duck-typed, :mod:`pytracer_amd.flatten`), runs the HIP
 kernels through the C-ABI and fills ``image`` in place; it returns ``None`` like the reference.
 
-Differences that follow from running on a GPU, all explicit:
+What ``func`` may be:
 
-* ``func`` must be one of the reference's renderers (``OnOffRenderer``, ``FlatRenderer``,
-  ``PathTracer``, ``PointLightRenderer`` — by class name, from pytracer or
-  :mod:`pytracer_amd.hostmodel`).  An arbitrary Python callable cannot run on the device and
-  raises ``UnsupportedSceneError``; nothing falls back to a CPU loop.
-* Random streams: the reference draws jitter and scattering numbers from two global sequential
-  generators in row-major pixel order (imagetracer.py:89-92, render.py:118,128), which is
-  inherently serial.  The device uses the per-pixel alignment of SURVEY.md §8c: pixel
-  ``i = row*W + col`` owns ``PCG(S0, Q0 + i)`` (``pcg_mode="pixel"``) or each sample owns
-  ``PCG(S0, Q0 + i*S² + k)`` (``"sample"``), where (S0, Q0) are the seeds of ``PathTracer.pcg``
-  (or of the tracer's ``pcg`` for the other renderers).  Images are deterministic and independent
-  of grid, tile or rank layout.
-* ``callback`` is invoked once before rendering (as the reference does, imagetracer.py:77-78) and
-  once after the frame completes; the device renders a frame in well under ``callback_time_s``.
+* one of the reference's renderers (``OnOffRenderer``, ``FlatRenderer``, ``PathTracer``,
+  ``PointLightRenderer`` — by class name, from pytracer or :mod:`pytracer_amd.hostmodel`): the frame
+  is rendered on the MI355X.  A renderer whose world the device cannot express (unknown shape / BRDF /
+  pigment class, non-affine matrix) raises ``UnsupportedSceneError``: a renderer never silently runs
+  anywhere else.
+* any other callable ``Ray -> Color`` (the lambdas of the reference's own ``TestImageTracer``,
+  test_all.py:576-604): there is nothing to put on a GPU, the contract is "call ``func`` once per
+  sample, in the reference's order, and store what it returns".  That per-pixel loop runs on the host
+  in this class (``_host_loop``), drawing the jitter numbers from ``self.pcg`` exactly as
+  imagetracer.py:80-104 does.
+
+Random streams on the device: the reference draws jitter and scattering numbers from two global
+sequential generators in row-major pixel order (imagetracer.py:89-92, render.py:118,128), which is
+inherently serial.  The device uses the per-pixel alignment of SURVEY.md §8c: pixel
+``i = row*W + col`` owns ``PCG(S0, Q0 + i)`` (``pcg_mode="pixel"``) or each sample owns
+``PCG(S0, Q0 + i*S² + k)`` (``"sample"``), where (S0, Q0) are the seeds of ``PathTracer.pcg``
+(or of the tracer's ``pcg`` for the other renderers).  Images are deterministic and independent
+of grid, tile or rank layout.
+
+``callback(col=, row=, **kw)`` is invoked once before rendering and then whenever more than
+``callback_time_s`` have passed since the last call (imagetracer.py:76-78, 106-110), with the last
+pixel traced so far.  On the device a frame is rendered in horizontal bands (a few per frame, halved
+while a band takes longer than half of ``callback_time_s``) so that long frames report progress;
+without a callback the frame is one launch.  The clock is wall time (the reference uses
+``process_time``, which stands still while the host waits for the GPU).
+
+The scene is re-flattened on every call, as the reference re-reads ``World.shapes`` on every call;
+the device copy is reused only when the flattened arrays are bit-identical to the ones uploaded.
 """
 from __future__ import annotations
 
+from time import perf_counter, process_time
 from typing import Optional
 
 import numpy as np
@@ -34,7 +50,8 @@ _PCG_MODES = {"pixel": abi.PCG_PIXEL, "sample": abi.PCG_SAMPLE}
 
 
 class _RayView:
-    """What ``fire_ray`` returns: origin, dir, tmin, tmax, depth (ray.py:29-44) as plain data."""
+    """What ``fire_ray`` returns when the camera is a plain parameter holder: origin, dir, tmin, tmax,
+    depth and ``at`` (ray.py:29-57) as plain data."""
 
     def __init__(self, o, d):
         from .hostmodel import Vec
@@ -64,19 +81,21 @@ class GpuImageTracer:
             raise ValueError(f"pcg_mode must be one of {sorted(_PCG_MODES)}")
         self.pcg_mode = pcg_mode
         self._scene: Optional[DeviceScene] = None
-        self._scene_world = None
         self.last_stats: Optional[abi.Stats] = None
+        self.last_bands = 0
 
-    # -- imagetracer.py:48-58 (host arithmetic only: one ray, for inspection/tests) ----------------
+    # -- imagetracer.py:48-58 ---------------------------------------------------------------------------
     def fire_ray(self, col: int, row: int, u_pixel=0.5, v_pixel=0.5):
-        cam = flatten.flatten_camera(self.camera)
         u = (col + u_pixel) / self.image.width
         v = 1.0 - (row + v_pixel) / self.image.height
+        if callable(getattr(self.camera, "fire_ray", None)):
+            return self.camera.fire_ray(u, v)  # the reference's own camera object: its own Ray
+        cam = flatten.flatten_camera(self.camera)
         m = list(cam.m)
-        if cam.kind == abi.CAMERA_PERSPECTIVE:
+        if cam.kind == abi.CAMERA_PERSPECTIVE:  # camera.py:116-124
             o = (-cam.screen_distance, 0.0, 0.0)
             d = (cam.screen_distance, (1.0 - 2 * u) * cam.aspect_ratio, 2 * v - 1)
-        else:
+        else:  # camera.py:70-78
             o = (-1.0, (1.0 - 2 * u) * cam.aspect_ratio, 2 * v - 1)
             d = (1.0, 0.0, 0.0)
         wo = tuple(o[0] * m[4 * r] + o[1] * m[4 * r + 1] + o[2] * m[4 * r + 2] + m[4 * r + 3] for r in range(3))
@@ -85,23 +104,92 @@ class GpuImageTracer:
 
     # -- imagetracer.py:60-110 ------------------------------------------------------------------------
     def fire_all_rays(self, func, callback=None, callback_time_s: float = 2.0, **callback_kwargs) -> None:
+        if flatten.is_device_renderer(func):
+            self._device_frame(func, callback, callback_time_s, callback_kwargs)
+        elif callable(func):
+            self._host_loop(func, callback, callback_time_s, callback_kwargs)
+        else:
+            raise TypeError(f"func must be a renderer or a callable Ray -> Color, not {type(func).__name__}")
+
+    def _host_loop(self, func, callback, callback_time_s, callback_kwargs) -> None:
+        """imagetracer.py:76-110 for a ``func`` that is not a renderer: the same calls in the same order."""
+        image, S = self.image, int(self.samples_per_side)
+        last_call_time = process_time()
+        if callback:
+            callback(col=0, row=0, **callback_kwargs)
+        for row in range(image.height):
+            for col in range(image.width):
+                if S > 0:
+                    r = g = b = 0.0
+                    cls = Color
+                    for inter_pixel_row in range(S):
+                        for inter_pixel_col in range(S):
+                            u_pixel = (inter_pixel_col + self.pcg.random_float()) / S  # drawn first
+                            v_pixel = (inter_pixel_row + self.pcg.random_float()) / S
+                            c = func(self.fire_ray(col=col, row=row, u_pixel=u_pixel, v_pixel=v_pixel))
+                            cls = type(c)
+                            r, g, b = r + c.r, g + c.g, b + c.b  # Color.__add__ (colors.py:34)
+                    k = 1 / S ** 2
+                    image.set_pixel(col, row, cls(r * k, g * k, b * k))  # Color.__mul__ by a scalar
+                else:
+                    image.set_pixel(col, row, func(self.fire_ray(col=col, row=row)))
+                current_time = process_time()
+                if callback and (current_time - last_call_time > callback_time_s):
+                    callback(col=col, row=row, **callback_kwargs)
+                    last_call_time = current_time
+
+    def _device_scene(self, world) -> DeviceScene:
+        flat = flatten.flatten_world(world)
+        if self._scene is not None and not self._scene.flat.same_bits(flat):
+            self._scene.close()
+            self._scene = None
+        if self._scene is None:
+            self._scene = DeviceScene(flat, self.device)
+        return self._scene
+
+    def _device_frame(self, func, callback, callback_time_s, callback_kwargs) -> None:
+        last_call_time = perf_counter()
         if callback:
             callback(col=0, row=0, **callback_kwargs)
         w, h = int(self.image.width), int(self.image.height)
         params = flatten.renderer_params(func, w, h, samples_per_side=int(self.samples_per_side),
                                          tracer_pcg=self.pcg, pcg_mode=_PCG_MODES[self.pcg_mode])
         cam = flatten.flatten_camera(self.camera)
-        world = func.world
-        if self._scene is None or self._scene_world is not world:
-            if self._scene is not None:
-                self._scene.close()
-            self._scene = DeviceScene(flatten.flatten_world(world), self.device)
-            self._scene_world = world
-        out = self._scene.render(cam, params)  # [H, W, 3] fp64, row 0 = top (hdrimages.py:78-80)
-        self.last_stats = self._scene.stats()
+        scene = self._device_scene(func.world)
+        if not callback or h <= 8:
+            out = scene.render(cam, params)  # [H, W, 3] fp64, row 0 = top (hdrimages.py:78-80)
+            self.last_stats = scene.stats()
+            self.last_bands = 1
+        else:
+            # Bands of 2^k rows starting at multiples of their height (so a band is "block r0/L of L-row
+            # blocks", which the partition fields of pt_params express); per-pixel seeds make the frame
+            # independent of how it is cut.  Four or fewer bands for a frame that renders quickly.
+            out = np.empty((h, w, 3), dtype=np.float64)
+            band = 1
+            while band * 4 < h:
+                band *= 2
+            row0, n_rays, kernel_ms, total_ms, self.last_bands = 0, 0, 0.0, 0.0, 0
+            while row0 < h:
+                while row0 % band:
+                    band //= 2
+                p = abi.copy_params(params, row_block=band, n_ranks=(h + band - 1) // band, rank=row0 // band)
+                t0 = perf_counter()
+                shard = scene.render(cam, p)
+                dt = perf_counter() - t0
+                out[row0:row0 + shard.shape[0]] = shard
+                row0 += shard.shape[0]
+                st = scene.stats()
+                n_rays, kernel_ms, total_ms = n_rays + st.n_rays, kernel_ms + st.kernel_ms, total_ms + st.total_ms
+                self.last_bands += 1
+                now = perf_counter()
+                if row0 < h and now - last_call_time > callback_time_s:
+                    callback(col=w - 1, row=row0 - 1, **callback_kwargs)
+                    last_call_time = now
+                if dt > 0.5 * callback_time_s and band > 1:
+                    band //= 2
+            st.n_rays, st.kernel_ms, st.total_ms, st.n_pixels = n_rays, kernel_ms, total_ms, w * h
+            self.last_stats = st
         _fill_image(self.image, out)
-        if callback:
-            callback(col=w - 1, row=h - 1, **callback_kwargs)
 
     def close(self):
         if self._scene is not None:

@@ -433,6 +433,30 @@ def g5_frames():
                   mode=abi.PCG_PIXEL, s0=45, q0=54)
 
 
+def g5_c4():
+    """BASELINE.json config 4 as specified -- the §8(d) "wide" 256-sphere scene, PathTracer N=1 D=5 rr=3,
+    S=8 (spp 64) -- at a frame the pure-Python reference finishes in minutes, in both per-thread PCG modes."""
+    w4 = ref_synthetic_world(256, wide=True)
+    for mode, tag in ((abi.PCG_PIXEL, "pixel"), (abi.PCG_SAMPLE, "sample")):
+        frame_fixture(f"g5_c4_path_32x18_n1d5_s8_{tag}", w4, ref_synthetic_camera(32, 18),
+                      lambda: PathTracer(w4, pcg=PCG(45, 54), num_of_rays=1, max_depth=5, russian_roulette_limit=3),
+                      32, 18, S=8, mode=mode, s0=45, q0=54)
+
+
+def g5_cli():
+    """What `python -m pytracer render examples/demo.txt` computes with its defaults (main.py:76-129: S=1, so the
+    pixel is jittered; PathTracer N=10 D=3 seeds 45/54), driven into Mode PIXEL: the frames the CLI of this
+    repository must reproduce.  Flat takes its seeds from ImageTracer's default PCG (42, 54)."""
+    with open("/root/reference/examples/demo.txt", "rt") as f:
+        scene = parse_scene(InputStream(f), {})
+    world, cam = scene.world, scene.camera
+    frame_fixture("g5_cli_demo_flat_s1_64x48", world, cam, lambda: FlatRenderer(world), 64, 48, S=1,
+                  mode=abi.PCG_PIXEL, s0=42, q0=54)
+    frame_fixture("g5_cli_demo_path_s1_32x24_n10d3", world, cam,
+                  lambda: PathTracer(world, pcg=PCG(45, 54), num_of_rays=10, max_depth=3), 32, 24, S=1,
+                  mode=abi.PCG_PIXEL, s0=45, q0=54)
+
+
 def g9_furnace():
     """test_all.py:1015-1051: closed diffuse unit sphere, N=1, D=100, rr_limit=101."""
     pcg = PCG()
@@ -488,9 +512,10 @@ def g10_postprocess():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g6", "g8", "g9", "g5", "g10"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g6", "g8", "g9", "g5", "g10", "g5cli", "g5c4"]
     table = {"g1": g1_pcg, "g2": g2_xform, "g3": g3_shapes, "g4": g4_camera, "g6": g6_g7_scatter_onb,
-             "g8": g8_pigments, "g9": g9_furnace, "g5": g5_frames, "g10": g10_postprocess}
+             "g8": g8_pigments, "g9": g9_furnace, "g5": g5_frames, "g10": g10_postprocess, "g5c4": g5_c4,
+             "g5cli": g5_cli}
     for k in which:
         table[k]()
 

@@ -1,11 +1,17 @@
-"""the ``render`` command mirrors pytracer's flags (main.py:76-129)."""
+"""the ``render`` command takes pytracer's flags (main.py:76-129) and produces what
+``python -m pytracer render`` produces -- checked EXACTLY against frames the reference itself computed with the
+CLI's defaults (tests/golden/make_golden.py: g5_cli_*; the CLI always jitters, S = 1)."""
 import os
+import sys
 
 import numpy as np
 import pytest
 from click.testing import CliRunner
 
 from tests import util
+
+REF_SRC = "/root/reference/src"
+REF_DEMO = "/root/reference/examples/demo.txt"
 
 
 def test_cli_options_match_reference():
@@ -22,26 +28,121 @@ def test_cli_options_match_reference():
     assert "input_scene_name" in opts
 
 
-def test_cli_rejects_non_square_samples():
+def test_cli_rejects_bad_values_before_touching_a_gpu():
     from pytracer_amd.cli import cli
 
-    r = CliRunner().invoke(cli, ["render", "--samples-per-pixel", "3", "builtin:demo"])
-    assert "must be a perfect square" in r.output
+    for args, needle in ((["--samples-per-pixel", "3", "builtin:demo"], "perfect square"),
+                         (["-d", "clock", "builtin:demo"], "NAME:VALUE"),
+                         (["-d", "a:b:c", "builtin:demo"], "NAME:VALUE"),
+                         (["-d", "clock:fast", "builtin:demo"], "not a floating-point"),
+                         (["builtin:nosuch"], "no built-in scene"),
+                         (["/nonexistent/scene.txt"], "")):
+        r = CliRunner().invoke(cli, ["render"] + args)
+        assert r.exit_code == 2, (args, r.output)
+        assert needle in r.output
+
+
+def test_float_overrides():
+    from pytracer_amd.cli import UsageError, parse_float_overrides
+
+    assert parse_float_overrides(["clock:150", "x:-2.5e-1"]) == {"clock": 150.0, "x": -0.25}
+    assert parse_float_overrides([]) == {}
+    for bad in ("clock", ":1", "a:1:2", "a:"):
+        with pytest.raises(UsageError):
+            parse_float_overrides([bad])
+
+
+def test_plan_render_builds_the_four_renderers():
+    from pytracer_amd import flatten
+    from pytracer_amd.cli import plan_render
+
+    for algo, kind in (("onoff", "OnOffRenderer"), ("flat", "FlatRenderer"), ("pathtracing", "PathTracer"),
+                       ("pointlight", "PointLightRenderer")):
+        job = plan_render(64, 48, algo, 7, 2, 45, 54, 4, ("clock:10",), "builtin:demo")
+        assert type(job.renderer).__name__ == kind and job.samples_per_side == 2
+        par = flatten.renderer_params(job.renderer, 64, 48, samples_per_side=job.samples_per_side)
+        if algo == "pathtracing":
+            assert (par.num_of_rays, par.max_depth, par.rr_limit, par.path_state, par.path_seq) == (7, 2, 3, 45, 54)
+
+
+@pytest.fixture()
+def reference_importable():
+    """Build container only: pytracer's parser on sys.path for the scene-file branch (removed afterwards)."""
+    if not (os.path.isdir(os.path.join(REF_SRC, "pytracer")) and os.path.exists(REF_DEMO)):
+        pytest.skip("the reference is not present here")
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, REF_SRC)
+    try:
+        yield
+    finally:
+        sys.path.remove(REF_SRC)
+        for name in [m for m in sys.modules if m == "pytracer" or m.startswith("pytracer.")]:
+            del sys.modules[name]
+
+
+def test_scene_file_branch_flattens_to_the_golden_scene(reference_importable):
+    """`render SCENE.txt` up to (not including) the GPU: pytracer's parser reads examples/demo.txt, the renderer is
+    the reference's own class, and flattening gives bit for bit the scene + camera + parameters of the golden
+    fixture the reference rendered (so the frame the device would produce is the one test_cli_* pins)."""
+    from pytracer_amd import abi, flatten
+    from pytracer_amd.cli import plan_render
+
+    job = plan_render(32, 24, "pathtracing", 10, 3, 45, 54, 1, ("clock:150",), REF_DEMO)
+    assert type(job.renderer).__module__.startswith("pytracer.")
+    scene, cam, par, _ = util.load_frame("g5_cli_demo_path_s1_32x24_n10d3")
+    assert flatten.flatten_world(job.world).same_bits(scene)
+    got_cam = flatten.flatten_camera(job.camera)
+    assert bytes(got_cam) == bytes(cam)
+    from pytracer_amd.hostmodel import PCG
+    got_par = flatten.renderer_params(job.renderer, 32, 24, samples_per_side=job.samples_per_side, tracer_pcg=PCG(),
+                                      pcg_mode=abi.PCG_PIXEL)
+    assert bytes(got_par) == bytes(par)
+    # the built-in demo scene is the same data
+    builtin = plan_render(32, 24, "pathtracing", 10, 3, 45, 54, 1, (), "builtin:demo")
+    assert flatten.flatten_world(builtin.world).same_bits(scene)
+    assert bytes(flatten.flatten_camera(builtin.camera)) == bytes(cam)
+    # a -d override reaches the parser
+    other = plan_render(32, 24, "flat", 10, 3, 45, 54, 1, ("clock:10",), REF_DEMO)
+    assert not flatten.flatten_world(other.world).same_bits(scene)
+
+
+def _read_pfm(path, w, h):
+    raw = open(path, "rb").read()
+    head = f"PF\n{w} {h}\n-1.0\n".encode()
+    assert raw.startswith(head)
+    return np.frombuffer(raw[len(head):], dtype="<f4").reshape(h, w, 3)[::-1]
 
 
 @pytest.mark.gpu
-def test_cli_renders_demo(tmp_path):
+@pytest.mark.parametrize("algo,fixture,w,h", [("flat", "g5_cli_demo_flat_s1_64x48", 64, 48),
+                                              ("pathtracing", "g5_cli_demo_path_s1_32x24_n10d3", 32, 24)])
+def test_cli_frame_equals_reference_cli_frame(tmp_path, algo, fixture, w, h):
+    """The PFM the CLI writes == the reference's frame for the same command line, rounded to the PFM's fp32
+    (hdrimages.py:35-43): exactly for Flat (no libm on the path: checkered planes and a uniform mirror), within 1e-5
+    for the path tracer (sin/cos of ocml vs glibc)."""
     from pytracer_amd.cli import cli
 
     pfm, png = str(tmp_path / "o.pfm"), str(tmp_path / "o.png")
-    r = CliRunner().invoke(cli, ["render", "--width", "160", "--height", "120", "--algorithm", "flat",
-                                 "--samples-per-pixel", "1", "--pfm-output", pfm, "--png-output", png,
-                                 "-d", "clock:150", "builtin:demo"])
+    r = CliRunner().invoke(cli, ["render", "--width", str(w), "--height", str(h), "--algorithm", algo,
+                                 "--pfm-output", pfm, "--png-output", png, "-d", "clock:150", "builtin:demo"])
     assert r.exit_code == 0, r.output
-    assert "Using flat renderer" in r.output and os.path.getsize(png) > 100
-    raw = open(pfm, "rb").read()
-    assert raw.startswith(b"PF\n160 120\n-1.0\n")
-    img = np.frombuffer(raw[len(b"PF\n160 120\n-1.0\n"):], dtype="<f4").reshape(120, 160, 3)[::-1]
-    # the CLI always jitters (samples_per_side = 1): compare to the un-jittered golden loosely
-    gold = util.load("g5_demo_flat_160x120")["pixels"]
-    assert np.mean(np.abs(img - gold) < 1e-6) > 0.9
+    assert os.path.getsize(png) > 100
+    img = _read_pfm(pfm, w, h)
+    gold = util.load(fixture)["pixels"]
+    if algo == "flat":
+        assert np.array_equal(img, gold.astype(np.float32))
+    else:
+        err = util.rel_err(img, gold.astype(np.float32))
+        assert err.max() <= 1e-5, f"max rel err {err.max():.3e}"
+
+
+@pytest.mark.gpu
+def test_cli_scene_file_on_the_gpu(tmp_path, reference_importable):
+    """Where both the reference and a GPU exist: the scene-file branch end to end."""
+    from pytracer_amd.cli import cli
+
+    pfm, png = str(tmp_path / "o.pfm"), str(tmp_path / "o.png")
+    r = CliRunner().invoke(cli, ["render", "--width", "64", "--height", "48", "--algorithm", "flat",
+                                 "--pfm-output", pfm, "--png-output", png, REF_DEMO])
+    assert r.exit_code == 0, r.output
+    assert np.array_equal(_read_pfm(pfm, 64, 48), util.load("g5_cli_demo_flat_s1_64x48")["pixels"].astype(np.float32))
