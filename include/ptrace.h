@@ -135,7 +135,8 @@ typedef struct pt_stats {
   uint64_t n_pixels;    /* pixels written by this call                                   */
   double kernel_ms;     /* hipEvent time of the render kernel(s) only                    */
   double total_ms;      /* hipEvent time incl. D2H copy when the call copies             */
-  int32_t vgprs, lds_bytes, grid, block; /* launch geometry of the render kernel        */
+  int32_t vgprs, lds_bytes, grid, block; /* registers per lane / launch geometry of the render kernel
+                                            (of its last launch when a frame takes several)   */
 } pt_stats;
 
 typedef struct pt_scene pt_scene; /* opaque: device-resident scene + workspace */
@@ -153,8 +154,17 @@ size_t pt_output_bytes(const pt_params *p);
  * pixel (col,row) at out[(row*W+col)*3 + k]  (hdrimages.py:78-80). */
 int pt_render(pt_scene *scene, const pt_camera *cam, const pt_params *p, void *out_host,
               size_t out_bytes);
+/* Page-locked host memory for the output of pt_render (optional): with a destination obtained here the
+ * device-to-host copy is a single DMA at link speed; any other host pointer works too, through the HIP
+ * runtime's staging path.  (The reference's image lives in a Python list, hdrimages.py:70; this is the
+ * buffer the binding hands to numpy.)  pt_host_free(NULL) is a no-op. */
+int pt_host_alloc(size_t bytes, void **out);
+int pt_host_free(void *p);
 /* Render into a caller-owned DEVICE buffer on `stream` (a hipStream_t, NULL = the library's own
- * stream); asynchronous when a stream is given. Nothing is copied to the host. */
+ * stream); asynchronous when a stream is given. Nothing is copied to the host.
+ * A scene's workspace is shared by all its launches, which are ordered by running on one stream: a
+ * launch on a different stream than the scene's previous one first waits (on the host) until that
+ * previous stream has drained. */
 int pt_render_device(pt_scene *scene, const pt_camera *cam, const pt_params *p, void *out_dev,
                      size_t out_bytes, void *stream);
 /* Statistics of the last completed pt_render / synchronised pt_render_device on this scene. */

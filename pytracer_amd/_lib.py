@@ -14,7 +14,7 @@ _lib = None
 EXPORTS = ("pt_device_count", "pt_scene_upload", "pt_scene_free", "pt_rows_for_rank", "pt_output_bytes",
            "pt_render", "pt_render_device", "pt_get_stats", "pt_set_count_rays", "pt_sync", "pt_last_error",
            "pt_version", "pt_profile_begin", "pt_profile_end", "pt_set_timing", "pt_image_pack_pfm",
-           "pt_image_average_luminosity", "pt_image_tonemap")
+           "pt_image_average_luminosity", "pt_image_tonemap", "pt_host_alloc", "pt_host_free")
 
 
 class PtraceError(RuntimeError):
@@ -102,6 +102,10 @@ def lib():
         L.pt_image_tonemap.restype = C.c_int
         L.pt_image_tonemap.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double,
                                        C.c_void_p, C.c_int, C.c_void_p]
+        L.pt_host_alloc.restype = C.c_int
+        L.pt_host_alloc.argtypes = [C.c_size_t, P(C.c_void_p)]
+        L.pt_host_free.restype = C.c_int
+        L.pt_host_free.argtypes = [C.c_void_p]
         L.pt_debug_probe.restype = C.c_int
         L.pt_debug_probe.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         _lib = L

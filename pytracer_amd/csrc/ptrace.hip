@@ -78,6 +78,10 @@ struct pt_scene {
   hipStream_t stream = nullptr;
   hipStream_t last_stream = nullptr;  // stream of the most recent launch
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
+  hipEvent_t ev_count = nullptr;  // recorded behind the copy of the ray count into ray_counter_host
+  bool count_pending = false;     // the last launch enqueued that copy: fold_stats waits for ev_count
+  bool launched = false;          // last_stream names a stream this scene has work on
+  int vgprs_last = 0;             // registers per lane of the render kernel launched last
   std::vector<hipEvent_t> prof;  // 2 * capacity events while profiling
   int prof_used = 0;             // pairs recorded
   bool profiling = false;
@@ -188,6 +192,7 @@ extern "C" void pt_scene_free(pt_scene *s) {
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
   if (s->ev2) (void)hipEventDestroy(s->ev2);
+  if (s->ev_count) (void)hipEventDestroy(s->ev_count);
   for (hipEvent_t e : s->prof) (void)hipEventDestroy(e);
   if (s->stream) (void)hipStreamDestroy(s->stream);
   delete s;
@@ -556,6 +561,7 @@ extern "C" int pt_scene_upload(const pt_scene_desc *d, int device, pt_scene **ou
   if ((rc = hip_or_free(hipEventCreate(&s->ev0), "hipEventCreate"))) return rc;
   if ((rc = hip_or_free(hipEventCreate(&s->ev1), "hipEventCreate"))) return rc;
   if ((rc = hip_or_free(hipEventCreate(&s->ev2), "hipEventCreate"))) return rc;
+  if ((rc = hip_or_free(hipEventCreateWithFlags(&s->ev_count, hipEventDisableTiming), "hipEventCreate"))) return rc;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) s->n_cu = prop.multiProcessorCount;
   *out = s;
@@ -605,6 +611,13 @@ static hipError_t path_lds_limit(const void *kernel, size_t bytes) {
   if (bytes <= 64 * 1024) return hipSuccess;
   return hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PT_LDS_BUDGET);
 }
+
+// launch a render kernel proper on `st` and remember which one it was (pt_stats.vgprs)
+#define PT_LAUNCH(KERNEL, GRID, LDS, ...)                                                     \
+  do {                                                                                        \
+    main_fn = (const void *)(KERNEL);                                                         \
+    hipLaunchKernelGGL((KERNEL), dim3(GRID), dim3(PT_BLOCK), LDS, st, __VA_ARGS__);           \
+  } while (0)
 
 static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *out_dev, hipStream_t st) {
   PtKArgs a;
@@ -667,7 +680,15 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
     a.onoff[k] = p->onoff_color[k];
     a.ambient[k] = p->ambient[k];
   }
+  // The scene's workspace (argument block copy, hoisted constants, region/cell tables, frame stack, ray
+  // partials) is shared by all its launches, which are ordered by being on ONE stream.  A launch on another
+  // stream than the previous one first lets that stream drain (host-side wait; a rare event).
+  if (s->launched && s->last_stream != st) {
+    if (hipStreamSynchronize(s->last_stream) != hipSuccess) (void)hipGetLastError();  // (a destroyed stream has nothing in flight)
+  }
   s->last_stream = st;
+  s->launched = true;
+  s->count_pending = false;
   const int rows = pt_rows_for_rank(p);
   a.rows_local = rows;
   a.npass = (s->n_shapes + 63) / 64;
@@ -771,6 +792,8 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
       HIP_TRY(hipMemsetAsync(s->ray_counter, 0, sizeof(unsigned long long), st));
       HIP_TRY(hipMemcpyAsync(s->ray_counter_host, s->ray_counter, sizeof(unsigned long long),
                              hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipEventRecord(s->ev_count, st));
+      s->count_pending = true;
     }
     return PT_OK;
   }
@@ -857,6 +880,7 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
     s->args_valid = true;
     s->args_stream = st;
   }
+  const void *main_fn = nullptr;  // the render kernel proper (the last one launched), for pt_stats.vgprs
   const bool prof = s->timing && s->profiling && (size_t)(2 * s->prof_used + 1) < s->prof.size();
   if (s->timing) HIP_TRY(hipEventRecord(prof ? s->prof[2 * s->prof_used] : s->ev0, st));
   if (tile || path_tiled) {
@@ -876,71 +900,85 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
       HIP_TRY(hipMemsetAsync(s->cell_count, 0, (size_t)ncells * sizeof(int), st));
       hipLaunchKernelGGL(pt_cell_kernel, dim3(ngroups * nchunks), dim3(PT_BLOCK), 0, st, a, nchunks, chunk_len);
       if (p->renderer == PT_RENDERER_ONOFF)
-        hipLaunchKernelGGL((pt_tile_kernel<PT_RENDERER_ONOFF, 4, true>), dim3(tgrid), dim3(PT_BLOCK), lds, st, a, 0);
+        PT_LAUNCH((pt_tile_kernel<PT_RENDERER_ONOFF, 4, true>), tgrid, lds, a, 0);
       else if (p->renderer == PT_RENDERER_FLAT)
-        hipLaunchKernelGGL((pt_tile_kernel<PT_RENDERER_FLAT, 4, true>), dim3(tgrid), dim3(PT_BLOCK), lds, st, a, 0);
+        PT_LAUNCH((pt_tile_kernel<PT_RENDERER_FLAT, 4, true>), tgrid, lds, a, 0);
       else if (p->renderer == PT_RENDERER_POINTLIGHT)
-        hipLaunchKernelGGL((pt_tile_kernel<PT_RENDERER_POINTLIGHT, 3, true>), dim3(tgrid), dim3(PT_BLOCK), lds, st, a, 0);
+        PT_LAUNCH((pt_tile_kernel<PT_RENDERER_POINTLIGHT, 3, true>), tgrid, lds, a, 0);
       else
-        hipLaunchKernelGGL((pt_tile_kernel<PT_RENDERER_PATHTRACER, 4, true>), dim3(tgrid), dim3(PT_BLOCK), lds, st, a, grid);
+        PT_LAUNCH((pt_tile_kernel<PT_RENDERER_PATHTRACER, 4, true>), tgrid, lds, a, grid);
     } else if (ortho) {
       if (p->renderer == PT_RENDERER_ONOFF)
-        hipLaunchKernelGGL((pt_tile_kernel<PT_RENDERER_ONOFF, 4, false, true>), dim3(tgrid), dim3(PT_BLOCK), lds, st, a, 0);
+        PT_LAUNCH((pt_tile_kernel<PT_RENDERER_ONOFF, 4, false, true>), tgrid, lds, a, 0);
       else if (p->renderer == PT_RENDERER_FLAT)
-        hipLaunchKernelGGL((pt_tile_kernel<PT_RENDERER_FLAT, 4, false, true>), dim3(tgrid), dim3(PT_BLOCK), lds, st, a, 0);
+        PT_LAUNCH((pt_tile_kernel<PT_RENDERER_FLAT, 4, false, true>), tgrid, lds, a, 0);
       else if (p->renderer == PT_RENDERER_POINTLIGHT)
-        hipLaunchKernelGGL((pt_tile_kernel<PT_RENDERER_POINTLIGHT, 3, false, true>), dim3(tgrid), dim3(PT_BLOCK), lds, st, a, 0);
+        PT_LAUNCH((pt_tile_kernel<PT_RENDERER_POINTLIGHT, 3, false, true>), tgrid, lds, a, 0);
       else
-        hipLaunchKernelGGL((pt_tile_kernel<PT_RENDERER_PATHTRACER, 4, false, true>), dim3(tgrid), dim3(PT_BLOCK), lds, st, a, grid);
+        PT_LAUNCH((pt_tile_kernel<PT_RENDERER_PATHTRACER, 4, false, true>), tgrid, lds, a, grid);
     } else if (p->renderer == PT_RENDERER_ONOFF)
-      hipLaunchKernelGGL((pt_tile_kernel<PT_RENDERER_ONOFF, 4, false>), dim3(tgrid), dim3(PT_BLOCK), lds, st, a, 0);
+      PT_LAUNCH((pt_tile_kernel<PT_RENDERER_ONOFF, 4, false>), tgrid, lds, a, 0);
     else if (p->renderer == PT_RENDERER_FLAT)
-      hipLaunchKernelGGL((pt_tile_kernel<PT_RENDERER_FLAT, 4, false>), dim3(tgrid), dim3(PT_BLOCK), lds, st, a, 0);
+      PT_LAUNCH((pt_tile_kernel<PT_RENDERER_FLAT, 4, false>), tgrid, lds, a, 0);
     else if (p->renderer == PT_RENDERER_POINTLIGHT)
-      hipLaunchKernelGGL((pt_tile_kernel<PT_RENDERER_POINTLIGHT, 3, false>), dim3(tgrid), dim3(PT_BLOCK), lds, st, a, 0);
+      PT_LAUNCH((pt_tile_kernel<PT_RENDERER_POINTLIGHT, 3, false>), tgrid, lds, a, 0);
     else
-      hipLaunchKernelGGL((pt_tile_kernel<PT_RENDERER_PATHTRACER, 4, false>), dim3(tgrid), dim3(PT_BLOCK), lds, st, a, grid);
+      PT_LAUNCH((pt_tile_kernel<PT_RENDERER_PATHTRACER, 4, false>), tgrid, lds, a, grid);
     if (path_tiled) {
       // second pass: the pixels the first one flagged, fullest regions first
       hipLaunchKernelGGL(pt_region_sort, dim3(1), dim3(1024), 0, st, s->region_keys, nregions, s->region_order, s->queue);
       if (lds_frames) {
         HIP_TRY(path_lds_limit((const void *)pt_path_regions_kernel<true>, lds + frame_lds + diag_lds_bytes));
-        hipLaunchKernelGGL((pt_path_regions_kernel<true>), dim3(grid), dim3(PT_BLOCK), lds + frame_lds + diag_lds_bytes, st, a);
+        PT_LAUNCH((pt_path_regions_kernel<true>), grid, lds + frame_lds + diag_lds_bytes, a);
       } else {
         HIP_TRY(path_lds_limit((const void *)pt_path_regions_kernel<false>, lds + diag_lds_bytes));
-        hipLaunchKernelGGL((pt_path_regions_kernel<false>), dim3(grid), dim3(PT_BLOCK), lds + diag_lds_bytes, st, a);
+        PT_LAUNCH((pt_path_regions_kernel<false>), grid, lds + diag_lds_bytes, a);
       }
     }
   } else
   switch (p->renderer) {
     case PT_RENDERER_ONOFF:
       if (hoist)
-        hipLaunchKernelGGL((pt_simple_kernel<PT_RENDERER_ONOFF, true>), dim3(grid), dim3(PT_BLOCK), 0, st, a);
+        PT_LAUNCH((pt_simple_kernel<PT_RENDERER_ONOFF, true>), grid, 0, a);
       else
-        hipLaunchKernelGGL((pt_simple_kernel<PT_RENDERER_ONOFF, false>), dim3(grid), dim3(PT_BLOCK), 0, st, a);
+        PT_LAUNCH((pt_simple_kernel<PT_RENDERER_ONOFF, false>), grid, 0, a);
       break;
     case PT_RENDERER_FLAT:
       if (hoist)
-        hipLaunchKernelGGL((pt_simple_kernel<PT_RENDERER_FLAT, true>), dim3(grid), dim3(PT_BLOCK), 0, st, a);
+        PT_LAUNCH((pt_simple_kernel<PT_RENDERER_FLAT, true>), grid, 0, a);
       else
-        hipLaunchKernelGGL((pt_simple_kernel<PT_RENDERER_FLAT, false>), dim3(grid), dim3(PT_BLOCK), 0, st, a);
+        PT_LAUNCH((pt_simple_kernel<PT_RENDERER_FLAT, false>), grid, 0, a);
       break;
     case PT_RENDERER_POINTLIGHT:
       if (hoist)
-        hipLaunchKernelGGL((pt_simple_kernel<PT_RENDERER_POINTLIGHT, true>), dim3(grid), dim3(PT_BLOCK), 0, st, a);
+        PT_LAUNCH((pt_simple_kernel<PT_RENDERER_POINTLIGHT, true>), grid, 0, a);
       else
-        hipLaunchKernelGGL((pt_simple_kernel<PT_RENDERER_POINTLIGHT, false>), dim3(grid), dim3(PT_BLOCK), 0, st, a);
+        PT_LAUNCH((pt_simple_kernel<PT_RENDERER_POINTLIGHT, false>), grid, 0, a);
       break;
     default:
       if (lds_frames) {
         HIP_TRY(path_lds_limit((const void *)pt_path_kernel<true>, frame_lds));
-        hipLaunchKernelGGL((pt_path_kernel<true>), dim3(grid), dim3(PT_BLOCK), frame_lds, st, a);
+        PT_LAUNCH((pt_path_kernel<true>), grid, frame_lds, a);
       } else {
-        hipLaunchKernelGGL((pt_path_kernel<false>), dim3(grid), dim3(PT_BLOCK), 0, st, a);
+        PT_LAUNCH((pt_path_kernel<false>), grid, 0, a);
       }
       break;
   }
   HIP_TRY(hipGetLastError());
+  if (main_fn) {
+    // registers per lane of that kernel (hipFuncGetAttributes; looked up once per kernel)
+    static std::vector<std::pair<const void *, int>> known;
+    int regs = -1;
+    for (const auto &kv : known)
+      if (kv.first == main_fn) regs = kv.second;
+    if (regs < 0) {
+      hipFuncAttributes fa;
+      regs = hipFuncGetAttributes(&fa, main_fn) == hipSuccess ? fa.numRegs : 0;
+      (void)hipGetLastError();
+      known.push_back({main_fn, regs});
+    }
+    s->stats.vgprs = regs;
+  }
   if (prof) {
     HIP_TRY(hipEventRecord(s->prof[2 * s->prof_used + 1], st));
     s->prof_used++;
@@ -955,6 +993,9 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
     hipLaunchKernelGGL(pt_sum_counts, dim3(1), dim3(256), 0, st, s->ray_partials, grid + grid_first, s->ray_counter);
     HIP_TRY(hipMemcpyAsync(s->ray_counter_host, s->ray_counter, sizeof(unsigned long long),
                            hipMemcpyDeviceToHost, st));
+    // ev1 was recorded BEFORE the count left the device: whoever reads ray_counter_host waits for this one
+    HIP_TRY(hipEventRecord(s->ev_count, st));
+    s->count_pending = true;
   }
   return PT_OK;
 }
@@ -976,7 +1017,13 @@ static int fold_stats(pt_scene *s) {
   } else {
     s->stats.kernel_ms = s->stats.total_ms = 0.0;
   }
-  s->stats.n_rays = s->count_rays ? *s->ray_counter_host : 0;
+  if (s->count_pending) {
+    HIP_TRY(hipEventSynchronize(s->ev_count));
+    s->count_pending = false;
+    s->stats.n_rays = *s->ray_counter_host;
+  } else {
+    s->stats.n_rays = 0;  // (no pixels, or counting off)
+  }
   s->pending = false;
   s->pending_copy = false;
   return PT_OK;
@@ -1039,6 +1086,29 @@ extern "C" int pt_render(pt_scene *s, const pt_camera *cam, const pt_params *p, 
   }
   HIP_TRY(hipStreamSynchronize(s->stream));
   return fold_stats(s);
+}
+
+// Page-locked host memory for pt_render's output: the D2H copy then is one DMA at link speed into the
+// caller's buffer (a pageable destination goes through the runtime's staging path at roughly 2/3 of it).
+extern "C" int pt_host_alloc(size_t bytes, void **out) {
+  if (!out) return fail(PT_ERR_INVALID, "null output pointer");
+  *out = nullptr;
+  if (bytes == 0) return PT_OK;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(PT_ERR_NODEVICE, "no HIP device visible");
+  hipError_t e = hipHostMalloc(out, bytes, hipHostMallocDefault);
+  if (e != hipSuccess) {
+    *out = nullptr;
+    return fail(e == hipErrorOutOfMemory ? PT_ERR_NOMEM : PT_ERR_HIP, "hipHostMalloc(%zu) failed: %s", bytes,
+                hipGetErrorString(e));
+  }
+  return PT_OK;
+}
+
+extern "C" int pt_host_free(void *p) {
+  if (!p) return PT_OK;
+  HIP_TRY(hipHostFree(p));
+  return PT_OK;
 }
 
 extern "C" int pt_get_stats(pt_scene *s, pt_stats *out) {

@@ -793,3 +793,74 @@ def test_c4_full_size_spp64_row_subset_partition_invariance(dev):
             b = ds.render(cam, pb)
             assert np.array_equal(b[sel], a[rows_b[sel] - 1024]), f"rank {rank}"
     assert n_a >= 128 * W * 64 and np.isfinite(a).all() and float(a.min()) >= 0.0
+
+
+# ---- statistics, streams and host buffers at the C-ABI --------------------------------------------------------------
+def test_stats_follow_the_frame_just_rendered(dev):
+    """pt_render_device(stream=NULL) -> pt_get_stats must report THIS frame's ray count, not the one
+    before (the count leaves the device after the timing event): alternate two workloads and look every time."""
+    import torch
+
+    scene, cam = _synthetic(32, True, False, 320, 180)
+    out = torch.empty((180, 320, 3), dtype=torch.float32, device="cuda")
+    small = abi.make_params(160, 90, abi.RENDERER_FLAT, out_format=abi.OUT_F32)
+    big = abi.make_params(320, 180, abi.RENDERER_FLAT, samples_per_side=2, out_format=abi.OUT_F32)
+    cam_small = _synthetic(32, True, False, 160, 90)[1]
+    with dev.DeviceScene(scene) as ds:
+        for k in range(6):
+            par, c, want = (small, cam_small, 160 * 90) if k % 2 == 0 else (big, cam, 320 * 180 * 4)
+            ds.render_into(c, par, out.data_ptr(), out.numel() * 4, None)
+            st = ds.stats()
+            assert st.n_rays == want and st.n_pixels == par.width * par.height, (k, st.n_rays, want)
+            assert st.vgprs > 0 and st.block == 256 and st.grid > 0 and st.kernel_ms > 0.0
+        # the same on a caller-owned stream: stats() synchronises that stream's frame
+        stream = torch.cuda.Stream()
+        for k in range(4):
+            par, c, want = (small, cam_small, 160 * 90) if k % 2 == 0 else (big, cam, 320 * 180 * 4)
+            ds.render_into(c, par, out.data_ptr(), out.numel() * 4, stream.cuda_stream)
+            assert ds.stats().n_rays == want
+        ds.set_count_rays(False)
+        ds.render_into(cam, big, out.data_ptr(), out.numel() * 4, None)
+        assert ds.stats().n_rays == 0
+        stream.synchronize()
+
+
+def test_launches_on_alternating_streams_share_the_workspace_safely(dev, oracle):
+    """the per-scene workspace (argument block, hoisted constants, region tables, LDS-backed frame
+    stack) is shared by all launches.  Frames launched alternately on two caller streams, with different
+    cameras and parameters, must each equal the frame rendered alone."""
+    import torch
+
+    scene, cam_a = _synthetic(32, False, False, 256, 144)
+    cam_b = _synthetic(32, False, False, 192, 144)[1]  # another aspect ratio: other hoisted cones
+    pa = abi.make_params(256, 144, abi.RENDERER_PATHTRACER, samples_per_side=2, num_of_rays=1, max_depth=3, rr_limit=3,
+                         path_state=45, path_seq=54)
+    pb = abi.make_params(192, 144, abi.RENDERER_PATHTRACER, samples_per_side=3, num_of_rays=2, max_depth=2, rr_limit=2,
+                         path_state=7, path_seq=99)
+    with dev.DeviceScene(scene) as ds:
+        want_a, want_b = ds.render(cam_a, pa).copy(), ds.render(cam_b, pb).copy()
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        outs = []
+        for k in range(6):
+            st, cam, par, shape = (s1, cam_a, pa, (144, 256, 3)) if k % 2 == 0 else (s2, cam_b, pb, (144, 192, 3))
+            o = torch.empty(shape, dtype=torch.float64, device="cuda")
+            ds.render_into(cam, par, o.data_ptr(), o.numel() * 8, st.cuda_stream)
+            outs.append(o)
+        torch.cuda.synchronize()
+        for k, o in enumerate(outs):
+            assert util.bits_equal(o.cpu().numpy(), want_a if k % 2 == 0 else want_b), k
+
+
+def test_pinned_and_pageable_host_outputs_agree(dev):
+    scene, cam = _synthetic(32, True, False, 320, 180)
+    for fmt in (abi.OUT_F64, abi.OUT_F32):
+        par = abi.make_params(320, 180, abi.RENDERER_FLAT, out_format=fmt)
+        with dev.DeviceScene(scene) as ds:
+            a = ds.render(cam, par, pinned=True)
+            b = ds.render(cam, par, pinned=False)
+            assert a.dtype == b.dtype and np.array_equal(a, b)
+            keep = a.copy()
+            del a
+            c = ds.render(cam, par)  # the pool hands the same page-locked buffer out again
+            assert np.array_equal(c, keep)
+
