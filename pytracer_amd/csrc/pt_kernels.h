@@ -78,9 +78,11 @@ struct Hit {
 // ---- PCG-XSH-RR 64/32 (pcg.py:23-62) -----------------------------------------------------------
 struct Pcg {
   uint64_t state, inc;
+  unsigned n;  // draws since the counter was last cleared (only the path tracer's second pass reads it)
 };
 PT_DEV uint32_t pcg_next(Pcg &p) {
   const uint64_t old = p.state;
+  p.n++;
   p.state = old * 6364136223846793005ULL + p.inc;
   const uint32_t xs = (uint32_t)(((old >> 18) ^ old) >> 27);
   const uint32_t rot = (uint32_t)(old >> 59);
@@ -92,6 +94,22 @@ PT_DEV void pcg_seed(Pcg &p, uint64_t init_state, uint64_t init_seq) {
   pcg_next(p);
   p.state += init_state;
   pcg_next(p);
+  p.n = 0;
+}
+// The state `delta` draws further on: state -> state * M^delta + inc * (M^(delta-1) + ... + 1) mod 2^64, by
+// repeated squaring (the generator is a linear congruential one; identical to `delta` calls of pcg_next).
+PT_DEV uint64_t pcg_advance(uint64_t state, uint64_t inc, unsigned delta) {
+  uint64_t acc_mul = 1ULL, acc_add = 0ULL, cur_mul = 6364136223846793005ULL, cur_add = inc;
+  while (delta) {
+    if (delta & 1u) {
+      acc_mul *= cur_mul;
+      acc_add = acc_add * cur_mul + cur_add;
+    }
+    cur_add = (cur_mul + 1ULL) * cur_add;
+    cur_mul *= cur_mul;
+    delta >>= 1;
+  }
+  return acc_mul * state + acc_add;
 }
 // pcg.py:60-62: random() / 0xFFFFFFFF, an fp64 division (inclusive 1.0)
 PT_DEV double pcg_float(Pcg &p) { return (double)pcg_next(p) / 4294967295.0; }
@@ -1117,6 +1135,43 @@ PT_DEV TileCone tile_cone(const PtKArgs &a, int x0, int x1, int grow0, int grow1
   return tile_cone(cone_cam(a), x0, x1, grow0, grow1);
 }
 
+// The cone of ONE pixel's primary rays (perspective camera), computed by every lane for its own pixel
+// (x, global row grow): all jittered rays of the pixel pass through [x, x+1] x [grow, grow+1] of the image
+// plane and directions are affine in the image position, so they lie in the circular cone around the pixel
+// centre's direction whose half-angle is the largest of the four corner angles.  A pixel's cone is ~1e-3 rad
+// wide or less, where 1 - cos is below fp32 resolution: the opening is taken from the SINE, |axis x k| / |k|
+// (relative error ~1e-6), widened by 1e-5 relative + 3e-6 absolute for the fp32 model of the directions
+// (~3e-7 relative, the same model tile_cone uses) and the evaluation; cos t only scales `perp` in cone_keeps
+// and is rounded down.  Apex and error scale come from the tile's cone.
+PT_DEV TileCone pixel_cone(const ConeCam &k, const TileCone &tile, int x, int grow) {
+  TileCone pc = tile;
+  const float fx0 = (float)x, fx1 = (float)(x + 1), fy0 = (float)grow, fy1 = (float)(grow + 1);
+  const float xm = 0.5f * (fx0 + fx1), ym = 0.5f * (fy0 + fy1);
+  const float cx = k.d0[0] + xm * k.dx[0] + ym * k.dy[0], cy = k.d0[1] + xm * k.dx[1] + ym * k.dy[1],
+              cz = k.d0[2] + xm * k.dx[2] + ym * k.dy[2];
+  const float rc = __frsqrt_rn(cx * cx + cy * cy + cz * cz);
+  pc.ax = cx * rc;
+  pc.ay = cy * rc;
+  pc.az = cz * rc;
+  float sn = 0.0f, cs = 1.0f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float xk = (q & 1) ? fx1 : fx0, yk = (q & 2) ? fy1 : fy0;
+    const float kx = k.d0[0] + xk * k.dx[0] + yk * k.dy[0], ky = k.d0[1] + xk * k.dx[1] + yk * k.dy[1],
+                kz = k.d0[2] + xk * k.dx[2] + yk * k.dy[2];
+    const float rk = __frsqrt_rn(kx * kx + ky * ky + kz * kz);
+    const float wx = pc.ay * kz - pc.az * ky, wy = pc.az * kx - pc.ax * kz, wz = pc.ax * ky - pc.ay * kx;
+    sn = fmaxf(sn, __fsqrt_rn(wx * wx + wy * wy + wz * wz) * rk);
+    cs = fminf(cs, (pc.ax * kx + pc.ay * ky + pc.az * kz) * rk);
+  }
+  pc.cos_t = cs - 4e-6f;
+  pc.sin_t = sn * (1.0f + 1e-5f) + 3e-6f;
+  pc.rbeam = 0.0f;
+  pc.ortho = false;
+  pc.all = tile.all || !(pc.cos_t > 0.05f) || !(pc.sin_t < 0.5f);  // also NaN
+  return pc;
+}
+
 // may the bounding sphere touch the cone?  (conservative: true when in doubt)
 // In the half-plane (d, perp) = (distance along the axis, distance from the axis) the solid cone lies
 // on the side q <= 0 of the line through the apex with direction (cos t, sin t), where
@@ -1373,13 +1428,14 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_cell_kernel(const PtKArgs a, int 
 // hoisted (HOISTED = false queries), no dome shortcut.
 template <int RENDERER, int WAVES, bool HIER, bool ORTHO = false>
 __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) void pt_tile_kernel(const PtKArgs a, int count_base) {
-  int S, W, rows_local, npass;
+  int S, W, rows_local, npass, dome_slot;
   {
     pt_kargs c = cold_args(a);
     S = c->S;
     W = c->W;
     rows_local = c->rows_local;
     npass = c->npass;
+    dome_slot = c->dome_slot;  // -1: the camera is inside no sphere with uniform pigments
   }
   const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
   const int mbase = wib * npass;  // this wave's slice of pt_lds_masks
@@ -1416,6 +1472,7 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
     int tpass = npass;
     const unsigned int *list = nullptr;
     int nsurv = 0, only = 0;  // survivors of this tile; the slot of the last one (wave-uniform)
+    bool dome_here = false;   // PATHTRACER: the frame's dome candidate (a.dome_slot) is among them
     if (HIER) {
       // the tile's 8 rows are consecutive global rows starting at a multiple of 8 (the host checks
       // row_block % 8 == 0), so they lie in one cell row
@@ -1442,6 +1499,7 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
         if (lane == 0) pt_lds_masks[mbase + p] = m;
         nsurv += __popcll(m);
         if (m) only = (int)list[p * 64 + (__ffsll((long long)m) - 1)];
+        if (RENDERER == PT_RENDERER_PATHTRACER && __ballot(keep && slot == dome_slot)) dome_here = true;
       }
     } else {
       for (int p = 0; p < npass; ++p) {
@@ -1459,6 +1517,7 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
         if (lane == 0) pt_lds_masks[mbase + p] = m;
         nsurv += __popcll(m);
         if (m) only = p * 64 + (__ffsll((long long)m) - 1);
+        if (RENDERER == PT_RENDERER_PATHTRACER && p == (dome_slot >> 6) && ((m >> (dome_slot & 63)) & 1ULL)) dome_here = true;
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1558,6 +1617,78 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
           __builtin_amdgcn_wave_barrier();  // the next tile overwrites this wave's mask slice
           continue;
         }
+      }
+    }
+
+    // ---- path tracer, a dome among several survivors: the first pass only CLASSIFIES ----
+    // The dome (same conditions as above, for this tile) is hit by every primary ray of the tile; a pixel
+    // whose own cone misses the bounding spheres of all the other survivors can hit nothing else, so all
+    // its samples end on the dome at depth 0 (black BRDF pigment, no Russian roulette at depth 0): its value
+    // is the same replayed sum, no ray needed.  Every other pixel of the tile is left to the second pass,
+    // untraced: there a pixel's samples are spread over lanes, here they would be walked one by one by a
+    // wave that 60 finished lanes wait for.  (Planes carry no bounding sphere: a pixel of a tile some plane
+    // survived in is always left over.)
+    if (RENDERER == PT_RENDERER_PATHTRACER && !ORTHO && dome_here && nsurv > 1) {
+      pt_kargs ca = cold_args(a);
+      const PtShapeAux *ax = ca->aux + dome_slot;
+      const float fro2 = (float)PT_KD(&a.recs[dome_slot])[13];  // PtShapeRec::fro2
+      const double hc_ = (dome_slot < a.n_diag) ? PT_KD(&a.hoist_diag[dome_slot])[6] : PT_KD(&a.hoist[dome_slot])[3];
+      const V3 hc = brdf_pigment(a, ax, 0.0, 0.0), em = emitted_pigment(a, ax, 0.0, 0.0);
+      const double lum = max2(max2(hc.x, hc.y), hc.z);
+      if (hc_ < -0.5 && fro2 * tc.dmax2 < 1e6f && tc.dmin > 1e-6f && !tc.all && ax->needs_uv == 0 && ca->rr > 0 && !(lum > 0.0)) {
+        const TileCone pc = pixel_cone(cone_cam(a), tc, pcol, grow);
+        bool hitable = pc.all;
+        for (int p = 0; p < tpass; ++p) {
+          const unsigned long long mv = pt_lds_masks[mbase + p];
+          const unsigned m_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(mv >> 32));
+          const unsigned m_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)mv);
+          unsigned long long mask = ((unsigned long long)m_hi << 32) | (unsigned long long)m_lo;
+          while (mask) {
+            const int idx = p * 64 + (__ffsll((long long)mask) - 1);
+            mask &= mask - 1;
+            const int slot = HIER ? PT_KI(list)[idx] : idx;
+            if (slot == dome_slot) continue;
+            if (slot >= a.n_spheres) {
+              hitable = true;
+            } else {
+              typedef const __attribute__((address_space(4))) float *pt_kfloat;
+              pt_kfloat bp = (pt_kfloat)(const void *)(a.bounds + slot);  // (wave-uniform slot: scalar loads)
+              const float4 b = {bp[0], bp[1], bp[2], bp[3]};
+              hitable = hitable || cone_keeps(pc, b);
+            }
+          }
+        }
+        const double invN = 1.0 / (double)ca->N;
+        V3 c;  // render.py:139 with cum_radiance = 0
+        c.x = em.x + 0.0 * invN;
+        c.y = em.y + 0.0 * invN;
+        c.z = em.z + 0.0 * invN;
+        V3 cum = c;
+        if (S > 0) {  // imagetracer.py:83-101: the same additions, the same final scaling
+          cum.x = 0.0;
+          cum.y = 0.0;
+          cum.z = 0.0;
+          for (int s = 0; s < nsamp; ++s) {
+            cum.x = cum.x + c.x;
+            cum.y = cum.y + c.y;
+            cum.z = cum.z + c.z;
+          }
+          const double k = 1.0 / (double)(S * S);
+          cum.x = cum.x * k;
+          cum.y = cum.y * k;
+          cum.z = cum.z * k;
+        }
+        if (active && !hitable) {
+          store_pixel(a, pix, cum);
+          nrays += (unsigned long long)nsamp;
+        }
+        const unsigned long long todo = __ballot(active && hitable);
+        if (lane == 0) {
+          ca->region_mask[tile] = todo;
+          ca->region_keys[tile] = (unsigned char)__popcll(todo);
+        }
+        __builtin_amdgcn_wave_barrier();  // the next tile overwrites this wave's mask slice
+        continue;
       }
     }
 
@@ -1675,38 +1806,92 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
   add_ray_count(a, nrays, count_base);
 }
 
-// ---- region ordering for the path tracer -------------------------------------------------------------
-// The first pass (pt_tile_kernel<PATHTRACER>) leaves, per 8x8 region, the mask of the pixels that need
-// real path tracing and their number as a key.  The frame time is set by the longest per-wave chain,
-// so the fullest regions start first: a counting sort (descending) of the keys; regions with key 0
-// sort last and are never visited (order[n] = number of regions with work).  The order only changes
-// WHEN a region is rendered, never its pixels.
-// one workgroup: histogram (256 bins) -> descending offsets -> scatter
-__global__ void pt_region_sort(const unsigned char *keys, int n, int *order, unsigned long long *queue) {
-  __shared__ int hist[256];
-  __shared__ int offs[256];
-  if (threadIdx.x == 0) queue[0] = 0ULL;  // the second pass's region queue starts empty
-  for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
+// ---- work units for the path tracer's second pass ---------------------------------------------------------
+// The first pass (pt_tile_kernel<PATHTRACER>) leaves, per 8x8 region, the mask of the pixels that need real
+// path tracing and their number as a key.  The second pass works in UNITS: a unit is up to `ppu` flagged
+// pixels of one region, rendered by one wave whose 64 lanes are shared out L = min(S*S, 64 / pixels) to a
+// pixel -- the lanes of a pixel trace different samples of it at the same time (path_trace).  ppu is chosen
+// from the frame's total F of flagged pixels: with few of them (a rank's share of a frame, a sparse frame) a
+// region is cut into several units so that the whole chip works on samples in parallel instead of a few
+// waves walking their pixels' S*S samples one after the other; with many, ppu = 64 (a unit = a region) and
+// nothing is spent on idle lanes.  Units with the most pixels start first (counting sort by size, descending):
+// they have the fewest lanes per pixel, hence the longest chains.  Regions without flagged pixels yield
+// nothing.  The order only changes WHEN a pixel is rendered, never its value.
+// one workgroup: F -> ppu -> histogram of unit sizes -> descending offsets -> scatter
+// queue[0] = queue head (reset), queue[9] = number of units, queue[10] = ppu (for the statistics)
+__global__ void pt_unit_sort(const unsigned char *keys, int n, int2 *units, int units_cap, unsigned long long *queue,
+                             long long lanes_cap, int nsamp) {
+  __shared__ int hist[65];
+  __shared__ int offs[65];
+  __shared__ unsigned long long total;
+  __shared__ int ppu_s;
+  if (threadIdx.x == 0) {
+    queue[0] = 0ULL;
+    total = 0ULL;
+  }
+  for (int i = threadIdx.x; i < 65; i += blockDim.x) hist[i] = 0;
   __syncthreads();
-  // (regions with key 0 -- usually most of the frame -- are never visited and get no place at all)
+  unsigned long long mine = 0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) mine += keys[i];
+  for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off, 64);
+  if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&total, mine);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    // lanes per pixel every unit gets at least: the largest power of two (<= S*S, <= 64) at which all flagged
+    // pixels together still fit the lanes the launch keeps resident
+    int lg = 1;
+    while (lg * 2 <= 64 && lg * 2 <= nsamp && (long long)total * (lg * 2) <= lanes_cap) lg *= 2;
+    ppu_s = 64 / lg;
+  }
+  __syncthreads();
+  const int ppu = ppu_s;
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     const int k = keys[i];
-    if (k) atomicAdd(&hist[k], 1);
+    if (k) {
+      const int full = k / ppu, rem = k - full * ppu;
+      if (full) atomicAdd(&hist[ppu], full);
+      if (rem) atomicAdd(&hist[rem], 1);
+    }
   }
   __syncthreads();
   if (threadIdx.x == 0) {
     int run = 0;
-    for (int k = 255; k >= 1; --k) {
+    for (int k = 64; k >= 1; --k) {
       offs[k] = run;
       run += hist[k];
     }
-    order[n] = run;
+    queue[9] = (unsigned long long)(run < units_cap ? run : units_cap);
+    queue[10] = (unsigned long long)ppu;
   }
   __syncthreads();
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     const int k = keys[i];
-    if (k) order[atomicAdd(&offs[k], 1)] = i;
+    if (!k) continue;
+    const int full = k / ppu, rem = k - full * ppu;
+    if (full) {
+      const int at = atomicAdd(&offs[ppu], full);
+      for (int g = 0; g < full; ++g)
+        if (at + g < units_cap) units[at + g] = make_int2(i, (g * ppu) | (ppu << 8));  // (region, first | count << 8)
+    }
+    if (rem) {
+      const int at = atomicAdd(&offs[rem], 1);
+      if (at < units_cap) units[at] = make_int2(i, (full * ppu) | (rem << 8));
+    }
   }
+}
+
+// position of the n-th (0-based) set bit of m (which has more than n bits set)
+PT_DEV int nth_set_bit(unsigned long long m, int n) {
+  int pos = 0;
+#pragma unroll
+  for (int w = 32; w >= 1; w >>= 1) {
+    const int c = __popcll((m >> pos) & ((1ULL << w) - 1ULL));
+    if (n >= c) {
+      pos += w;
+      n -= c;
+    }
+  }
+  return pos & 63;
 }
 
 #ifdef PT_DEBUG_TIME
@@ -1770,20 +1955,37 @@ PT_DEV long long next_pixel(const PtKArgs &a, bool need, long long npix) {
 //   P  lanes starting a sample (mode 0): jitter draws, primary ray, query against the survivors.
 //   S  lanes holding a scattered ray (mode 1): query against ALL shapes.
 // Both kinds then share one shade + unwind block (deliver radiance up the frame stack, scatter the
-// next child) which leaves each lane with a ray to query (mode 1), a finished sample (mode 0) or a
+// next child) which leaves each lane with a ray to query (mode 1), a finished sample (mode 0 / 3) or a
 // finished pixel (mode 2).  S queries are batched until >= 16 lanes wait, so the 32..10k-shape loop
 // does not run for one or two lanes at a time; regions of pure background never run it.
 //
-// TILED (perspective camera): a wave works through PT_REGION^2-pixel regions; its lanes take the region's
-// pixels dynamically (wave-local counter) and P-steps use the hoisted, culled tile query against the
-// region's survivor masks.  !TILED (orthogonal camera): pixels come from one global queue and P-steps
-// run the full shape loop.
-// LAT: the second pass of the two-pass scheme runs at most a wave or two per SIMD and its time is the
-// longest chain of dependent steps of one pixel: everything inline, registers no object.
+// !TILED (orthogonal camera): 1 lane = 1 pixel, pixels come from one global queue, a lane walks its pixel's
+// samples one after the other and P-steps run the full shape loop.
+//
+// TILED (perspective camera, second pass): a wave works through UNITS (pt_unit_sort): up to 64 flagged pixels
+// of one 8x8 region.  The unit's P-steps use the hoisted, culled tile query against the region's survivor
+// masks.  The wave's lanes are shared out L = min(S*S, 64 / pixels) to a pixel, and the L lanes of a pixel
+// trace L consecutive samples of it AT THE SAME TIME (a "round"):
+//   PT_PCG_SAMPLE  every sample owns its generator: the L samples are independent, all of them count.
+//   PT_PCG_PIXEL   the samples of a pixel share ONE generator, consumed in program order: where sample k+1
+//     starts in the stream depends on how many numbers sample k drew, which is only known once its path has
+//     ended.  Lane j therefore SPECULATES: it assumes that each of the j samples before it draws `cpred`
+//     numbers (what the last validated sample of this pixel drew) and starts from the state j * cpred draws
+//     ahead (pcg_advance).  After the round the samples are validated in order: sample j counts if and only
+//     if the state it started from IS the state sample j-1 ended with -- then everything it computed is what
+//     the sequential program computes -- and the first one that started elsewhere is thrown away together
+//     with everything behind it and repeated in the next round, now from the right state.  The first lane
+//     always starts from the validated state, so every round completes at least one sample.
+// A round's radiances are added to the pixel's sum in sample order (imagetracer.py:97: cum_color += ...), one
+// lane after the other through wave shuffles, so the sum is the sequential one bit for bit; rays are counted
+// for validated samples only.  Per-pixel / per-sample seeds depend on the global pixel index alone: the image
+// does not depend on how regions are cut into units or how many lanes a pixel gets.
+// LAT: the second pass is built for few waves per SIMD; its time is set by chains of dependent steps:
+// everything inline, registers no object.
 template <bool TILED, bool LDSF, bool LAT>
 PT_DEV void path_trace(const PtKArgs &a) {
   PathCtx w;
-  int S, nsamp, N, W = 0, rows_local = 0, npass = 0, D = 0, rr = 0, diag_lds = -1;
+  int S, nsamp, N, W = 0, rows_local = 0, npass = 0, D = 0, rr = 0, diag_lds = -1, pcg_mode = PT_PCG_PIXEL;
   bool ortho = false;
   {
     pt_kargs c = cold_args(a);
@@ -1795,6 +1997,7 @@ PT_DEV void path_trace(const PtKArgs &a) {
     w.lds_base = TILED ? 4 * c->npass : 0;  // behind the four waves' survivor masks (8-byte units)
     ortho = c->cam_kind != PT_CAMERA_PERSPECTIVE;
     diag_lds = c->diag_lds;
+    pcg_mode = c->pcg_mode;
     S = c->S;
     N = c->N;
     W = c->W;
@@ -1814,17 +2017,18 @@ PT_DEV void path_trace(const PtKArgs &a) {
   const int lane = threadIdx.x & 63;
   const int mbase = (threadIdx.x >> 6) * npass;
   const int regions_x = (W + PT_REGION - 1) / PT_REGION;
-  const int nregions = regions_x * ((rows_local + PT_REGION - 1) / PT_REGION);
   bool exhausted = false;           // !TILED: the global queue is empty
-  bool first_region = true;         // TILED (wave-uniform)
+  bool first_unit = true;           // TILED (wave-uniform)
   unsigned long long nrays = 0;
 
-  // lane state.  mode 0: starts a sample at the next P-step; 1: inside a path (S-steps); 2: no pixel
+  // lane state.  mode 0: starts a sample at the next P-step; 1: inside a path (S-steps); 2: nothing to do;
+  // 3 (TILED): sample finished, waits for the end of the round
   int mode = 2;
   long long pix = -1;
   Pcg pcg;
   pcg.state = 0;
   pcg.inc = 1;
+  pcg.n = 0;
   int samp = 0, sp = 0, col = 0, grow = 0;
   V3 cum = {0.0, 0.0, 0.0};
   Ray ray;
@@ -1836,16 +2040,28 @@ PT_DEV void path_trace(const PtKArgs &a) {
   bool spawn = false;
   V3 f_wp = {0.0, 0.0, 0.0}, f_n = {0.0, 0.0, 1.0}, f_in = {1.0, 0.0, 0.0};
   int f_brdf = 0;
+  // TILED: the unit (wave-uniform) and this lane's place in it
+  int L = 1;                        // lanes per pixel
+  int leader = lane, jlane = 0;     // first lane of this lane's pixel; this lane's sample slot in a round
+  bool in_unit = false;             // the lane belongs to a pixel of the unit
+  int vbase = 0;                    // samples of the pixel validated so far (same in all lanes of the pixel)
+  uint64_t vstate = 0;              // PT_PCG_PIXEL: generator state behind the last validated sample
+  unsigned cpred = 0;               // PT_PCG_PIXEL: draws per sample the next round assumes
+  uint64_t st_start = 0;            // state this lane's sample started from
+  unsigned srays = 0, prays = 0;    // rays of the current sample; of the pixel's validated samples
+  unsigned long long gpix = 0;      // global pixel index (seeds)
 
   // pixel coordinates + seeds + the sample's primary ray (imagetracer.py:86-97)
   auto start_sample = [&]() {
     pt_kargs c = cold_args(a);
-    if (samp == 0) {
-      pixel_coords(a, pix, col, grow);
-      if (c->pcg_mode == PT_PCG_PIXEL) pcg_seed(pcg, c->s0, c->q0 + ((unsigned long long)grow * c->W + col));
+    if (!TILED) {
+      if (samp == 0) {
+        pixel_coords(a, pix, col, grow);
+        if (c->pcg_mode == PT_PCG_PIXEL) pcg_seed(pcg, c->s0, c->q0 + ((unsigned long long)grow * c->W + col));
+      }
+      if (c->pcg_mode == PT_PCG_SAMPLE)
+        pcg_seed(pcg, c->s0, c->q0 + ((unsigned long long)grow * c->W + col) * (unsigned)nsamp + (unsigned)samp);
     }
-    if (c->pcg_mode == PT_PCG_SAMPLE)
-      pcg_seed(pcg, c->s0, c->q0 + ((unsigned long long)grow * c->W + col) * (unsigned)nsamp + (unsigned)samp);
     double up = 0.5, vp = 0.5;
     if (S > 0) {
       const int sr = samp / S, sc = samp - sr * S;
@@ -1853,6 +2069,18 @@ PT_DEV void path_trace(const PtKArgs &a) {
       vp = ((double)sr + pcg_float(pcg)) / (double)S;
     }
     ray = primary_ray(a, col, grow, up, vp);
+  };
+
+  // TILED: the generator a lane's next sample starts from, `samp` = vbase + jlane
+  auto seed_round = [&]() {
+    pt_kargs c = cold_args(a);
+    if (pcg_mode == PT_PCG_SAMPLE)
+      pcg_seed(pcg, c->s0, c->q0 + gpix * (unsigned)nsamp + (unsigned)samp);
+    else
+      pcg.state = pcg_advance(vstate, pcg.inc, (unsigned)jlane * cpred);
+    pcg.n = 0;
+    st_start = pcg.state;
+    srays = 0;
   };
 
   // render.py:103-139 up to (not including) the recursion: sets `ret`, or pushes frame `sp` and asks
@@ -1962,6 +2190,10 @@ PT_DEV void path_trace(const PtKArgs &a) {
 
   // the primary call returned `ret`: one sample done (imagetracer.py:94-104)
   auto finish_sample = [&]() {
+    if (TILED) {  // the radiance stays in `ret` until the round is validated
+      mode = 3;
+      return;
+    }
     if (S > 0) {
       cum.x = cum.x + ret.x;
       cum.y = cum.y + ret.y;
@@ -1987,7 +2219,7 @@ PT_DEV void path_trace(const PtKArgs &a) {
   };
 
 #ifdef PT_DEBUG_TIME
-  // section sums for every wave, plus a step-by-step trace of the wave that drew the first (fullest) region
+  // section sums for every wave, plus a step-by-step trace of the wave that drew the first (fullest) unit
   unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
   bool tracing = false;
   int trace_n = 0;
@@ -2006,46 +2238,145 @@ PT_DEV void path_trace(const PtKArgs &a) {
 #endif
   for (;;) {
     PT_STAMP(7);
-    // ---- pixels for idle lanes ----
+    // ---- work for idle lanes ----
     if (TILED) {
-      if (!__any(mode != 2)) {
-        // next region for this wave, then the region's cone and survivor masks.  The first one is the
-        // wave's own index (thousands of waves start together: one atomic each on the queue head would
-        // serialise them); later ones come from the queue, one atomic by lane 0.
-        unsigned rid = 0;
-        if (first_region) {
-          rid = blockIdx.x * (PT_BLOCK / 64) + (threadIdx.x >> 6);
-          first_region = false;
-        } else {
-          if (lane == 0) rid = gridDim.x * (PT_BLOCK / 64) + (unsigned)atomicAdd(cold_args(a)->queue, 1ULL);
-        }
-        const int seq = (int)__builtin_amdgcn_readfirstlane((int)rid);
+      if (!__any(mode == 0 || mode == 1)) {
+        if (__any(mode == 3)) {
+          // ---- end of a round: validate the pixel's samples in order, add them up in order ----
+          // (every lane of a pixel runs the same loop over the pixel's L lanes and ends with the same
+          //  vbase / vstate / cpred; only the values in the leader are used for the pixel's result)
+          const bool fin = mode == 3;
+          bool chain = true;
 #ifdef PT_DEBUG_TIME
-        tracing = seq == 0;
+          const int dbg_vbase0 = vbase;
+          int dbg_fin = 0;
 #endif
-        const int *order = cold_args(a)->region_order;  // fullest regions first (pt_region_sort)
-        if (seq >= order[nregions]) break;
-        const int region = order[seq];
-        const unsigned long long todo = cold_args(a)->region_mask[region];  // left over by the first pass
-        const int ry = region / regions_x, rx = region - ry * regions_x;
-        const int gr0 = global_row(a, ry * PT_REGION);
-        const int gr1 = global_row(a, (ry * PT_REGION + PT_REGION - 1 < rows_local) ? ry * PT_REGION + PT_REGION - 1 : rows_local - 1);
-        const TileCone tc = tile_cone(a, rx * PT_REGION, (rx * PT_REGION + PT_REGION < W) ? rx * PT_REGION + PT_REGION : W, gr0, gr1);
-        __builtin_amdgcn_wave_barrier();
-        for (int p = 0; p < npass; ++p) {
-          const int slot = p * 64 + lane;
-          bool keep = false;
-          if (slot < a.n_shapes) keep = slot >= a.n_spheres || cone_keeps(tc, a.bounds[slot]);  // planes: always
-          const unsigned long long m = __ballot(keep);
-          if (lane == 0) pt_lds_masks[mbase + p] = m;
+          for (int jj = 0; jj < L; ++jj) {
+            const int src = (leader + jj) & 63;
+            const uint64_t s_from = __shfl((unsigned long long)st_start, src, 64);
+            const uint64_t s_to = __shfl((unsigned long long)pcg.state, src, 64);
+            const int s_fin = __shfl((int)fin, src, 64);
+            const unsigned s_draws = (unsigned)__shfl((int)pcg.n, src, 64);
+            const unsigned s_rays = (unsigned)__shfl((int)srays, src, 64);
+            const double rx_ = __shfl(ret.x, src, 64), ry_ = __shfl(ret.y, src, 64), rz_ = __shfl(ret.z, src, 64);
+            chain = chain && s_fin != 0 && (pcg_mode == PT_PCG_SAMPLE || s_from == vstate);
+#ifdef PT_DEBUG_TIME
+            dbg_fin += s_fin;
+#endif
+            if (chain) {
+              if (S > 0) {  // imagetracer.py:97
+                cum.x = cum.x + rx_;
+                cum.y = cum.y + ry_;
+                cum.z = cum.z + rz_;
+              } else {
+                cum.x = rx_;
+                cum.y = ry_;
+                cum.z = rz_;
+              }
+              vstate = s_to;
+              cpred = s_draws;
+              prays += s_rays;
+              vbase++;
+            }
+          }
+          mode = 2;
+#ifdef PT_DEBUG_TIME
+          if (in_unit && lane == leader && pix >= 0) {  // speculation statistics: pixel-rounds, samples traced, samples kept
+            atomicAdd(&pt_dbg[4], 1ULL);
+            atomicAdd(&pt_dbg[5], (unsigned long long)dbg_fin);
+            atomicAdd(&pt_dbg[6], (unsigned long long)(vbase - dbg_vbase0));
+          }
+#endif
+          if (in_unit) {
+            if (vbase >= nsamp) {
+              if (lane == leader && pix >= 0) {  // imagetracer.py:99-104
+                if (S > 0) {
+                  const double k = 1.0 / (double)(S * S);
+                  cum.x = cum.x * k;
+                  cum.y = cum.y * k;
+                  cum.z = cum.z * k;
+                }
+                store_pixel(a, pix, cum);
+                nrays += prays;
+              }
+              pix = -1;  // this pixel is done (in every lane of it)
+            } else {
+              samp = vbase + jlane;
+              if (samp < nsamp) {
+                seed_round();
+                mode = 0;
+              }
+            }
+          }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // every lane is idle here: lane l takes pixel l of the region (the first pass's layout)
-        if ((todo >> lane) & 1ULL) {
-          pix = (long long)(ry * PT_REGION + (lane >> 3)) * W + (rx * PT_REGION + (lane & 7));
-          mode = 0;
+        if (!__any(mode == 0)) {
+          // next unit for this wave, then its region's cone and survivor masks.  The first one is the
+          // wave's own index (thousands of waves start together: one atomic each on the queue head would
+          // serialise them); later ones come from the queue, one atomic by lane 0.
+          unsigned uid = 0;
+          if (first_unit) {
+            uid = blockIdx.x * (PT_BLOCK / 64) + (threadIdx.x >> 6);
+            first_unit = false;
+          } else {
+            if (lane == 0) uid = gridDim.x * (PT_BLOCK / 64) + (unsigned)atomicAdd(cold_args(a)->queue, 1ULL);
+          }
+          const int seq = (int)__builtin_amdgcn_readfirstlane((int)uid);
+#ifdef PT_DEBUG_TIME
+          tracing = seq == 0;
+#endif
+          pt_kargs ca = cold_args(a);
+          if (seq >= (int)ca->queue[9]) break;  // (written by pt_unit_sort, before this kernel started)
+#ifdef PT_DEBUG_TIME
+          if (lane == 0) atomicAdd(&pt_dbg[7], 1ULL);
+#endif
+          const int2 unit = ca->units[seq];
+          const int region = unit.x, first = unit.y & 0xff, count = (unit.y >> 8) & 0xff;
+          const unsigned long long todo = ca->region_mask[region];  // left over by the first pass
+          const int ry = region / regions_x, rx = region - ry * regions_x;
+          const int gr0 = global_row(a, ry * PT_REGION);
+          const int gr1 = global_row(a, (ry * PT_REGION + PT_REGION - 1 < rows_local) ? ry * PT_REGION + PT_REGION - 1 : rows_local - 1);
+          const TileCone tc = tile_cone(a, rx * PT_REGION, (rx * PT_REGION + PT_REGION < W) ? rx * PT_REGION + PT_REGION : W, gr0, gr1);
+          __builtin_amdgcn_wave_barrier();
+          for (int p = 0; p < npass; ++p) {
+            const int slot = p * 64 + lane;
+            bool keep = false;
+            if (slot < a.n_shapes) keep = slot >= a.n_spheres || cone_keeps(tc, a.bounds[slot]);  // planes: always
+            const unsigned long long m = __ballot(keep);
+            if (lane == 0) pt_lds_masks[mbase + p] = m;
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          // lanes [p * L, (p + 1) * L) take the unit's p-th pixel = flagged pixel `first + p` of the region
+          L = 64 / count;
+          if (L > nsamp) L = nsamp;
+          const int pidx = lane / L;
+          in_unit = pidx < count;
+          leader = in_unit ? pidx * L : lane;
+          jlane = lane - leader;
+          mode = 2;
+          pix = -1;
+          if (in_unit) {
+            const int bit = nth_set_bit(todo, first + pidx);
+            pix = (long long)(ry * PT_REGION + (bit >> 3)) * W + (rx * PT_REGION + (bit & 7));
+            pixel_coords(a, pix, col, grow);
+            gpix = (unsigned long long)grow * ca->W + col;
+            if (pcg_mode != PT_PCG_SAMPLE) {
+              pcg_seed(pcg, ca->s0, ca->q0 + gpix);
+              vstate = pcg.state;
+            }
+            cpred = (unsigned)ca->spec_draws;
+            vbase = 0;
+            prays = 0;
+            cum.x = 0.0;
+            cum.y = 0.0;
+            cum.z = 0.0;
+            samp = jlane;
+            if (samp < nsamp) {
+              seed_round();
+              mode = 0;
+            }
+          }
         }
       }
     } else {
@@ -2066,7 +2397,7 @@ PT_DEV void path_trace(const PtKArgs &a) {
     PT_STAMP(0);
     const int n_start = __popcll(__ballot(mode == 0));
     const int n_path = __popcll(__ballot(mode == 1));
-    if (n_start == 0 && n_path == 0) continue;  // TILED: region exhausted, fetch the next one
+    if (n_start == 0 && n_path == 0) continue;  // TILED: nothing in flight, the round / unit logic above decides
     const bool do_p = n_start > 0 && n_path < cold_args(a)->p_max_path;
     const bool do_s = n_path >= cold_args(a)->s_min_path || (n_path > 0 && !do_p);
 
@@ -2102,10 +2433,13 @@ PT_DEV void path_trace(const PtKArgs &a) {
     }
 
     // ---- shade the hit, then unwind: deliver radiance up the stack / scatter the next child, until
-    //      this lane has a ray that needs a query (mode 1) or its sample is complete (mode 0 / 2) ----
+    //      this lane has a ray that needs a query (mode 1) or its sample is complete (mode 0 / 2 / 3) ----
     const bool work = prim || scat;
     if (work) {
-      nrays++;
+      if (TILED)
+        srays++;
+      else
+        nrays++;
       shade(hit, best_t);
       mode = 1;
     }
@@ -2127,7 +2461,7 @@ PT_DEV void path_trace(const PtKArgs &a) {
         break;  // mode 1: queried at the next S-step
       }
       if (sp == 0) {
-        finish_sample();  // mode 0 (next sample) or 2 (pixel done)
+        finish_sample();  // mode 0 (next sample), 2 (pixel done) or 3 (TILED: wait for the round's end)
         break;
       }
       // a child of frame sp-1 returned `ret` (render.py:135-137)
@@ -2178,8 +2512,11 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAV
   path_trace<false, LDSF, false>(a);
 }
 // second pass behind pt_tile_kernel<PATHTRACER> (perspective camera): the flagged pixels, by region
+#ifndef PT_WAVES_REGIONS
+#define PT_WAVES_REGIONS 2
+#endif
 template <bool LDSF>
-__global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(1, 2))) void pt_path_regions_kernel(const PtKArgs a) {
+__global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAVES_REGIONS, 8))) void pt_path_regions_kernel(const PtKArgs a) {
   path_trace<true, LDSF, true>(a);
 }
 

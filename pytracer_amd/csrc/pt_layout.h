@@ -98,7 +98,9 @@ struct PtKArgs {
   double *ws;                      // path-tracer frame stack: [slot][field][thread]
   unsigned long long *ray_counter; // per-workgroup partial counts; may be null
   unsigned long long *queue;       // path tracer: next unassigned pixel (zeroed per launch)
-  const int *region_order;         // path tracer: region visiting order (may be null = raster order)
+  const int2 *units;               // path tracer, second pass: (region, first flagged pixel | pixels << 8) per work unit
+  int dome_slot;                   // path tracer, first pass: the sphere the camera is deepest inside (uniform pigments), or -1
+  int spec_draws;                  // ... PT_PCG_PIXEL: draws per sample assumed for a pixel nothing is known about yet
   unsigned long long *region_mask; // path tracer: [region] pixels the first pass left to pt_path_kernel
   unsigned char *region_keys;      // path tracer: [region] their number
   unsigned int *cell_list;         // large scenes: [cell][cell_stride] surviving slots (pt_cell_kernel)

@@ -64,7 +64,13 @@ struct pt_scene {
   unsigned long long *queue = nullptr;  // path-tracer pixel queue head
   PtKArgs *args_dev = nullptr;          // device copy of the argument block (cold fields)
   unsigned char *region_keys = nullptr;  // path tracer region ordering
-  int *region_order = nullptr;
+  struct DomeCand {
+    int slot;
+    double invm[12];
+  };
+  std::vector<DomeCand> dome_cands;  // spheres that may serve as "the dome" of a view: uniform pigments, sane scale
+  int2 *units = nullptr;  // second pass: work units (pt_unit_sort)
+  int units_cap = 0;
   unsigned long long *region_mask = nullptr;
   int region_cap = 0;
   unsigned int *cell_list = nullptr;  // large scenes: per-cell survivor lists (pt_cell_kernel)
@@ -184,7 +190,7 @@ extern "C" void pt_scene_free(pt_scene *s) {
   (void)hipFree(s->queue);
   (void)hipFree(s->args_dev);
   (void)hipFree(s->region_keys);
-  (void)hipFree(s->region_order);
+  (void)hipFree(s->units);
   (void)hipFree(s->region_mask);
   (void)hipFree(s->cell_list);
   (void)hipFree(s->cell_count);
@@ -529,6 +535,13 @@ extern "C" int pt_scene_upload(const pt_scene_desc *d, int device, pt_scene **ou
       for (int c_ = 0; c_ < 4; ++c_) cs[(size_t)c_ * s->cs_stride + k] = b4[c_];
     }
   }
+  for (int slot = 0; slot < s->n_spheres; ++slot)
+    if (aux[slot].needs_uv == 0 && std::isfinite(recs[slot].fro2)) {
+      pt_scene::DomeCand dc;
+      dc.slot = slot;
+      memcpy(dc.invm, recs[slot].invm, sizeof dc.invm);
+      s->dome_cands.push_back(dc);
+    }
   UP(upload(&s->recs, recs));
   UP(upload(&s->bounds, bounds));
   UP(upload(&s->bsoa, bsoa));
@@ -820,26 +833,56 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
     a.ws = s->ws;
   }
 
-  // path tracer: per-region masks/keys from the first pass, visiting order from pt_region_sort
+  // path tracer: per-region masks/keys from the first pass, work units for the second from pt_unit_sort
   const int nregions = path_tiled ? ((p->width + PT_REGION - 1) / PT_REGION) * ((rows + PT_REGION - 1) / PT_REGION) : 0;
+  // lanes the second pass keeps resident: pt_unit_sort cuts regions into smaller units (more lanes per
+  // pixel) as long as all flagged pixels together still fit them
+  const long long lanes_cap = (long long)grid * PT_BLOCK;
   if (path_tiled) {
-    if (nregions > s->region_cap) {
+    const int units_need = nregions + (int)(lanes_cap / 64) + 64;
+    if (nregions > s->region_cap || units_need > s->units_cap) {
       HIP_TRY(hipStreamSynchronize(st));
       if (s->region_keys) HIP_TRY(hipFree(s->region_keys));
-      if (s->region_order) HIP_TRY(hipFree(s->region_order));
+      if (s->units) HIP_TRY(hipFree(s->units));
       if (s->region_mask) HIP_TRY(hipFree(s->region_mask));
       s->region_keys = nullptr;
-      s->region_order = nullptr;
+      s->units = nullptr;
       s->region_mask = nullptr;
       s->region_cap = 0;
+      s->units_cap = 0;
       HIP_TRY(hipMalloc((void **)&s->region_keys, (size_t)nregions));
-      HIP_TRY(hipMalloc((void **)&s->region_order, ((size_t)nregions + 1) * sizeof(int)));
+      HIP_TRY(hipMalloc((void **)&s->units, (size_t)units_need * sizeof(int2)));
       HIP_TRY(hipMalloc((void **)&s->region_mask, (size_t)nregions * sizeof(unsigned long long)));
       s->region_cap = nregions;
+      s->units_cap = units_need;
     }
-    a.region_order = s->region_order;
+    a.units = s->units;
     a.region_keys = s->region_keys;
     a.region_mask = s->region_mask;
+    // PT_PCG_PIXEL: what a sample is assumed to draw before anything is known about its pixel: two jitter
+    // numbers and one diffuse bounce (a guess only costs a round when it is wrong, never a bit of the image)
+    static const int env_spec = getenv("PTRACE_SPEC_DRAWS") ? atoi(getenv("PTRACE_SPEC_DRAWS")) : -1;
+    a.spec_draws = env_spec >= 0 ? env_spec : (p->samples_per_side > 0 ? 4 : 2);
+    // The sphere the camera is deepest inside (object-space |o'|^2 - 1 most negative, and below -0.5): the
+    // first pass settles, per pixel, what can only hit that sphere (pt_tile_kernel re-checks every condition
+    // from the exact hoisted constants; this only names the candidate).
+    a.dome_slot = -1;
+    static const int env_dome = getenv("PTRACE_PIXEL_DOME") ? atoi(getenv("PTRACE_PIXEL_DOME")) : 1;
+    if (!ortho && env_dome) {
+      const double ox = -cam->screen_distance * cam->m[0] + cam->m[3], oy = -cam->screen_distance * cam->m[4] + cam->m[7],
+                   oz = -cam->screen_distance * cam->m[8] + cam->m[11];
+      double best = -0.5;
+      for (const auto &dc : s->dome_cands) {
+        const double *m = dc.invm;
+        const double px = ox * m[0] + oy * m[1] + oz * m[2] + m[3], py = ox * m[4] + oy * m[5] + oz * m[6] + m[7],
+                     pz = ox * m[8] + oy * m[9] + oz * m[10] + m[11];
+        const double c = px * px + py * py + pz * pz - 1.0;
+        if (c < best) {
+          best = c;
+          a.dome_slot = dc.slot;
+        }
+      }
+    }
   }
   // large scenes: two-level culling (cells of PT_CELL x PT_CELL global pixels, then 8x8 tiles)
   static const int env_hier = getenv("PTRACE_HIER_MIN") ? atoi(getenv("PTRACE_HIER_MIN")) : 256;
@@ -926,7 +969,10 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
       PT_LAUNCH((pt_tile_kernel<PT_RENDERER_PATHTRACER, 4, false>), tgrid, lds, a, grid);
     if (path_tiled) {
       // second pass: the pixels the first one flagged, fullest regions first
-      hipLaunchKernelGGL(pt_region_sort, dim3(1), dim3(1024), 0, st, s->region_keys, nregions, s->region_order, s->queue);
+      static const int env_ppu = getenv("PTRACE_UNIT_LANES_CAP") ? atoi(getenv("PTRACE_UNIT_LANES_CAP")) : -1;  // 0: a unit = a region
+      const int nsamp = p->samples_per_side > 0 ? p->samples_per_side * p->samples_per_side : 1;
+      hipLaunchKernelGGL(pt_unit_sort, dim3(1), dim3(1024), 0, st, s->region_keys, nregions, s->units, s->units_cap, s->queue,
+                         env_ppu >= 0 ? (long long)env_ppu : lanes_cap, nsamp);
       if (lds_frames) {
         HIP_TRY(path_lds_limit((const void *)pt_path_regions_kernel<true>, lds + frame_lds + diag_lds_bytes));
         PT_LAUNCH((pt_path_regions_kernel<true>), grid, lds + frame_lds + diag_lds_bytes, a);

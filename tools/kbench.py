@@ -66,8 +66,11 @@ def main():
     ap.add_argument("--f64", action="store_true")
     args = ap.parse_args()
     for name in args.names:
-        ns, plane, wide, W, H, kw = CONFIGS[name]
+        sample = name.endswith(":sample")  # e.g. c4:sample = the same configuration under PT_PCG_SAMPLE
+        ns, plane, wide, W, H, kw = CONFIGS[name.split(":")[0]]
         kw = dict(kw)
+        if sample:
+            kw["pcg_mode"] = abi.PCG_SAMPLE
         world = scenes.synthetic_world(ns, with_plane=plane, wide=wide)
         for l in range(kw.pop("lights", 0)):
             from pytracer_amd import hostmodel as hm
@@ -96,7 +99,7 @@ def main():
         n_pl = int((flat.kind == 1).sum())
         flop = rays * (n_sph * 54 + n_pl * 36)
         t = float(np.median(ms)) * 1e-3
-        print(f"{name:8s} {W}x{H} shapes={flat.n_shapes:5d} rays={rays:9d}  kernel ms: min {ms.min():.4f} "
+        print(f"{name:14s} {W}x{H} shapes={flat.n_shapes:5d} rays={rays:9d}  kernel ms: min {ms.min():.4f} "
               f"med {np.median(ms):.4f} max {ms.max():.4f} | {rays / t / 1e6:9.1f} Mray/s "
               f"{rays * flat.n_shapes / t:.3e} tests/s {flop / t / 1e12:6.2f} TFLOP/s(alg) grid={st.grid}", flush=True)
         ds.close()
