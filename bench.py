@@ -1,27 +1,28 @@
 #!/usr/bin/env python3
-"""bench.py — headline benchmark of the MI355X ray-trace/shade path.
-
-Workload (BASELINE.json configs[1], "C2"): 1280x720, 32 spheres + 1 checkered plane, FlatRenderer,
-pixel-centre rays (S=0), synthetic scene of SURVEY.md §8(d).  One *step* = one frame through the C-ABI
-(`pt_render_device`: hoist prep + render kernel) with the scene already resident in HBM and the output
-left in HBM (fp32 RGB, the reference's PFM precision: 12 B/pixel).
+"""bench.py — benchmark of the MI355X ray-trace/shade path (BASELINE.json metric: Mray/s, ms/frame).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
-N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): weak scaling — the frame grows with
-N (same scene and view, area x N), rows are cut in interleaved 8-row blocks and every rank renders its
-blocks into its own HBM.  The path has no exchange step, so the timed region has no collective: as at
-N = 1 the output stays resident in HBM (there on one GPU, here sharded over N).  Assembling the HdrImage
-on rank 0 (one RCCL gather per frame on a side stream, double-buffered behind the next frame's render)
-is timed in a second loop and reported as `with_gather`, together with a bit-for-bit check of the
-assembled frame against a single-rank render.
+N = 1 — workload = BASELINE.json configs[1] ("C2"): 1280x720, 32 spheres + 1 checkered plane, FlatRenderer,
+pixel-centre rays (S=0), synthetic scene of SURVEY.md §8(d).  One *step* = one frame through the C-ABI
+(`pt_render_device`) with the scene resident in HBM and the output left in HBM (fp32 RGB, the reference's PFM
+precision: 12 B/pixel).  Every timed launch carries its own hipEvent pair IN the dispatch (no barrier
+packets), so `roofline.avg_kernel_ms` is the mean over all K timed launches.
 
-Prints ONE JSON line (rank 0).  `value` = rays handed to a world query by all ranks / wall time.
+N > 1 (torch.distributed.run, one rank per GPU, RCCL) — workload = configs[3] ("C4"): ONE 3840x2160 frame, 256
+spheres, PathTracer depth 5, 64 samples per pixel, STRONG-scaled: rows are cut in interleaved 8-row blocks,
+every rank renders its blocks, and the frame is assembled on rank 0 by one batched RCCL point-to-point gather
+per frame straight into row-block order (double-buffered: the gather of frame i overlaps the render of frame
+i+1).  The gather is INSIDE the timed region: `value` = rays of the whole frame x K / wall time.  The same loop
+without the gather, the other PCG mode and the same frame on rank 0 alone are side rows.
+
+Prints ONE JSON line (rank 0).
 """
 import argparse
+import datetime
 import json
-import math
 import os
+import platform
 import sys
 import time
 
@@ -32,33 +33,65 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 from pytracer_amd import abi, flatten, scenes  # noqa: E402
-from pytracer_amd.device import DeviceScene  # noqa: E402
+from pytracer_amd.device import DeviceScene, device_info  # noqa: E402
 from pytracer_amd.dist import ShardedFrameLoop  # noqa: E402
 
-PEAK_FP64_VECTOR_TFLOPS = 78.6  # MI355X vector fp64 (vendor spec; an FMA counts 2), SURVEY.md §8(d)
+PEAK_FP64_VECTOR_TFLOPS = 78.6  # MI355X vector fp64, vendor figure: an FMA counts 2
 PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FLOP_PER_SPHERE_TEST = 54       # 33 transform + 5 a + 6 b + 6 c + 4 delta
 FLOP_PER_PLANE_TEST = 36
+VALU_CYCLES_PER_WAVE_INSTR = 4  # one wave64 fp64-rate VALU instruction holds its SIMD for 4 cycles
+
+C4 = dict(n_spheres=256, wide=True, W=3840, H=2160,
+          kw=dict(renderer=abi.RENDERER_PATHTRACER, samples_per_side=8, num_of_rays=1, max_depth=5, rr_limit=3,
+                  path_state=45, path_seq=54))
+PCG_NAMES = {abi.PCG_PIXEL: "PT_PCG_PIXEL", abi.PCG_SAMPLE: "PT_PCG_SAMPLE"}
 
 
-def frame_size(n_gpus: int):
-    """Weak scaling: area x N at the 16:9 view of the 1280x720 base frame."""
-    s = math.sqrt(n_gpus)
-    w = int(round(1280 * s / 2)) * 2
-    h = int(round(720 * s / 2)) * 2
-    return w, h
+def cam_for(w, h):
+    return flatten.flatten_camera(scenes.synthetic_camera(w, h))
 
 
-def cpu_baseline(scene, cam_for, seconds_budget=20.0):
-    """Time the CPU oracle (a C restatement of the reference path: kind "port") on this host's cores,
-    on the same C2 frame.  Test infrastructure used only as a reported baseline."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return platform.processor() or "unknown"
+
+
+def usable_cores():
+    """Cores this job may really use: the affinity mask, cut by the cgroup's CPU quota when there is one; a GPU
+    box hands a one-GPU job a 16-core share of a much larger host, so without a quota to read, 16 it is."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    return max(1, min(n, int(int(txt[0]) / int(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    return max(1, min(n, int(q / per + 0.5)))
+        except (OSError, ValueError, IndexError):
+            pass
+    return min(n, 16)
+
+
+def cpu_baseline(scene, seconds_budget=20.0):
+    """Time the CPU oracle (a C restatement of the reference path: kind "port") on this host's cores, on the
+    same C2 frame.  Test infrastructure used only as a reported baseline."""
     from oracle import oracle as orc
 
     orc.build()
     par = abi.make_params(1280, 720, abi.RENDERER_FLAT, out_format=abi.OUT_F32)
     cam = cam_for(1280, 720)
-    # the GPU box gives this job a 16-core share of the host (more threads only oversubscribe it)
-    threads = int(os.environ.get("PT_CPU_THREADS", min(orc.max_threads(), 16)))
+    usable = usable_cores()
+    threads = int(os.environ.get("PT_CPU_THREADS", max(1, min(orc.max_threads(), usable))))
     t0 = time.perf_counter()
     _, rays = orc.render(scene, cam, par, n_threads=threads, sqr_mode=orc.SQR_MUL)
     first = time.perf_counter() - t0
@@ -76,60 +109,71 @@ def cpu_baseline(scene, cam_for, seconds_budget=20.0):
     return {
         "value": rays / dt / 1e6, "unit": "Mray/s", "cores": threads, "kind": "port",
         "sample": f"full 1280x720 C2 frame x{reps} on {threads} threads (OpenMP rows), C oracle, x*x arithmetic",
+        "cpu_model": cpu_model(), "nproc": os.cpu_count(), "usable_cores": usable,
         "ms_per_frame": dt * 1e3,
         "one_core_Mray_s": rays1 / dt1 / 1e6,
         "one_core_sample": "rows of rank 3/8 (90 rows) of the same frame, 1 thread",
+        "reference_itself": "pure Python, one core, measured in the build container: 4.2e3 rays/s on this scene shape (BASELINE.md)",
     }
+
+
+def kernel_row(ds, cam, par, out, reps, flat):
+    """Median kernel time (events in the dispatches) and ray statistics of `reps` frames."""
+    ms = []
+    for r in range(reps + 1):
+        ds.render_into(cam, par, out.data_ptr(), out.numel() * out.element_size(), None)
+        st = ds.stats()
+        if r > 0:
+            ms.append(st.kernel_ms)
+    t = float(np.median(ms)) * 1e-3
+    n_sph = int((flat.kind == abi.SHAPE_SPHERE).sum())
+    n_pl = flat.n_shapes - n_sph
+    return {"Mray_s": st.n_rays / t / 1e6, "ms_per_frame": t * 1e3, "rays_per_frame": int(st.n_rays),
+            "traced_ray_fraction": 1.0 - st.n_rays_resolved / max(1, st.n_rays),
+            "traced_Mray_s": (st.n_rays - st.n_rays_resolved) / t / 1e6,
+            "ray_shape_tests_per_s": st.n_rays * flat.n_shapes / t,
+            "algorithmic_equivalent_TFLOP_s": st.n_rays * (n_sph * FLOP_PER_SPHERE_TEST + n_pl * FLOP_PER_PLANE_TEST) / t / 1e12}
 
 
 def extra_rows(device: int):
-    """Secondary rows (not the headline): the other 1280x720 configurations of BASELINE.json on one GPU,
-    kernel time from the library's hipEvents, median of a few frames."""
+    """Secondary rows (not the headline): the other configurations of BASELINE.json on one GPU, kernel time from
+    the library's events, median of a few frames.  The path-traced ones in both per-thread PCG modes."""
     rows = {}
+    c3 = dict(renderer=abi.RENDERER_PATHTRACER, samples_per_side=4, num_of_rays=1, max_depth=3, rr_limit=3,
+              path_state=45, path_seq=54)
     cases = {
-        "C3_pathtracer_1280x720_32sph_D3_spp16_N1": (32, False, False, 1280, 720, 7, dict(
-            renderer=abi.RENDERER_PATHTRACER, samples_per_side=4, num_of_rays=1, max_depth=3, rr_limit=3,
-            path_state=45, path_seq=54)),
-        "C3_cli_default_N10_spp1": (32, False, False, 1280, 720, 3, dict(
-            renderer=abi.RENDERER_PATHTRACER, samples_per_side=1, num_of_rays=10, max_depth=3, rr_limit=3,
-            path_state=45, path_seq=54)),
+        "C3_pathtracer_1280x720_32sph_D3_spp16_N1": (32, False, False, 1280, 720, 7, c3),
+        "C3_same_PT_PCG_SAMPLE": (32, False, False, 1280, 720, 7, dict(c3, pcg_mode=abi.PCG_SAMPLE)),
+        "C3_cli_default_N10_spp1": (32, False, False, 1280, 720, 3, dict(c3, samples_per_side=1, num_of_rays=10)),
         "C5_flat_1280x720_10k_spheres": (10000, False, True, 1280, 720, 5, dict(renderer=abi.RENDERER_FLAT)),
-        "C4_crop_pathtracer_960x540_256sph_D5_spp16": (256, False, True, 960, 540, 3, dict(
-            renderer=abi.RENDERER_PATHTRACER, samples_per_side=4, num_of_rays=1, max_depth=5, rr_limit=3,
-            path_state=45, path_seq=54)),
-        "C4_pathtracer_3840x2160_256sph_D5_spp64_one_gpu": (256, False, True, 3840, 2160, 3, dict(
-            renderer=abi.RENDERER_PATHTRACER, samples_per_side=8, num_of_rays=1, max_depth=5, rr_limit=3,
-            path_state=45, path_seq=54)),
-        "C4_share_of_rank_3_of_8": (256, False, True, 3840, 2160, 3, dict(
-            renderer=abi.RENDERER_PATHTRACER, samples_per_side=8, num_of_rays=1, max_depth=5, rr_limit=3,
-            path_state=45, path_seq=54, n_ranks=8, rank=3, row_block=8)),
+        "C4_pathtracer_3840x2160_256sph_D5_spp64_one_gpu": (256, False, True, 3840, 2160, 3, C4["kw"]),
+        "C4_same_PT_PCG_SAMPLE": (256, False, True, 3840, 2160, 3, dict(C4["kw"], pcg_mode=abi.PCG_SAMPLE)),
+        "C4_share_of_rank_3_of_8": (256, False, True, 3840, 2160, 3, dict(C4["kw"], n_ranks=8, rank=3, row_block=8)),
+        "C4_share_of_rank_3_of_8_PT_PCG_SAMPLE": (256, False, True, 3840, 2160, 3,
+                                                  dict(C4["kw"], n_ranks=8, rank=3, row_block=8, pcg_mode=abi.PCG_SAMPLE)),
     }
+    scene_cache = {}
     for name, (ns, plane, wide, W, H, reps, kw) in cases.items():
-        flat = flatten.flatten_world(scenes.synthetic_world(ns, with_plane=plane, wide=wide))
-        cam = flatten.flatten_camera(scenes.synthetic_camera(W, H))
+        key = (ns, plane, wide)
+        if key not in scene_cache:
+            for ds_old in scene_cache.values():
+                ds_old[1].close()
+            scene_cache.clear()
+            flat = flatten.flatten_world(scenes.synthetic_world(ns, with_plane=plane, wide=wide))
+            scene_cache[key] = (flat, DeviceScene(flat, device=device))
+        flat, ds = scene_cache[key]
         par = abi.make_params(W, H, out_format=abi.OUT_F32, **kw)
-        ds = DeviceScene(flat, device=device)
         out = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")  # (a rank's share uses the top of it)
-        ms = []
-        for r in range(reps + 1):
-            ds.render_into(cam, par, out.data_ptr(), out.numel() * 4, None)
-            st = ds.stats()
-            if r > 0:
-                ms.append(st.kernel_ms)
-        t = float(np.median(ms)) * 1e-3
-        n_sph = int((flat.kind == abi.SHAPE_SPHERE).sum())
-        n_pl = flat.n_shapes - n_sph
-        rows[name] = {"Mray_s": st.n_rays / t / 1e6, "ms_per_frame": t * 1e3, "rays_per_frame": int(st.n_rays),
-                      "ray_shape_tests_per_s": st.n_rays * flat.n_shapes / t,
-                      "algorithmic_TFLOP_s": st.n_rays * (n_sph * FLOP_PER_SPHERE_TEST + n_pl * FLOP_PER_PLANE_TEST) / t / 1e12}
-        ds.close()
+        rows[name] = kernel_row(ds, cam_for(W, H), par, out, reps, flat)
+    for ds_old in scene_cache.values():
+        ds_old[1].close()
     return rows
 
 
-def boundary_rows(flat, cam_for, device: int):
-    """the same C2 frame seen from the drop-in boundary -- ms per frame at the C-ABI with
-    caller-owned HOST buffers (`pt_render`: kernel + D2H), scene upload (flatten + H2D), and the Python
-    fill of a reference-style HdrImage (a list of W*H Color objects).  None of these is `value`."""
+def boundary_rows(flat, device: int, rays_per_frame: int):
+    """SURVEY.md 8(d) / BASELINE.md 4.3: the same C2 frame seen from the drop-in boundary -- ms per frame at the
+    C-ABI = kernel + D2H (`pt_render` into a caller-owned host buffer), scene upload (flatten + H2D), and the
+    Python fill of a reference-style HdrImage (a list of W*H Color objects).  None of these is `value`."""
     from pytracer_amd.tracer import _fill_image
 
     W, H = 1280, 720
@@ -138,15 +182,26 @@ def boundary_rows(flat, cam_for, device: int):
     ds = DeviceScene(flat, device=device)
     upload_ms = (time.perf_counter() - t0) * 1e3
     rows = {"scene_upload_ms": upload_ms}
-    for name, fmt in (("pt_render_host_f64_ms", abi.OUT_F64), ("pt_render_host_f32_ms", abi.OUT_F32)):
+    for fmt, tag, nbytes in ((abi.OUT_F32, "f32", 4), (abi.OUT_F64, "f64", 8)):
         par = abi.make_params(W, H, abi.RENDERER_FLAT, out_format=fmt)
-        ds.render(cam, par)
-        ts = []
-        for _ in range(5):
-            t0 = time.perf_counter()
-            out = ds.render(cam, par)
-            ts.append((time.perf_counter() - t0) * 1e3)
-        rows[name] = float(np.median(ts))
+        for pinned in (True, False):
+            ds.render(cam, par, pinned=pinned)
+            ts = []
+            for _ in range(9):
+                t0 = time.perf_counter()
+                out = ds.render(cam, par, pinned=pinned)
+                ts.append((time.perf_counter() - t0) * 1e3)
+            ms = float(np.median(ts))
+            rows[f"pt_render_host_{tag}_{'pinned' if pinned else 'pageable'}_ms"] = ms
+            if pinned:
+                st = ds.stats()
+                rows[f"pt_render_host_{tag}_d2h_GB_s"] = W * H * 3 * nbytes / max(1e-9, (st.total_ms - st.kernel_ms) * 1e-3) / 1e9
+    rows["value_at_c_abi"] = {
+        "value": rays_per_frame / rows["pt_render_host_f32_pinned_ms"] / 1e3, "unit": "Mray/s",
+        "ms_per_frame": rows["pt_render_host_f32_pinned_ms"],
+        "note": "kernel + device-to-host copy of the fp32 frame (11.06 MB) into a page-locked caller buffer, one blocking "
+                "pt_render call per frame: the copy runs at the host link's rate and is >90 % of the time",
+    }
 
     class RefColor:  # the reference's Color: three attributes
         __slots__ = ("r", "g", "b")
@@ -161,27 +216,249 @@ def boundary_rows(flat, cam_for, device: int):
 
     img = RefImage(W, H)
     t0 = time.perf_counter()
-    _fill_image(img, out.astype(np.float64))
+    _fill_image(img, np.asarray(out, dtype=np.float64))
     rows["python_hdrimage_fill_ms"] = (time.perf_counter() - t0) * 1e3
     ds.close()
     return rows
 
 
-def measured_traffic():
-    """HBM bytes per launch of the headline kernel from rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE;
-    collected separately, see profiles/): bench.py cannot read hardware counters itself."""
-    path = os.path.join(ROOT, "profiles", "traffic_c2.json")
+def load_profile(name):
+    path = os.path.join(ROOT, "profiles", name)
     if os.path.exists(path):
         with open(path) as f:
             return json.load(f)
     return None
 
 
+def fence(dist):
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+        torch.cuda.synchronize()
+
+
+def timed_loop(ds, loop, steps, dist, gather, events=True):
+    """K frames between two fences; -> (wall s, summed kernel ms, launches).  With `events` every launch is timed by
+    an event pair carried in its own dispatch (they cost a few microseconds of pipelining per launch, so the
+    headline loop runs without them and a second, identical loop supplies the kernel's average duration)."""
+    ds.set_count_rays(False)
+    ds.set_timing(events)
+    loop.step(0, gather=gather)  # one uncounted frame so the timed region starts from the steady state
+    fence(dist)
+    if events:
+        ds.profile_begin(steps + 2)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        loop.step(i, gather=gather)
+    fence(dist)
+    elapsed = time.perf_counter() - t0
+    kernel_total_ms, launches = ds.profile_end() if events else (0.0, 0)
+    ds.set_timing(True)
+    return elapsed, kernel_total_ms, launches
+
+
+def run_single(args, local_rank):
+    W, H = 1280, 720
+    world = scenes.synthetic_world(32, with_plane=True)
+    flat = flatten.flatten_world(world)
+    cam = cam_for(W, H)
+    ds = DeviceScene(flat, device=local_rank)
+    par = abi.make_params(W, H, abi.RENDERER_FLAT, out_format=abi.OUT_F32)
+    loop = ShardedFrameLoop(ds, cam, par, row_block=8)
+
+    ds.set_count_rays(True)
+    for i in range(max(1, args.warmup)):
+        loop.step(i, gather=False)
+    fence(None)
+    ds.sync()
+    st = ds.stats()
+    # rays per frame are counted (in-kernel counter) during warm-up; the workload is deterministic, so the timed
+    # steps run without the counter: one step == exactly one render-kernel launch
+    rays_per_step, resolved = int(st.n_rays), int(st.n_rays_resolved)
+    n_wg = st.grid
+    elapsed, _, _ = timed_loop(ds, loop, args.steps, None, False, events=False)  # the headline: K frames back to back
+    elapsed_ev, kernel_total_ms, launches = timed_loop(ds, loop, args.steps, None, False, events=True)  # the same, all K timed
+    avg_kernel_s = kernel_total_ms / max(launches, 1) * 1e-3
+    ms_per_step = elapsed / args.steps * 1e3
+
+    # the same frames with the dome shortcut off: every primary ray generated and traced
+    ds.set_dome_shortcut(False)
+    for i in range(3):
+        loop.step(i, gather=False)
+    el_off, _, _ = timed_loop(ds, loop, max(2, args.steps // 2), None, False, events=False)
+    _, k_off, n_off = timed_loop(ds, loop, max(2, args.steps // 2), None, False, events=True)
+    ds.set_dome_shortcut(True)
+
+    n_cu, clock_khz = device_info(local_rank)
+    n_simd = n_cu * 4
+    clock_hz = clock_khz * 1e3
+    n_sph = int((flat.kind == abi.SHAPE_SPHERE).sum())
+    n_pl = int((flat.kind == abi.SHAPE_PLANE).sum())
+    flops = rays_per_step * (n_sph * FLOP_PER_SPHERE_TEST + n_pl * FLOP_PER_PLANE_TEST)
+    alg_bytes = rays_per_step * 12 + n_wg * flat.n_shapes * 104
+    peak_lane_ops = n_simd * 16 * clock_hz / 1e12  # fp64-rate VALU: 16 lanes per SIMD per cycle, no FMA on the parity path
+    pmc = load_profile("pmc_c2.json")
+    roofline = {
+        "bound": "valu_fp64_issue",
+        "achieved": None, "peak": peak_lane_ops, "unit": "TFLOP/s", "frac": None, "traffic": None,
+        "kernel": "pt_tile_kernel<FLAT> (8x8 tiles, culled shape lists, hoisted scale+translate tests)",
+        "avg_kernel_ms": avg_kernel_s * 1e3, "launches_timed": launches,
+        "ms_per_step_of_the_timed_launch_loop": elapsed_ev / args.steps * 1e3,
+        "note": "no dense contraction: MFMA unused; the path is bound by fp64 VALU issue/latency, not HBM (SURVEY.md 8d). "
+                "`achieved` = EXECUTED VALU lane-operations per second: wave-level VALU instructions per launch (rocprofv3 PMC "
+                "SQ_INSTS_VALU, profiles/pmc_c2.json) x 64 lanes / the kernel's average duration measured here over every "
+                "timed launch; `peak` = SIMDs x 16 lanes x clock (one fp64-rate VALU instruction holds a SIMD 4 cycles; "
+                "the parity kernels may not fuse a*b+c, so this, half the vendor's FMA figure, is their ceiling); "
+                "`frac` = achieved/peak = VALU issue utilisation.",
+    }
+    if avg_kernel_s * 1e3 > ms_per_step * 1.02:
+        roofline["avg_kernel_ms"] = None
+        roofline["note"] += " (kernel time discarded: it exceeded the step time)"
+    elif pmc is not None:
+        valu = pmc["counters"]["SQ_INSTS_VALU"]
+        ach = valu * 64 / avg_kernel_s / 1e12
+        f64 = sum(pmc["counters"].get(k, 0.0) for k in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64",
+                                                         "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64"))
+        roofline.update({
+            "achieved": ach, "frac": valu * VALU_CYCLES_PER_WAVE_INSTR / (n_simd * avg_kernel_s * clock_hz),
+            "traffic": pmc.get("hbm_bytes_per_launch"),
+            "executed": {"valu_wave_instructions_per_launch": valu,
+                         "salu_wave_instructions_per_launch": pmc["counters"].get("SQ_INSTS_SALU"),
+                         "fp64_instruction_share": (f64 / valu) if f64 else None,
+                         "kernel_us_under_rocprof": pmc.get("dur_us"), "simds": n_simd, "clock_GHz": clock_hz / 1e9,
+                         "source": pmc.get("source")},
+        })
+    roofline["algorithmic_equivalent"] = {
+        "flop_per_launch": flops, "TFLOP_s": flops / avg_kernel_s / 1e12,
+        "note": "SURVEY.md 8(d) recipe: 54 flop per ray-sphere and 36 per ray-plane test, every ray x every shape, / kernel "
+                "time.  NOT a hardware fraction: the kernel executes far less (tile culling, hoisted origin, scale+translate "
+                "fast path, dome shortcut) with bit-identical results, so this figure may exceed the fp64 peak (78.6 TFLOP/s "
+                "with FMA); it says how fast a brute-force loop would have to be to keep up",
+    }
+    roofline["hbm"] = {"achieved": alg_bytes / avg_kernel_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                       "frac": alg_bytes / avg_kernel_s / 1e9 / PEAK_HBM_GBS, "algorithmic_bytes_per_launch": alg_bytes,
+                       "note": "12 B per pixel written + the scene once per workgroup: not the bound"}
+    result = {
+        "metric": "Mray/s (primary+shadow) at 1280x720 per GPU, C2: 32 spheres + 1 plane, FlatRenderer",
+        "value": rays_per_step * args.steps / elapsed / 1e6,
+        "unit": "Mray/s",
+        "n_gpus": 1,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": f"C2 flat {W}x{H}, 32 spheres + 1 plane, S=0, fp32 RGB output resident in HBM",
+                   "width": W, "height": H, "n_shapes": flat.n_shapes, "renderer": "FlatRenderer"},
+        "ray_shape_tests_per_s": rays_per_step * flat.n_shapes * args.steps / elapsed,
+        "traced_ray_fraction": 1.0 - resolved / max(1, rays_per_step),
+        "traced_ray_note": "rays of tiles whose only possible hit is the sphere around the camera are resolved without being "
+                           "generated (exact, DESIGN.md 4 item 8) and counted in `value`; this is the share that was traced",
+        "dome_off": {"value": rays_per_step * max(2, args.steps // 2) / el_off / 1e6, "unit": "Mray/s",
+                     "ms_per_step": el_off / max(2, args.steps // 2) * 1e3, "avg_kernel_ms": k_off / max(1, n_off),
+                     "note": "same frames with the shortcut switched off (pt_set_dome_shortcut(0)): every primary ray traced"},
+        "roofline": roofline,
+    }
+    ds.close()
+    if not args.no_extras:
+        result["extra"] = extra_rows(local_rank)
+        result["boundary"] = boundary_rows(flat, local_rank, rays_per_step)
+    if not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(flat)
+    print(json.dumps(result), flush=True)
+
+
+def run_multi(args, rank, local_rank, world_size, dist):
+    W, H = C4["W"], C4["H"]
+    flat = flatten.flatten_world(scenes.synthetic_world(C4["n_spheres"], wide=C4["wide"]))
+    cam = cam_for(W, H)
+    ds = DeviceScene(flat, device=local_rank)
+    err = None
+    rows = {}
+    rays_frame = {}
+    try:
+        for mode in (abi.PCG_PIXEL, abi.PCG_SAMPLE):
+            par = abi.make_params(W, H, out_format=abi.OUT_F32, pcg_mode=mode, **C4["kw"])
+            loop = ShardedFrameLoop(ds, cam, par, row_block=8)
+            ds.set_count_rays(True)
+            ds.set_timing(True)
+            for i in range(max(2, args.warmup)):
+                loop.step(i, gather=True)
+            fence(dist)
+            ds.sync()
+            r = torch.tensor([int(ds.stats().n_rays)], dtype=torch.int64, device="cuda")
+            dist.all_reduce(r, op=dist.ReduceOp.SUM)
+            rays_frame[mode] = int(r.item())
+            for gather in (True, False):
+                elapsed, _, _ = timed_loop(ds, loop, args.steps, dist, gather, events=False)
+                _, kernel_ms, launches = timed_loop(ds, loop, max(2, args.steps // 2), dist, gather, events=True)
+                t = torch.tensor([elapsed, kernel_ms / max(1, launches)], dtype=torch.float64, device="cuda")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                rows[(mode, gather)] = (float(t[0].item()), float(t[1].item()))
+            # the frame assembled on rank 0 must be bit-identical to the same frame rendered by one rank
+            loop.step(0, gather=True)
+            fence(dist)
+            if rank == 0:
+                full = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
+                one = abi.copy_params(par, n_ranks=1, rank=0)
+                ms1 = []
+                for _ in range(3):
+                    ds.render_into(cam, one, full.data_ptr(), full.numel() * 4, None)
+                    ms1.append(ds.stats().kernel_ms)
+                rows[(mode, "check")] = "ok" if torch.equal(full, loop.image()) else "MISMATCH"
+                rows[(mode, "one_gpu_kernel_ms")] = float(np.median(ms1))
+            fence(dist)
+    except Exception as e:  # noqa: BLE001  (RCCL / driver errors surface as RuntimeError subclasses)
+        err = f"{type(e).__name__}: {e}"[:400]
+    # agree on failure: a rank that raised must not leave the others waiting in a collective for ever (the process
+    # group has a timeout; whoever gets here reports)
+    if rank == 0:
+        def line(mode, gather):
+            el, k = rows[(mode, gather)]
+            return {"value": rays_frame[mode] * args.steps / el / 1e6, "unit": "Mray/s", "ms_per_step": el / args.steps * 1e3,
+                    "avg_render_kernels_ms_max_over_ranks": k}
+        result = {
+            "metric": "Mray/s (primary+shadow), C4: ONE 3840x2160 frame, 256 spheres, PathTracer depth 5, 64 spp, strong-scaled "
+                      f"over {world_size} MI355X with the RCCL gather of the HdrImage inside the timed region",
+            "value": None, "unit": "Mray/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": None, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "C4 path tracer 3840x2160, 256 spheres, N=1, D=5, rr=3, S=8 (64 spp), fp32 RGB assembled on rank 0",
+                       "width": W, "height": H, "n_shapes": flat.n_shapes, "renderer": "PathTracer", "pcg_mode": "PT_PCG_PIXEL",
+                       "partition": f"interleaved 8-row blocks over {world_size} ranks, one batched RCCL send/recv group per frame "
+                                    "into row-block order on rank 0, double-buffered behind the next frame's render"},
+        }
+        if err is None and (abi.PCG_PIXEL, True) in rows:
+            head = line(abi.PCG_PIXEL, True)
+            result["value"], result["ms_per_step"] = head["value"], head["ms_per_step"]
+            result["avg_render_kernels_ms_max_over_ranks"] = head["avg_render_kernels_ms_max_over_ranks"]
+            result["gather_check"] = rows.get((abi.PCG_PIXEL, "check"))
+            result["without_gather"] = line(abi.PCG_PIXEL, False)
+            result["one_gpu_same_frame_kernel_ms"] = rows.get((abi.PCG_PIXEL, "one_gpu_kernel_ms"))
+            result["rays_per_frame"] = rays_frame[abi.PCG_PIXEL]
+            if (abi.PCG_SAMPLE, True) in rows:
+                result["pcg_sample"] = dict(line(abi.PCG_SAMPLE, True), without_gather=line(abi.PCG_SAMPLE, False),
+                                            gather_check=rows.get((abi.PCG_SAMPLE, "check")),
+                                            one_gpu_same_frame_kernel_ms=rows.get((abi.PCG_SAMPLE, "one_gpu_kernel_ms")),
+                                            rays_per_frame=rays_frame[abi.PCG_SAMPLE],
+                                            note="the same frame with one generator per SAMPLE (SURVEY.md 8c Mode SAMPLE): a pixel's "
+                                                 "64 samples are independent, so a rank's share keeps all its lanes busy")
+            result["gather_bytes_per_frame"] = W * H * 3 * 4 * (world_size - 1) // world_size
+        else:
+            result["error"] = err or "incomplete"
+        print(json.dumps(result), flush=True)
+    ds.close()
+    return 0 if err is None else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
     args = ap.parse_args()
@@ -189,184 +466,37 @@ def main():
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    n = args.gpus
-    if world_size != n and world_size > 1:
-        n = world_size
+    if args.steps is None:
+        args.steps = 200 if world_size == 1 else 20
+    if args.warmup is None:
+        args.warmup = 20 if world_size == 1 else 3
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
     # (PT_DIST_BACKEND=gloo + fewer GPUs than ranks: rehearsal of the N > 1 path on a one-GPU box)
     backend = os.environ.get("PT_DIST_BACKEND", "nccl")
     local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
-    dist = None
-    if world_size > 1:
-        import torch.distributed as dist  # noqa: F811
+    if world_size == 1:
+        run_single(args, local_rank)
+        return 0
+    import torch.distributed as dist
 
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world_size,
-                                    device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world_size)
-
-    W, H = frame_size(n)
-    world = scenes.synthetic_world(32, with_plane=True)
-    flat = flatten.flatten_world(world)
-    cam_for = lambda w, h: flatten.flatten_camera(scenes.synthetic_camera(w, h))  # noqa: E731
-    cam = cam_for(W, H)
-    ds = DeviceScene(flat, device=local_rank)
-    par = abi.make_params(W, H, abi.RENDERER_FLAT, out_format=abi.OUT_F32)
-    loop = ShardedFrameLoop(ds, cam, par, row_block=8)
-    rows = loop.rows
-    stream = loop.stream
-    ev_pairs = []
-
-    TIME_EVERY = 8  # bracket every 8th launch of the timed region with a hipEvent pair
-
-    def step(i, timed, gather=False):
-        if timed:
-            ds.set_timing(i % TIME_EVERY == 0)
-        loop.step(i, gather=gather)
-
-    def fence():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    ds.set_count_rays(True)
-    for i in range(args.warmup):
-        step(i, False)
-    fence()
-    ds.sync()
-    # rays per frame are counted (in-kernel counter) during warm-up; the workload is deterministic, so
-    # the timed steps run without the counter: one step == exactly one render-kernel launch
-    rays_per_step_local = int(ds.stats().n_rays) if args.warmup > 0 else rows * W
-    ds.set_count_rays(False)
-    ds.set_timing(False)
-    loop.step(0, gather=False)  # one uncounted frame so the timed region starts from the steady state
-    fence()
-    # every TIME_EVERY-th timed launch is bracketed by its own hipEvent pair on the launch stream (inside
-    # the library, directly around the render kernel): their mean is the kernel's average launch duration;
-    # the other launches carry no event so that frames run back to back
-    ds.profile_begin(args.steps // TIME_EVERY + 2)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i, True)
-    fence()
-    elapsed = time.perf_counter() - t0
-    kernel_total_ms, kernel_launches = ds.profile_end()
-    ds.set_timing(True)
-
-    # the headline numbers first: max time over ranks, rays of all ranks
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        r = torch.tensor([rays_per_step_local], dtype=torch.int64, device="cuda")
-        dist.all_reduce(r, op=dist.ReduceOp.SUM)
-        rays_per_step = int(r.item())
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    timeout = datetime.timedelta(seconds=int(os.environ.get("PT_DIST_TIMEOUT_S", "300")))
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world_size, timeout=timeout,
+                                device_id=torch.device("cuda", local_rank))
     else:
-        rays_per_step = rays_per_step_local
-
-    # N > 1: the same loop with the image assembled on rank 0 every frame (RCCL gather, overlapped), and the
-    # frame assembled on rank 0 must be bit-identical to the same frame rendered by one rank.  A failure
-    # here is reported in the line, it does not take the headline measurement with it.
-    gather_elapsed = None
-    gather_check = None
-    gather_error = None
-    gather_steps = max(2, min(args.steps, 100))
-    if dist is not None:
-        try:
-            for i in range(4):
-                step(i, False, gather=True)
-            fence()
-            t0 = time.perf_counter()
-            for i in range(gather_steps):
-                step(i, False, gather=True)
-            fence()
-            gather_elapsed = time.perf_counter() - t0
-            if rank == 0:
-                full = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
-                ds.render_into(cam, abi.copy_params(par, n_ranks=1, rank=0), full.data_ptr(), full.numel() * 4, None)
-                gather_check = "ok" if torch.equal(full, loop.image()) else "MISMATCH"
-            t = torch.tensor([gather_elapsed], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            gather_elapsed = float(t.item())
-        except Exception as e:  # noqa: BLE001  (RCCL / driver errors surface as RuntimeError subclasses)
-            gather_error = f"{type(e).__name__}: {e}"[:300]
-
-    avg_kernel_s = kernel_total_ms / max(kernel_launches, 1) * 1e-3
-
-    if rank == 0:
-        n_sph = int((flat.kind == abi.SHAPE_SPHERE).sum())
-        n_pl = int((flat.kind == abi.SHAPE_PLANE).sum())
-        rays_local = rows * W
-        flops = rays_local * (n_sph * FLOP_PER_SPHERE_TEST + n_pl * FLOP_PER_PLANE_TEST)
-        n_wg = ds.stats().grid
-        alg_bytes = rays_local * 12 + n_wg * flat.n_shapes * 104
-        tflops = flops / avg_kernel_s / 1e12
-        result = {
-            "metric": "Mray/s (primary+shadow) at 1280x720 per GPU, C2: 32 spheres + 1 plane, FlatRenderer",
-            "value": rays_per_step * args.steps / elapsed / 1e6,
-            "unit": "Mray/s",
-            "n_gpus": n,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f64",
-            "data": "synthetic",
-            "config": {"workload": f"C2 flat {W}x{H}, 32 spheres + 1 plane, S=0, fp32 RGB output",
-                       "width": W, "height": H, "n_shapes": flat.n_shapes, "renderer": "FlatRenderer",
-                       "partition": f"interleaved 8-row blocks over {n} rank(s), output resident in each rank's HBM"},
-            "ray_shape_tests_per_s": rays_per_step * flat.n_shapes * args.steps / elapsed,
-            "roofline": {
-                "bound": "valu_fp64",
-                "achieved": tflops, "peak": PEAK_FP64_VECTOR_TFLOPS, "unit": "TFLOP/s",
-                "frac": tflops / PEAK_FP64_VECTOR_TFLOPS,
-                "traffic": None,
-                "kernel": "pt_tile_kernel<FLAT> (8x8 tiles, culled shape lists, hoisted scale+translate tests)",
-                "avg_kernel_ms": avg_kernel_s * 1e3,
-                "algorithmic_flop_per_launch": flops,
-                "note": "no dense contraction: MFMA unused; fp64 VALU issue/latency binds (SURVEY.md 8d). Rays of tiles whose only "
-                        "possible hit is a dome around the camera are resolved without being traced (DESIGN.md 4, item 8) and are "
-                        "counted like the others: they are part of the frame's workload. `achieved` is "
-                        "ALGORITHMIC flop (54 per ray-sphere, 36 per ray-plane test, every ray x every shape) / kernel "
-                        "time; the kernel executes fewer (tile culling, hoisted origin, scale+translate fast path) with "
-                        "bit-identical results, so frac can exceed what brute force allows (peak/2 without FMA)",
-                "hbm": {"achieved": alg_bytes / avg_kernel_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                        "frac": alg_bytes / avg_kernel_s / 1e9 / PEAK_HBM_GBS,
-                        "algorithmic_bytes_per_launch": alg_bytes},
-            },
-        }
-        if gather_error is not None:
-            result["with_gather"] = {"error": gather_error}
-        elif gather_check is not None:
-            result["gather_check"] = gather_check
-            result["with_gather"] = {
-                "value": rays_per_step * gather_steps / gather_elapsed / 1e6, "unit": "Mray/s",
-                "ms_per_step": gather_elapsed / gather_steps * 1e3, "steps": gather_steps,
-                "note": "same frames with the HdrImage assembled on rank 0 every frame (RCCL gather of "
-                        f"{loop.nbytes / 1e6:.1f} MB per rank, overlapped with the next render); a Flat frame renders faster "
-                        "than one xGMI link moves its shard, so this rate is link-bound (DESIGN.md 5)"}
-        tr = measured_traffic()
-        if tr is not None and n == 1:
-            result["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
-            result["roofline"]["traffic_source"] = tr["source"]
-        if n == 1 and not args.no_extras:
-            result["extra"] = extra_rows(local_rank)
-            result["boundary"] = boundary_rows(flat, cam_for, local_rank)
-        if n == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(flat, cam_for)
-        print(json.dumps(result), flush=True)
-    if dist is not None:
-        dist.barrier()
+        dist.init_process_group(backend, rank=rank, world_size=world_size, timeout=timeout)
+    rc = run_multi(args, rank, local_rank, world_size, dist)
+    try:
+        if rc == 0:
+            dist.barrier()
         dist.destroy_process_group()
-    ds.close()
+    except Exception:  # noqa: BLE001
+        pass
+    return rc
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

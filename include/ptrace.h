@@ -131,18 +131,22 @@ typedef struct pt_params {
 } pt_params;
 
 typedef struct pt_stats {
-  uint64_t n_rays;      /* rays handed to a world query (primary + scattered + shadow) */
+  uint64_t n_rays;      /* rays handed to a world query (primary + scattered + shadow), incl. n_rays_resolved */
   uint64_t n_pixels;    /* pixels written by this call                                   */
   double kernel_ms;     /* hipEvent time of the render kernel(s) only                    */
   double total_ms;      /* hipEvent time incl. D2H copy when the call copies             */
   int32_t vgprs, lds_bytes, grid, block; /* registers per lane / launch geometry of the render kernel
                                             (of its last launch when a frame takes several)   */
+  uint64_t n_rays_resolved; /* of n_rays: primary rays whose hit was known without tracing them (tiles and
+                               pixels that can only see a sphere around the camera) */
 } pt_stats;
 
 typedef struct pt_scene pt_scene; /* opaque: device-resident scene + workspace */
 
 /* ---- entry points --------------------------------------------------------------------------*/
 int pt_device_count(void);
+/* Compute units and peak shader clock (kHz) of `device`: what a roofline is priced against. */
+int pt_device_info(int device, int *compute_units, int *clock_khz);
 /* Copy the flattened scene to the HBM of `device` (packed into the kernel's record layout). */
 int pt_scene_upload(const pt_scene_desc *desc, int device, pt_scene **out);
 void pt_scene_free(pt_scene *scene);
@@ -171,6 +175,10 @@ int pt_render_device(pt_scene *scene, const pt_camera *cam, const pt_params *p, 
 int pt_get_stats(pt_scene *scene, pt_stats *out);
 /* Enable (1) / disable (0) the in-kernel ray counter (default on). */
 int pt_set_count_rays(pt_scene *scene, int enable);
+/* Measurement switch: 0 = primary rays are always generated and traced, also where the image can only show
+ * a sphere that encloses the camera (default 1: such tiles/pixels are resolved without rays; the image is
+ * bit-identical either way). */
+int pt_set_dome_shortcut(pt_scene *scene, int enable);
 /* Block until the scene's last asynchronous render has finished and fold its statistics. */
 int pt_sync(pt_scene *scene);
 /* Enable (1, default) / disable (0) the hipEvent pair around each render kernel.  An event record is a

@@ -14,7 +14,7 @@ _lib = None
 EXPORTS = ("pt_device_count", "pt_scene_upload", "pt_scene_free", "pt_rows_for_rank", "pt_output_bytes",
            "pt_render", "pt_render_device", "pt_get_stats", "pt_set_count_rays", "pt_sync", "pt_last_error",
            "pt_version", "pt_profile_begin", "pt_profile_end", "pt_set_timing", "pt_image_pack_pfm",
-           "pt_image_average_luminosity", "pt_image_tonemap", "pt_host_alloc", "pt_host_free")
+           "pt_image_average_luminosity", "pt_image_tonemap", "pt_host_alloc", "pt_host_free", "pt_set_dome_shortcut", "pt_device_info")
 
 
 class PtraceError(RuntimeError):
@@ -66,6 +66,8 @@ def lib():
         L = C.CDLL(_LIB_PATH)
         P = C.POINTER
         L.pt_device_count.restype = C.c_int
+        L.pt_device_info.restype = C.c_int
+        L.pt_device_info.argtypes = [C.c_int, P(C.c_int), P(C.c_int)]
         L.pt_scene_upload.restype = C.c_int
         L.pt_scene_upload.argtypes = [P(abi.SceneDesc), C.c_int, P(C.c_void_p)]
         L.pt_scene_free.restype = None
@@ -81,6 +83,8 @@ def lib():
                                        C.c_void_p]
         L.pt_get_stats.restype = C.c_int
         L.pt_get_stats.argtypes = [C.c_void_p, P(abi.Stats)]
+        L.pt_set_dome_shortcut.restype = C.c_int
+        L.pt_set_dome_shortcut.argtypes = [C.c_void_p, C.c_int]
         L.pt_set_count_rays.restype = C.c_int
         L.pt_set_count_rays.argtypes = [C.c_void_p, C.c_int]
         L.pt_sync.restype = C.c_int

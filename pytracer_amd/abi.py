@@ -117,6 +117,7 @@ class Stats(C.Structure):
         ("lds_bytes", C.c_int32),
         ("grid", C.c_int32),
         ("block", C.c_int32),
+        ("n_rays_resolved", C.c_uint64),
     ]
 
 

@@ -380,7 +380,18 @@ PT_DEV LatCand lat_cand(double ox, double oy, double oz, double dx, double dy, d
 }
 
 #ifdef PT_DEBUG_TIME
-__device__ unsigned long long pt_dbg[8];  // world_query_lanes: prefilter cycles, walk cycles, iterations, calls
+__device__ unsigned long long pt_dbg[8];  // world_query_lanes: prefilter cycles, walk cycles, iterations, calls; 4..7: units / rounds
+#define PT_DBG_WAVES 16384
+__device__ unsigned long long pt_dbg_wave[PT_DBG_WAVES * 8];  // the same, per wave, summed up at the end of the kernel
+static __device__ void pt_dbg_flush() {
+  if ((threadIdx.x & 63) == 0) {
+    unsigned long long *wv = pt_dbg_wave + (size_t)((blockIdx.x * PT_BLOCK + threadIdx.x) >> 6) * 8;
+    for (int k = 0; k < 8; ++k) {
+      if (wv[k]) atomicAdd(&pt_dbg[k], wv[k]);
+      wv[k] = 0ULL;
+    }
+  }
+}
 #endif
 // (the kernels' one dynamic LDS block, viewed as 64-bit words and as doubles; see pt_tile_kernel, path_trace)
 extern __shared__ unsigned long long pt_lds_masks[];
@@ -597,11 +608,12 @@ PT_DEV int world_query_lanes(const PtKArgs &a, const Ray &r, double tmax, double
 #endif
   }
 #ifdef PT_DEBUG_TIME
-  if ((threadIdx.x & 63) == 0) {
-    atomicAdd(&pt_dbg[0], dbg_pre);
-    atomicAdd(&pt_dbg[1], dbg_walk);
-    atomicAdd(&pt_dbg[2], dbg_it);
-    atomicAdd(&pt_dbg[3], 1ULL);
+  if ((threadIdx.x & 63) == 0) {  // per-wave partial sums (flushed once per kernel by pt_dbg_flush): no atomics in the hot loop
+    unsigned long long *wv = pt_dbg_wave + (size_t)((blockIdx.x * PT_BLOCK + threadIdx.x) >> 6) * 8;
+    wv[0] += dbg_pre;
+    wv[1] += dbg_walk;
+    wv[2] += dbg_it;
+    wv[3] += 1ULL;
   }
 #endif
   // ---- planes: shapes.py:168-175, only the z row of the object-space ray decides (wave-uniform loop) ----
@@ -796,32 +808,55 @@ PT_DEV void store_pixel(const PtKArgs &a, long long pix, V3 v) {
 
 // Ray accounting without a contended atomic: wave reduction -> LDS -> one plain store per workgroup
 // into a.ray_counter[blockIdx.x]; pt_sum_counts folds the per-workgroup partials afterwards.
-PT_DEV void add_ray_count(const PtKArgs &a, unsigned long long n, int base = 0) {
+// A partial carries two counts: all rays of the workgroup and, of those, the rays that were RESOLVED without
+// being traced (tiles / pixels settled by the dome shortcut, pt_tile_kernel).
+PT_DEV void add_ray_count(const PtKArgs &a, unsigned long long n, int base = 0, unsigned long long resolved = 0) {
   unsigned long long *counter = cold_args(a)->ray_counter;
   if (counter) {
-    __shared__ unsigned long long partial[PT_BLOCK / 64];
-    for (int off = 32; off > 0; off >>= 1) n += __shfl_down(n, off, 64);
-    if ((threadIdx.x & 63) == 0) partial[threadIdx.x >> 6] = n;
+    __shared__ unsigned long long partial[2 * (PT_BLOCK / 64)];
+    for (int off = 32; off > 0; off >>= 1) {
+      n += __shfl_down(n, off, 64);
+      resolved += __shfl_down(resolved, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+      partial[threadIdx.x >> 6] = n;
+      partial[PT_BLOCK / 64 + (threadIdx.x >> 6)] = resolved;
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
-      unsigned long long t = 0;
-      for (int w = 0; w < PT_BLOCK / 64; ++w) t += partial[w];
-      counter[base + blockIdx.x] = t;
+      unsigned long long t = 0, r = 0;
+      for (int w = 0; w < PT_BLOCK / 64; ++w) {
+        t += partial[w];
+        r += partial[PT_BLOCK / 64 + w];
+      }
+      counter[2 * (base + blockIdx.x)] = t;
+      counter[2 * (base + blockIdx.x) + 1] = r;
     }
   }
 }
 
+// partials: [n][2] (all rays, resolved rays) -> total[0], total[1]
 __global__ void pt_sum_counts(const unsigned long long *partials, int n, unsigned long long *total) {
-  __shared__ unsigned long long acc[256];
-  unsigned long long t = 0;
-  for (int i = threadIdx.x; i < n; i += 256) t += partials[i];
-  acc[threadIdx.x] = t;
+  __shared__ unsigned long long acc[2][256];
+  unsigned long long t = 0, r = 0;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    t += partials[2 * i];
+    r += partials[2 * i + 1];
+  }
+  acc[0][threadIdx.x] = t;
+  acc[1][threadIdx.x] = r;
   __syncthreads();
   for (int s = 128; s > 0; s >>= 1) {
-    if ((int)threadIdx.x < s) acc[threadIdx.x] += acc[threadIdx.x + s];
+    if ((int)threadIdx.x < s) {
+      acc[0][threadIdx.x] += acc[0][threadIdx.x + s];
+      acc[1][threadIdx.x] += acc[1][threadIdx.x + s];
+    }
     __syncthreads();
   }
-  if (threadIdx.x == 0) *total = acc[0];
+  if (threadIdx.x == 0) {
+    total[0] = acc[0][0];
+    total[1] = acc[1][0];
+  }
 }
 
 // ---- pt_prep_hoist: per-shape constants of the primary rays (perspective camera) ----------------------
@@ -998,6 +1033,9 @@ __global__ __launch_bounds__(PT_BLOCK)
     }
     if (active) store_pixel(a, pix, cum);
   }
+#ifdef PT_DEBUG_TIME
+  pt_dbg_flush();
+#endif
   add_ray_count(a, nrays);
 }
 
@@ -1429,6 +1467,7 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_cell_kernel(const PtKArgs a, int 
 template <int RENDERER, int WAVES, bool HIER, bool ORTHO = false>
 __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) void pt_tile_kernel(const PtKArgs a, int count_base) {
   int S, W, rows_local, npass, dome_slot;
+  bool dome_on;
   {
     pt_kargs c = cold_args(a);
     S = c->S;
@@ -1436,6 +1475,7 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
     rows_local = c->rows_local;
     npass = c->npass;
     dome_slot = c->dome_slot;  // -1: the camera is inside no sphere with uniform pigments
+    dome_on = c->dome_shortcut != 0;
   }
   const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
   const int mbase = wib * npass;  // this wave's slice of pt_lds_masks
@@ -1443,7 +1483,7 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
   const int tiles_x = (W + 7) >> 3, tiles_y = (rows_local + 7) >> 3;
   const int ntiles = tiles_x * tiles_y;
   const int nwaves = gridDim.x * (PT_BLOCK / 64);
-  unsigned long long nrays = 0;
+  unsigned long long nrays = 0, nres = 0;  // rays accounted for; of those, resolved by the dome shortcut
 #ifdef PT_DEBUG_TIME
   unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
 #define PT_TSTAMP(k) do { const unsigned long long tn = __builtin_amdgcn_s_memtime(); tsum[k] += tn - tprev; tprev = tn; } while (0)
@@ -1536,7 +1576,7 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
     // Orthogonal camera: the origins differ, but |o'|^2 is convex in the image position, so it is below
     // 0.5 for every ray when it is (by a margin, in fp32) at the tile's four corner origins; |d'| is one
     // number for the frame.
-    if (nsurv == 1 && only < a.n_spheres) {
+    if (dome_on && nsurv == 1 && only < a.n_spheres) {
       only = __builtin_amdgcn_readfirstlane(only);
       pt_kargs ca = cold_args(a);
       const PtShapeAux *ax = ca->aux + only;
@@ -1605,6 +1645,7 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
             if (active) {
               store_pixel(a, pix, cum);
               nrays += (unsigned long long)nsamp;
+              nres += (unsigned long long)nsamp;
             }
           }
           if (RENDERER == PT_RENDERER_PATHTRACER) {
@@ -1628,7 +1669,7 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
     // untraced: there a pixel's samples are spread over lanes, here they would be walked one by one by a
     // wave that 60 finished lanes wait for.  (Planes carry no bounding sphere: a pixel of a tile some plane
     // survived in is always left over.)
-    if (RENDERER == PT_RENDERER_PATHTRACER && !ORTHO && dome_here && nsurv > 1) {
+    if (RENDERER == PT_RENDERER_PATHTRACER && !ORTHO && dome_on && dome_here && nsurv > 1) {
       pt_kargs ca = cold_args(a);
       const PtShapeAux *ax = ca->aux + dome_slot;
       const float fro2 = (float)PT_KD(&a.recs[dome_slot])[13];  // PtShapeRec::fro2
@@ -1681,6 +1722,7 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
         if (active && !hitable) {
           store_pixel(a, pix, cum);
           nrays += (unsigned long long)nsamp;
+          nres += (unsigned long long)nsamp;
         }
         const unsigned long long todo = __ballot(active && hitable);
         if (lane == 0) {
@@ -1802,8 +1844,9 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
   // sampled (every 64th workgroup) so that the report's own atomics do not disturb the other waves
   if (RENDERER != PT_RENDERER_PATHTRACER && (threadIdx.x & 63) == 0 && (blockIdx.x & 63) == 0)
     for (int q = 0; q < 8; ++q) atomicAdd(cold_args(a)->queue + 1 + q, tsum[q]);
+  pt_dbg_flush();
 #endif
-  add_ray_count(a, nrays, count_base);
+  add_ray_count(a, nrays, count_base, nres);
 }
 
 // ---- work units for the path tracer's second pass ---------------------------------------------------------
@@ -2281,10 +2324,21 @@ PT_DEV void path_trace(const PtKArgs &a) {
           }
           mode = 2;
 #ifdef PT_DEBUG_TIME
-          if (in_unit && lane == leader && pix >= 0) {  // speculation statistics: pixel-rounds, samples traced, samples kept
-            atomicAdd(&pt_dbg[4], 1ULL);
-            atomicAdd(&pt_dbg[5], (unsigned long long)dbg_fin);
-            atomicAdd(&pt_dbg[6], (unsigned long long)(vbase - dbg_vbase0));
+          {  // speculation statistics: pixel-rounds, samples traced, samples kept
+            const bool lead = in_unit && lane == leader && pix >= 0;
+            unsigned long long r4 = lead ? 1ULL : 0ULL, r5 = lead ? (unsigned long long)dbg_fin : 0ULL,
+                               r6 = lead ? (unsigned long long)(vbase - dbg_vbase0) : 0ULL;
+            for (int off = 32; off > 0; off >>= 1) {
+              r4 += __shfl_down(r4, off, 64);
+              r5 += __shfl_down(r5, off, 64);
+              r6 += __shfl_down(r6, off, 64);
+            }
+            if (lane == 0) {
+              unsigned long long *wv = pt_dbg_wave + (size_t)((blockIdx.x * PT_BLOCK + threadIdx.x) >> 6) * 8;
+              wv[4] += r4;
+              wv[5] += r5;
+              wv[6] += r6;
+            }
           }
 #endif
           if (in_unit) {
@@ -2327,7 +2381,7 @@ PT_DEV void path_trace(const PtKArgs &a) {
           pt_kargs ca = cold_args(a);
           if (seq >= (int)ca->queue[9]) break;  // (written by pt_unit_sort, before this kernel started)
 #ifdef PT_DEBUG_TIME
-          if (lane == 0) atomicAdd(&pt_dbg[7], 1ULL);
+          if (lane == 0) pt_dbg_wave[(size_t)((blockIdx.x * PT_BLOCK + threadIdx.x) >> 6) * 8 + 7] += 1ULL;
 #endif
           const int2 unit = ca->units[seq];
           const int region = unit.x, first = unit.y & 0xff, count = (unit.y >> 8) & 0xff;
@@ -2502,6 +2556,7 @@ PT_DEV void path_trace(const PtKArgs &a) {
 #ifdef PT_DEBUG_TIME
   if ((threadIdx.x & 63) == 0)
     for (int q = 0; q < 8; ++q) atomicAdd(cold_args(a)->queue + 1 + q, tsum[q]);
+  pt_dbg_flush();
 #endif
   add_ray_count(a, nrays);
 }

@@ -4,6 +4,7 @@
 // the solvers of src/pytracer/render.py:42-193.  No torch types, no exceptions across the ABI, every
 // failure is a negative return code plus a thread-local message (pt_last_error).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cmath>
@@ -19,7 +20,7 @@
 #include "pt_layout.h"
 #include "pt_post.h"
 
-#define PT_VERSION ((1 << 16) | 0)
+#define PT_VERSION ((1 << 16) | 1)
 
 static thread_local char g_err[512] = "";
 
@@ -58,8 +59,8 @@ struct pt_scene {
   size_t ws_bytes = 0;
   void *out_dev = nullptr;  // staging for pt_render (host output)
   size_t out_dev_bytes = 0;
-  unsigned long long *ray_counter = nullptr;   // total (1 word)
-  unsigned long long *ray_partials = nullptr;  // one word per workgroup
+  unsigned long long *ray_counter = nullptr;   // totals: all rays, rays resolved by the dome shortcut
+  unsigned long long *ray_partials = nullptr;  // the same two per workgroup
   int ray_partials_n = 0;
   unsigned long long *queue = nullptr;  // path-tracer pixel queue head
   PtKArgs *args_dev = nullptr;          // device copy of the argument block (cold fields)
@@ -92,6 +93,7 @@ struct pt_scene {
   int prof_used = 0;             // pairs recorded
   bool profiling = false;
   bool count_rays = true;
+  bool dome_shortcut = true;  // pt_set_dome_shortcut
   bool timing = true;  // bracket render kernels with hipEvents
   bool pending = false;  // an async render whose stats are not folded yet
   bool pending_copy = false;
@@ -119,6 +121,17 @@ extern "C" int pt_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
+}
+
+extern "C" int pt_device_info(int device, int *compute_units, int *clock_khz) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(PT_ERR_NODEVICE, "no HIP device visible");
+  if (device < 0 || device >= ndev) return fail(PT_ERR_INVALID, "device %d out of range [0,%d)", device, ndev);
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  if (compute_units) *compute_units = prop.multiProcessorCount;
+  if (clock_khz) *clock_khz = prop.clockRate;
+  return PT_OK;
 }
 
 extern "C" int pt_rows_for_rank(const pt_params *p) {
@@ -565,11 +578,11 @@ extern "C" int pt_scene_upload(const pt_scene_desc *d, int device, pt_scene **ou
     pt_scene_free(s);
     return code;
   };
-  if ((rc = hip_or_free(hipMalloc((void **)&s->ray_counter, sizeof(unsigned long long)), "hipMalloc(counter)"))) return rc;
+  if ((rc = hip_or_free(hipMalloc((void **)&s->ray_counter, 2 * sizeof(unsigned long long)), "hipMalloc(counter)"))) return rc;
   if ((rc = hip_or_free(hipMalloc((void **)&s->queue, 16 * sizeof(unsigned long long)), "hipMalloc(queue)"))) return rc;
   if ((rc = hip_or_free(hipMalloc((void **)&s->args_dev, sizeof(PtKArgs)), "hipMalloc(args)"))) return rc;
-  if ((rc = hip_or_free(hipHostMalloc((void **)&s->ray_counter_host, sizeof(unsigned long long)), "hipHostMalloc"))) return rc;
-  *s->ray_counter_host = 0;
+  if ((rc = hip_or_free(hipHostMalloc((void **)&s->ray_counter_host, 2 * sizeof(unsigned long long)), "hipHostMalloc"))) return rc;
+  s->ray_counter_host[0] = s->ray_counter_host[1] = 0;
   if ((rc = hip_or_free(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking), "hipStreamCreate"))) return rc;
   if ((rc = hip_or_free(hipEventCreate(&s->ev0), "hipEventCreate"))) return rc;
   if ((rc = hip_or_free(hipEventCreate(&s->ev1), "hipEventCreate"))) return rc;
@@ -578,6 +591,12 @@ extern "C" int pt_scene_upload(const pt_scene_desc *d, int device, pt_scene **ou
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) s->n_cu = prop.multiProcessorCount;
   *out = s;
+  return PT_OK;
+}
+
+extern "C" int pt_set_dome_shortcut(pt_scene *s, int enable) {
+  if (!s) return fail(PT_ERR_INVALID, "null scene");
+  s->dome_shortcut = enable != 0;
   return PT_OK;
 }
 
@@ -625,11 +644,16 @@ static hipError_t path_lds_limit(const void *kernel, size_t bytes) {
   return hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PT_LDS_BUDGET);
 }
 
-// launch a render kernel proper on `st` and remember which one it was (pt_stats.vgprs)
-#define PT_LAUNCH(KERNEL, GRID, LDS, ...)                                                     \
-  do {                                                                                        \
-    main_fn = (const void *)(KERNEL);                                                         \
-    hipLaunchKernelGGL((KERNEL), dim3(GRID), dim3(PT_BLOCK), LDS, st, __VA_ARGS__);           \
+// Launch a kernel of the frame on `st`; the LAST one is the render kernel proper (pt_stats.vgprs).  Timing: the
+// frame's first launch carries the start event and its last one the stop event IN the dispatch itself
+// (hipExtLaunchKernelGGL: the events take the kernel's own begin / end timestamps), so a timed frame costs no
+// barrier packet on the stream and the interval holds the frame's kernels, not the launch gaps around them.
+#define PT_LAUNCH(KERNEL, GRID, LDS, LAST, ...)                                                              \
+  do {                                                                                                       \
+    main_fn = (const void *)(KERNEL);                                                                        \
+    hipExtLaunchKernelGGL((KERNEL), dim3(GRID), dim3(PT_BLOCK), LDS, st, ev_started ? nullptr : ev_a,        \
+                          (LAST) ? ev_b : nullptr, 0, __VA_ARGS__);                                          \
+    ev_started = true;                                                                                       \
   } while (0)
 
 static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *out_dev, hipStream_t st) {
@@ -648,6 +672,7 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
   a.cs_stride = s->cs_stride;
   a.bs_levels = s->bs_levels;
   a.n_diag = s->n_diag;
+  a.dome_shortcut = s->dome_shortcut ? 1 : 0;
   a.lights = s->lights;
   a.tex = s->tex;
   a.tex_data = s->tex_data;
@@ -775,7 +800,7 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
       if (s->ray_partials) HIP_TRY(hipFree(s->ray_partials));
       s->ray_partials = nullptr;
       s->ray_partials_n = 0;
-      HIP_TRY(hipMalloc((void **)&s->ray_partials, (size_t)(grid + grid_first) * sizeof(unsigned long long)));
+      HIP_TRY(hipMalloc((void **)&s->ray_partials, (size_t)(grid + grid_first) * 2 * sizeof(unsigned long long)));
       s->ray_partials_n = grid + grid_first;
     }
     a.ray_counter = s->ray_partials;
@@ -801,9 +826,8 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
     HIP_TRY(hipMemsetAsync(out_dev, 0, pt_output_bytes(p), st));
     HIP_TRY(hipEventRecord(s->ev1, st));
     if (s->count_rays) {
-      *s->ray_counter_host = 0;
-      HIP_TRY(hipMemsetAsync(s->ray_counter, 0, sizeof(unsigned long long), st));
-      HIP_TRY(hipMemcpyAsync(s->ray_counter_host, s->ray_counter, sizeof(unsigned long long),
+      HIP_TRY(hipMemsetAsync(s->ray_counter, 0, 2 * sizeof(unsigned long long), st));
+      HIP_TRY(hipMemcpyAsync(s->ray_counter_host, s->ray_counter, 2 * sizeof(unsigned long long),
                              hipMemcpyDeviceToHost, st));
       HIP_TRY(hipEventRecord(s->ev_count, st));
       s->count_pending = true;
@@ -925,7 +949,9 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
   }
   const void *main_fn = nullptr;  // the render kernel proper (the last one launched), for pt_stats.vgprs
   const bool prof = s->timing && s->profiling && (size_t)(2 * s->prof_used + 1) < s->prof.size();
-  if (s->timing) HIP_TRY(hipEventRecord(prof ? s->prof[2 * s->prof_used] : s->ev0, st));
+  const hipEvent_t ev_a = s->timing ? (prof ? s->prof[2 * s->prof_used] : s->ev0) : nullptr;
+  const hipEvent_t ev_b = s->timing ? (prof ? s->prof[2 * s->prof_used + 1] : s->ev1) : nullptr;
+  bool ev_started = false;
   if (tile || path_tiled) {
 #ifdef PT_DEBUG_TIME
     HIP_TRY(hipMemsetAsync(s->queue, 0, 16 * sizeof(unsigned long long), st));
@@ -941,32 +967,32 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
       const int chunk_len = (max_chunks + nchunks - 1) / nchunks * PT_BLOCK;
       if (chunk_len > PT_CELL_CHUNK) return fail(PT_ERR_INVALID, "internal: cell chunk exceeds its LDS staging");
       HIP_TRY(hipMemsetAsync(s->cell_count, 0, (size_t)ncells * sizeof(int), st));
-      hipLaunchKernelGGL(pt_cell_kernel, dim3(ngroups * nchunks), dim3(PT_BLOCK), 0, st, a, nchunks, chunk_len);
+      PT_LAUNCH(pt_cell_kernel, ngroups * nchunks, 0, false, a, nchunks, chunk_len);
       if (p->renderer == PT_RENDERER_ONOFF)
-        PT_LAUNCH((pt_tile_kernel<PT_RENDERER_ONOFF, 4, true>), tgrid, lds, a, 0);
+        PT_LAUNCH((pt_tile_kernel<PT_RENDERER_ONOFF, 4, true>), tgrid, lds, !path_tiled, a, 0);
       else if (p->renderer == PT_RENDERER_FLAT)
-        PT_LAUNCH((pt_tile_kernel<PT_RENDERER_FLAT, 4, true>), tgrid, lds, a, 0);
+        PT_LAUNCH((pt_tile_kernel<PT_RENDERER_FLAT, 4, true>), tgrid, lds, !path_tiled, a, 0);
       else if (p->renderer == PT_RENDERER_POINTLIGHT)
-        PT_LAUNCH((pt_tile_kernel<PT_RENDERER_POINTLIGHT, 3, true>), tgrid, lds, a, 0);
+        PT_LAUNCH((pt_tile_kernel<PT_RENDERER_POINTLIGHT, 3, true>), tgrid, lds, !path_tiled, a, 0);
       else
-        PT_LAUNCH((pt_tile_kernel<PT_RENDERER_PATHTRACER, 4, true>), tgrid, lds, a, grid);
+        PT_LAUNCH((pt_tile_kernel<PT_RENDERER_PATHTRACER, 4, true>), tgrid, lds, !path_tiled, a, grid);
     } else if (ortho) {
       if (p->renderer == PT_RENDERER_ONOFF)
-        PT_LAUNCH((pt_tile_kernel<PT_RENDERER_ONOFF, 4, false, true>), tgrid, lds, a, 0);
+        PT_LAUNCH((pt_tile_kernel<PT_RENDERER_ONOFF, 4, false, true>), tgrid, lds, !path_tiled, a, 0);
       else if (p->renderer == PT_RENDERER_FLAT)
-        PT_LAUNCH((pt_tile_kernel<PT_RENDERER_FLAT, 4, false, true>), tgrid, lds, a, 0);
+        PT_LAUNCH((pt_tile_kernel<PT_RENDERER_FLAT, 4, false, true>), tgrid, lds, !path_tiled, a, 0);
       else if (p->renderer == PT_RENDERER_POINTLIGHT)
-        PT_LAUNCH((pt_tile_kernel<PT_RENDERER_POINTLIGHT, 3, false, true>), tgrid, lds, a, 0);
+        PT_LAUNCH((pt_tile_kernel<PT_RENDERER_POINTLIGHT, 3, false, true>), tgrid, lds, !path_tiled, a, 0);
       else
-        PT_LAUNCH((pt_tile_kernel<PT_RENDERER_PATHTRACER, 4, false, true>), tgrid, lds, a, grid);
+        PT_LAUNCH((pt_tile_kernel<PT_RENDERER_PATHTRACER, 4, false, true>), tgrid, lds, !path_tiled, a, grid);
     } else if (p->renderer == PT_RENDERER_ONOFF)
-      PT_LAUNCH((pt_tile_kernel<PT_RENDERER_ONOFF, 4, false>), tgrid, lds, a, 0);
+      PT_LAUNCH((pt_tile_kernel<PT_RENDERER_ONOFF, 4, false>), tgrid, lds, !path_tiled, a, 0);
     else if (p->renderer == PT_RENDERER_FLAT)
-      PT_LAUNCH((pt_tile_kernel<PT_RENDERER_FLAT, 4, false>), tgrid, lds, a, 0);
+      PT_LAUNCH((pt_tile_kernel<PT_RENDERER_FLAT, 4, false>), tgrid, lds, !path_tiled, a, 0);
     else if (p->renderer == PT_RENDERER_POINTLIGHT)
-      PT_LAUNCH((pt_tile_kernel<PT_RENDERER_POINTLIGHT, 3, false>), tgrid, lds, a, 0);
+      PT_LAUNCH((pt_tile_kernel<PT_RENDERER_POINTLIGHT, 3, false>), tgrid, lds, !path_tiled, a, 0);
     else
-      PT_LAUNCH((pt_tile_kernel<PT_RENDERER_PATHTRACER, 4, false>), tgrid, lds, a, grid);
+      PT_LAUNCH((pt_tile_kernel<PT_RENDERER_PATHTRACER, 4, false>), tgrid, lds, !path_tiled, a, grid);
     if (path_tiled) {
       // second pass: the pixels the first one flagged, fullest regions first
       static const int env_ppu = getenv("PTRACE_UNIT_LANES_CAP") ? atoi(getenv("PTRACE_UNIT_LANES_CAP")) : -1;  // 0: a unit = a region
@@ -975,38 +1001,38 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
                          env_ppu >= 0 ? (long long)env_ppu : lanes_cap, nsamp);
       if (lds_frames) {
         HIP_TRY(path_lds_limit((const void *)pt_path_regions_kernel<true>, lds + frame_lds + diag_lds_bytes));
-        PT_LAUNCH((pt_path_regions_kernel<true>), grid, lds + frame_lds + diag_lds_bytes, a);
+        PT_LAUNCH((pt_path_regions_kernel<true>), grid, lds + frame_lds + diag_lds_bytes, true, a);
       } else {
         HIP_TRY(path_lds_limit((const void *)pt_path_regions_kernel<false>, lds + diag_lds_bytes));
-        PT_LAUNCH((pt_path_regions_kernel<false>), grid, lds + diag_lds_bytes, a);
+        PT_LAUNCH((pt_path_regions_kernel<false>), grid, lds + diag_lds_bytes, true, a);
       }
     }
   } else
   switch (p->renderer) {
     case PT_RENDERER_ONOFF:
       if (hoist)
-        PT_LAUNCH((pt_simple_kernel<PT_RENDERER_ONOFF, true>), grid, 0, a);
+        PT_LAUNCH((pt_simple_kernel<PT_RENDERER_ONOFF, true>), grid, 0, true, a);
       else
-        PT_LAUNCH((pt_simple_kernel<PT_RENDERER_ONOFF, false>), grid, 0, a);
+        PT_LAUNCH((pt_simple_kernel<PT_RENDERER_ONOFF, false>), grid, 0, true, a);
       break;
     case PT_RENDERER_FLAT:
       if (hoist)
-        PT_LAUNCH((pt_simple_kernel<PT_RENDERER_FLAT, true>), grid, 0, a);
+        PT_LAUNCH((pt_simple_kernel<PT_RENDERER_FLAT, true>), grid, 0, true, a);
       else
-        PT_LAUNCH((pt_simple_kernel<PT_RENDERER_FLAT, false>), grid, 0, a);
+        PT_LAUNCH((pt_simple_kernel<PT_RENDERER_FLAT, false>), grid, 0, true, a);
       break;
     case PT_RENDERER_POINTLIGHT:
       if (hoist)
-        PT_LAUNCH((pt_simple_kernel<PT_RENDERER_POINTLIGHT, true>), grid, 0, a);
+        PT_LAUNCH((pt_simple_kernel<PT_RENDERER_POINTLIGHT, true>), grid, 0, true, a);
       else
-        PT_LAUNCH((pt_simple_kernel<PT_RENDERER_POINTLIGHT, false>), grid, 0, a);
+        PT_LAUNCH((pt_simple_kernel<PT_RENDERER_POINTLIGHT, false>), grid, 0, true, a);
       break;
     default:
       if (lds_frames) {
         HIP_TRY(path_lds_limit((const void *)pt_path_kernel<true>, frame_lds));
-        PT_LAUNCH((pt_path_kernel<true>), grid, frame_lds, a);
+        PT_LAUNCH((pt_path_kernel<true>), grid, frame_lds, true, a);
       } else {
-        PT_LAUNCH((pt_path_kernel<false>), grid, 0, a);
+        PT_LAUNCH((pt_path_kernel<false>), grid, 0, true, a);
       }
       break;
   }
@@ -1026,18 +1052,16 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
     s->stats.vgprs = regs;
   }
   if (prof) {
-    HIP_TRY(hipEventRecord(s->prof[2 * s->prof_used + 1], st));
     s->prof_used++;
     s->stats_valid = false;
   } else if (s->timing) {
-    HIP_TRY(hipEventRecord(s->ev1, st));
     s->stats_valid = true;
   } else {
     s->stats_valid = false;
   }
   if (s->count_rays) {
     hipLaunchKernelGGL(pt_sum_counts, dim3(1), dim3(256), 0, st, s->ray_partials, grid + grid_first, s->ray_counter);
-    HIP_TRY(hipMemcpyAsync(s->ray_counter_host, s->ray_counter, sizeof(unsigned long long),
+    HIP_TRY(hipMemcpyAsync(s->ray_counter_host, s->ray_counter, 2 * sizeof(unsigned long long),
                            hipMemcpyDeviceToHost, st));
     // ev1 was recorded BEFORE the count left the device: whoever reads ray_counter_host waits for this one
     HIP_TRY(hipEventRecord(s->ev_count, st));
@@ -1066,9 +1090,10 @@ static int fold_stats(pt_scene *s) {
   if (s->count_pending) {
     HIP_TRY(hipEventSynchronize(s->ev_count));
     s->count_pending = false;
-    s->stats.n_rays = *s->ray_counter_host;
+    s->stats.n_rays = s->ray_counter_host[0];
+    s->stats.n_rays_resolved = s->ray_counter_host[1];
   } else {
-    s->stats.n_rays = 0;  // (no pixels, or counting off)
+    s->stats.n_rays = s->stats.n_rays_resolved = 0;  // (no pixels, or counting off)
   }
   s->pending = false;
   s->pending_copy = false;

@@ -107,6 +107,10 @@ class DeviceScene:
     def set_count_rays(self, enable: bool) -> None:
         _lib.check(_lib.lib().pt_set_count_rays(self._h, int(bool(enable))))
 
+    def set_dome_shortcut(self, enable: bool) -> None:
+        """Measurement switch: off = every primary ray is generated and traced (same image)."""
+        _lib.check(_lib.lib().pt_set_dome_shortcut(self._h, int(bool(enable))))
+
     def set_timing(self, enable: bool) -> None:
         """hipEvent pair around each render kernel on/off (off: frames run back to back)."""
         _lib.check(_lib.lib().pt_set_timing(self._h, int(bool(enable))))
@@ -125,6 +129,13 @@ class DeviceScene:
         st = abi.Stats()
         _lib.check(_lib.lib().pt_get_stats(self._h, C.byref(st)))
         return st
+
+
+def device_info(device: int = 0) -> Tuple[int, int]:
+    """-> (compute units, peak shader clock in kHz)."""
+    cu, khz = C.c_int(0), C.c_int(0)
+    _lib.check(_lib.lib().pt_device_info(int(device), C.byref(cu), C.byref(khz)))
+    return int(cu.value), int(khz.value)
 
 
 def device_count() -> int:

@@ -2,7 +2,7 @@
 
 The GPU kernel cannot run here, so each rank's local renderer is the CPU oracle (allowed: tests may
 use the oracle as a stand-in); what is under test is pytracer_amd.dist — the interleaved row-block
-partition, the padded gather and the de-interleave — and the invariant that the assembled frame is
+partition and the gather straight into row-block order (one point-to-point transfer per remote block) — and the invariant that the assembled frame is
 bit-identical to the single-process frame (per-pixel seeds depend only on the global pixel index)."""
 import os
 import socket
@@ -80,3 +80,13 @@ def test_partition_helpers():
     assert ptdist.shard_rows(20, 8, 2, 1) == list(range(8, 16))
     assert ptdist.max_shard_rows(20, 8, 2) == 12
     assert ptdist.max_shard_rows(10, 8, 3) == 8
+    # (first row in the frame, first row in the compact shard, rows) per block
+    assert ptdist.shard_blocks(20, 8, 2, 0) == [(0, 0, 8), (16, 8, 4)]
+    assert ptdist.shard_blocks(20, 8, 2, 1) == [(8, 0, 8)]
+    assert ptdist.shard_blocks(10, 8, 3, 2) == []
+    for h, rb, w in ((2160, 8, 8), (721, 7, 3), (5, 8, 2)):
+        for r in range(w):
+            rows = [g0 + k for g0, _, n in ptdist.shard_blocks(h, rb, w, r) for k in range(n)]
+            assert rows == ptdist.shard_rows(h, rb, w, r)
+            assert [l0 for _, l0, _ in ptdist.shard_blocks(h, rb, w, r)] == \
+                [sum(n for _, _, n in ptdist.shard_blocks(h, rb, w, r)[:k]) for k in range(len(ptdist.shard_blocks(h, rb, w, r)))]

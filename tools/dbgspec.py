@@ -38,4 +38,8 @@ for name in sys.argv[1:]:
     print(f"{name:14s} kernel {st.kernel_ms:.3f} ms  units {units} (ppu {q[10]}, {q[9]} listed)  flagged pixels {kept // nsamp}  "
           f"pixel-rounds {rounds} = {rounds / max(1, kept // nsamp):.2f}/pixel (of {nsamp} samples)  "
           f"traced {traced} kept {kept} = {kept / max(1, traced):.2f}  kept/round {kept / max(1, rounds):.2f}", flush=True)
+    t = [q[i] for i in range(1, 9)]
+    names = ["0 unit/round handout", "1 start_sample", "2 tile query (P)", "3 -", "4 lane query (S)", "5 shade+unwind+scatter", "6 -", "7 loop top"]
+    tot = sum(t) or 1
+    print("   cycles per wave: " + "  ".join(f"{n}: {v / (st.grid * 4):.0f} ({100 * v / tot:.0f}%)" for n, v in zip(names, t) if v), flush=True)
     ds.close()
