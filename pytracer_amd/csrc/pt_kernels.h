@@ -543,17 +543,9 @@ PT_DEV int world_query_lanes(const PtKArgs &a, const Ray &r, double tmax, double
       }
       return g;
     };
-    bool has = mask != 0ULL;
-    int slot = base + (has ? __ffsll((long long)mask) - 1 : 0);
-    mask &= mask - 1ULL;
-    DiagL g = fetch(slot);
-    while (__ballot(has) != 0ULL) {
-      const bool has_next = mask != 0ULL;
-      const int slot_next = base + (has_next ? __ffsll((long long)mask) - 1 : 0);
-      mask &= mask - 1ULL;
-      const DiagL g_next = fetch(slot_next);
-      // the object-space ray: shapes.py:102, full product or (bit-identical under the guard) o*s + t, d*s
-      double ox, oy, oz, dx, dy, dz;
+    // the object-space ray of candidate `slot`: shapes.py:102, full product or (bit-identical under the guard) o*s + t, d*s
+    auto object_ray = [&](int slot, bool has, const DiagL &g, double &ox, double &oy, double &oz, double &dx, double &dy,
+                          double &dz) {
       if (!has || (slot < nd && lane_fast && (ozmask & ~(unsigned)g.tnz) == 0u)) {  // (!has: values unused)
         dx = r.d.x * g.s0;
         dy = r.d.y * g.s1;
@@ -570,31 +562,48 @@ PT_DEV int world_query_lanes(const PtKArgs &a, const Ray &r, double tmax, double
         oy = r.o.x * m[4] + r.o.y * m[5] + r.o.z * m[6] + m[7];
         oz = r.o.x * m[8] + r.o.y * m[9] + r.o.z * m[10] + m[11];
       }
-      const LatCand c = lat_cand(ox, oy, oz, dx, dy, dz);
-      const bool need = has && c.delta > 0.0 && !(c.bb > 1e-100 && c.cc >= 0.0);
-      if (__ballot(need) != 0ULL) {
-        double t1, t2 = 0.0;
-        PT_LAT_ROOT1(c, t1);
-        if (__ballot(need && !PT_LAT_INRANGE(t1)) != 0ULL) PT_LAT_ROOT2(c, t2);
-        const bool ok1 = PT_LAT_INRANGE(t1);
-        const double t = ok1 ? t1 : t2;
-        const bool ok = ok1 || PT_LAT_INRANGE(t2);
-        if (need && ok) {
-          bool take = t < best_t;
-          if (!ANYHIT && !take && t == best_t && best >= 0) take = a.recs[slot].index < a.recs[best].index;
-          if (take) {
-            best_t = t;
-            best = slot;
-          }
+    };
+    auto take_if_closer = [&](int slot, bool need, bool ok, double t) {
+      if (need && ok) {
+        bool take = t < best_t;
+        if (!ANYHIT && !take && t == best_t && best >= 0) take = a.recs[slot].index < a.recs[best].index;
+        if (take) {
+          best_t = t;
+          best = slot;
         }
       }
-      g = g_next;
-      slot = slot_next;
-      has = has_next;
-      if (ANYHIT && best >= 0) {  // this lane is blocked: nothing more to look at
-        has = false;
-        mask = 0ULL;
+    };
+    // Two candidates of the lane's list per iteration: a visit is a chain of dependent fp64 operations
+    // (transform, discriminant, sqrt, division) that a single wave cannot overlap with anything but another,
+    // independent visit.  The winner does not depend on the order of visits (ties go by World.shapes index).
+    while (__ballot(mask != 0ULL) != 0ULL) {
+      const bool has_a = mask != 0ULL;
+      const int slot_a = base + (has_a ? __ffsll((long long)mask) - 1 : 0);
+      mask &= mask - 1ULL;
+      // (shadow rays stop at their first blocker and run at three waves per SIMD: one visit at a time there)
+      const bool has_b = !ANYHIT && mask != 0ULL;
+      const int slot_b = base + (has_b ? __ffsll((long long)mask) - 1 : 0);
+      if (!ANYHIT) mask &= mask - 1ULL;
+      const DiagL ga = fetch(slot_a), gb = fetch(slot_b);
+      double oxa, oya, oza, dxa, dya, dza, oxb, oyb, ozb, dxb, dyb, dzb;
+      object_ray(slot_a, has_a, ga, oxa, oya, oza, dxa, dya, dza);
+      object_ray(slot_b, has_b, gb, oxb, oyb, ozb, dxb, dyb, dzb);
+      const LatCand ca = lat_cand(oxa, oya, oza, dxa, dya, dza), cb = lat_cand(oxb, oyb, ozb, dxb, dyb, dzb);
+      const bool need_a = has_a && ca.delta > 0.0 && !(ca.bb > 1e-100 && ca.cc >= 0.0);
+      const bool need_b = has_b && cb.delta > 0.0 && !(cb.bb > 1e-100 && cb.cc >= 0.0);
+      if (__ballot(need_a || need_b) != 0ULL) {
+        double t1a, t1b, t2a = 0.0, t2b = 0.0;
+        PT_LAT_ROOT1(ca, t1a);
+        PT_LAT_ROOT1(cb, t1b);
+        if (__ballot((need_a && !PT_LAT_INRANGE(t1a)) || (need_b && !PT_LAT_INRANGE(t1b))) != 0ULL) {
+          PT_LAT_ROOT2(ca, t2a);
+          PT_LAT_ROOT2(cb, t2b);
+        }
+        const bool ok1a = PT_LAT_INRANGE(t1a), ok1b = PT_LAT_INRANGE(t1b);
+        take_if_closer(slot_a, need_a, ok1a || PT_LAT_INRANGE(t2a), ok1a ? t1a : t2a);
+        take_if_closer(slot_b, need_b, ok1b || PT_LAT_INRANGE(t2b), ok1b ? t1b : t2b);
       }
+      if (ANYHIT && best >= 0) mask = 0ULL;  // this lane is blocked: nothing more to look at
 #ifdef PT_DEBUG_TIME
       dbg_it++;
 #endif
@@ -2025,8 +2034,12 @@ PT_DEV long long next_pixel(const PtKArgs &a, bool need, long long npix) {
 // does not depend on how regions are cut into units or how many lanes a pixel gets.
 // LAT: the second pass is built for few waves per SIMD; its time is set by chains of dependent steps:
 // everything inline, registers no object.
+#ifndef PT_REGIONS_INLINE
+#define PT_REGIONS_INLINE 1  // second pass: HitRecord / scatter / transcendental code inline (1) or behind calls (0)
+#endif
 template <bool TILED, bool LDSF, bool LAT>
 PT_DEV void path_trace(const PtKArgs &a) {
+  constexpr bool INL = LAT && PT_REGIONS_INLINE;
   PathCtx w;
   int S, nsamp, N, W = 0, rows_local = 0, npass = 0, D = 0, rr = 0, diag_lds = -1, pcg_mode = PT_PCG_PIXEL;
   bool ortho = false;
@@ -2146,7 +2159,7 @@ PT_DEV void path_trace(const PtKArgs &a) {
     const bool uv = ax->needs_uv != 0;
     bool details = false;
     if (uv) {
-      if (LAT)
+      if (INL)
         hit_details<true>(a.recs + hit, ax, ray, best_t, h, true);
       else
         hit_details_call(a.recs + hit, ax, &ray, best_t, &h, true);
@@ -2196,7 +2209,7 @@ PT_DEV void path_trace(const PtKArgs &a) {
     }
     // render.py:126-137: push the frame, child 0 is scattered at the next S-step
     if (!details) {
-      if (LAT)
+      if (INL)
         hit_details<true>(a.recs + hit, ax, ray, best_t, h, false);
       else
         hit_details_call(a.recs + hit, ax, &ray, best_t, &h, false);
@@ -2281,6 +2294,13 @@ PT_DEV void path_trace(const PtKArgs &a) {
 #endif
   for (;;) {
     PT_STAMP(7);
+    // (values that never flow from one iteration into the next: said explicitly, so that they hold no
+    //  registers across the queries)
+    spawn = false;
+    f_wp = {0.0, 0.0, 0.0};
+    f_n = {0.0, 0.0, 1.0};
+    f_in = {1.0, 0.0, 0.0};
+    f_brdf = 0;
     // ---- work for idle lanes ----
     if (TILED) {
       if (!__any(mode == 0 || mode == 1)) {
@@ -2501,7 +2521,7 @@ PT_DEV void path_trace(const PtKArgs &a) {
     while (unwinding) {
       if (spawn) {
         // scatter_ray consumes its draws even when the child is beyond max_depth
-        if (LAT)
+        if (INL)
           ray = scatter_ray<true>(f_brdf, pcg, f_in, f_wp, f_n);
         else
           scatter_ray_call(f_brdf, &pcg, &f_in, &f_wp, &f_n, &ray);
