@@ -379,6 +379,12 @@ PT_DEV LatCand lat_cand(double ox, double oy, double oz, double dx, double dy, d
   return c;
 }
 
+#ifndef PT_SPARSE_RAYS
+#define PT_SPARSE_RAYS 16  // world_query_lanes: at most this many live rays -> one ball per lane, rays take turns
+#endif
+#ifndef PT_SPARSE_MAX_SPHERES
+#define PT_SPARSE_MAX_SPHERES 1024  // ... in scenes up to this size (beyond, skipping whole chunks and groups pays more)
+#endif
 #ifdef PT_DEBUG_TIME
 __device__ unsigned long long pt_dbg[8];  // world_query_lanes: prefilter cycles, walk cycles, iterations, calls; 4..7: units / rounds
 #define PT_DBG_WAVES 16384
@@ -471,11 +477,53 @@ PT_DEV int world_query_lanes(const PtKArgs &a, const Ray &r, double tmax, double
   const int levels = a.bs_levels;
   pt_kfloat gsx = bsr + a.bs_stride, gsy = gsx + a.gs_stride, gsz = gsy + a.gs_stride, gsr = gsz + a.gs_stride;
   pt_kfloat csx = gsr + a.gs_stride, csy = csx + a.cs_stride, csz = csy + a.cs_stride, csr = csz + a.cs_stride;
+  // the same test for ONE ball, the ray's constants given explicitly (scalar form, see the sparse path below)
+  auto reject1 = [&](float cx, float cy, float cz, float cr, float sox, float soy, float soz, float sdx, float sdy,
+                     float sdz, float sdd, float seo, float sdd8) {
+    const float vx = cx - sox, vy = cy - soy, vz = cz - soz;
+    const float vd = vx * sdx + vy * sdy + vz * sdz;
+    const float vv = vx * vx + vy * vy + vz * vz;
+    const float t = vd * vd;
+    const float q = vv * sdd - t;
+    const float rk = cr + seo;
+    const float rdd = (rk * rk) * sdd;
+    const float slack = vv * sdd8;
+    const float rhs = rdd + slack, rhs_b = rdd * 1.001f + slack;
+    bool rej = (q > rhs) || (vd < 0.0f && t > rhs_b);
+    if (ANYHIT) {
+      const float wd = vd - tmaxf_dd * sdd;
+      rej = rej || (wd > 0.0f && wd * wd > rhs_b);
+    }
+    return rej;
+  };
   for (int base = 0; base < ns; base += 64) {
     const int cnt = ns - base < 64 ? ns - base : 64;
     unsigned long long mask = 0ULL;
     unsigned gtouch = 0xffu;  // groups of the chunk some lane may touch (wave-uniform)
     const bool live = active && !(ANYHIT && best >= 0);
+    const unsigned long long live_lanes = __ballot(live);
+    if (live_lanes == 0ULL) continue;
+    if (!ANYHIT && ns <= PT_SPARSE_MAX_SPHERES && __popcll(live_lanes) <= PT_SPARSE_RAYS) {
+      // Few rays in flight (the deep stragglers of a round): turn the loop around.  Every lane holds ONE ball of
+      // the chunk (coalesced load, once) and the rays take turns: a ray's constants are broadcast from its
+      // lane, all 64 balls are tested at once, and the ballot IS that ray's candidate mask.  ~35 instructions
+      // per ray and chunk instead of ~800 per chunk for the whole wave.
+      const int sl = base + (threadIdx.x & 63);
+      const float bx = ((const float *)a.bsoa)[sl], by = ((const float *)a.bsoa)[a.bs_stride + sl],
+                  bz = ((const float *)a.bsoa)[2 * a.bs_stride + sl], br = ((const float *)a.bsoa)[3 * a.bs_stride + sl];
+      const bool mine = (int)(threadIdx.x & 63) < cnt;
+      unsigned long long todo = live_lanes;
+      while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1ULL;
+#define PT_BCAST(x) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), src))
+        const bool rej = reject1(bx, by, bz, br, PT_BCAST(ofx), PT_BCAST(ofy), PT_BCAST(ofz), PT_BCAST(dfx), PT_BCAST(dfy),
+                                 PT_BCAST(dfz), PT_BCAST(dd), PT_BCAST(eo), PT_BCAST(dd8));
+#undef PT_BCAST
+        const unsigned long long m = __ballot(mine && !rej);
+        if ((int)(threadIdx.x & 63) == src) mask = m;
+      }
+    } else {
     if (levels) {
       const int c = base >> 6;
       bool r0, r1;
@@ -501,6 +549,7 @@ PT_DEV int world_query_lanes(const PtKArgs &a, const Ray &r, double tmax, double
         m8 |= (rej0 ? 0u : 1u << k) | (rej1 ? 0u : 2u << k);
       }
       mask |= (unsigned long long)m8 << j;
+    }
     }
     if (cnt < 64) mask &= (1ULL << cnt) - 1ULL;
     if (!live) mask = 0ULL;

@@ -9,7 +9,8 @@ W, H = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1280, 720
 nsph = int(sys.argv[3]) if len(sys.argv) > 3 else 32
 flat = flatten.flatten_world(scenes.synthetic_world(nsph, wide=nsph > 64))
 cam = flatten.flatten_camera(scenes.synthetic_camera(W, H))
-par = abi.make_params(W, H, abi.RENDERER_PATHTRACER, samples_per_side=int(os.environ.get('DBG_S', 4)), num_of_rays=int(os.environ.get('DBG_N', 1)), max_depth=3, rr_limit=3, path_state=45, path_seq=54)
+par = abi.make_params(W, H, abi.RENDERER_PATHTRACER, samples_per_side=int(os.environ.get('DBG_S', 4)), num_of_rays=int(os.environ.get('DBG_N', 1)), max_depth=int(os.environ.get('DBG_D', 3)), rr_limit=3, path_state=45, path_seq=54,
+                      pcg_mode=int(os.environ.get('DBG_MODE', 1)), n_ranks=int(os.environ.get('DBG_RANKS', 1)), rank=int(os.environ.get('DBG_RANK', 0)), row_block=8)
 ds = DeviceScene(flat)
 for _ in range(2):
     out = ds.render(cam, par)
@@ -35,7 +36,7 @@ if os.environ.get("DBG_TRACE"):
         agg[k][1] += t
     for k in sorted(agg):
         print(f"stamp {k}: n={agg[k][0]} total={agg[k][1]} ticks avg={agg[k][1]/agg[k][0]:.1f}")
-    print("first 80:", " ".join(f"{k}:{t}({npth})" for t, npth, k in rows[:80]))
+    print("first 160:", " ".join(f"{k}:{t}({npth})" for t, npth, k in rows[:160]))
 
 if os.environ.get("DBG_LANES"):
     d = (C.c_ulonglong * 8)()
