@@ -1998,6 +1998,10 @@ PT_DEV int nth_set_bit(unsigned long long m, int n) {
 #ifdef PT_DEBUG_TIME
 #define PT_TRACE_LEN 8192
 __device__ unsigned long long pt_trace[PT_TRACE_LEN];
+#define PT_UNITLOG_LEN 16384
+// per work unit of the second pass: start tick, end tick, rounds | iterations << 32, pixels | lanes per pixel << 8 |
+// workgroup << 16, then the unit's cycles in: scattered-ray queries, shade, sample start + primary query, commit + fetch
+__device__ unsigned long long pt_unitlog[PT_UNITLOG_LEN * 8];
 #endif
 
 // ---- PathTracer (render.py:99-139) as a per-lane state machine ----------------------------------------
@@ -2328,6 +2332,8 @@ PT_DEV void path_trace(const PtKArgs &a) {
   unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
   bool tracing = false;
   int trace_n = 0;
+  int ulog_seq = -1, ulog_rounds = 0, ulog_iters = 0;
+  unsigned long long ulog_t[4] = {0, 0, 0, 0};
 #define PT_STAMP(k)                                                                        \
   do {                                                                                     \
     const unsigned long long tn = __builtin_amdgcn_s_memtime();                            \
@@ -2360,6 +2366,7 @@ PT_DEV void path_trace(const PtKArgs &a) {
           const bool fin = mode == 3;
           bool chain = true;
 #ifdef PT_DEBUG_TIME
+          ulog_rounds++;
           const int dbg_vbase0 = vbase;
           int dbg_fin = 0;
 #endif
@@ -2445,7 +2452,22 @@ PT_DEV void path_trace(const PtKArgs &a) {
           }
           const int seq = (int)__builtin_amdgcn_readfirstlane((int)uid);
 #ifdef PT_DEBUG_TIME
-          tracing = seq == 0;
+          tracing = seq == cold_args(a)->dbg_trace_unit;
+          if (lane == 0 && ulog_seq >= 0 && ulog_seq < PT_UNITLOG_LEN) {  // close the log entry of the unit just finished
+            pt_unitlog[ulog_seq * 8 + 1] = __builtin_amdgcn_s_memtime();
+            pt_unitlog[ulog_seq * 8 + 2] = (unsigned long long)ulog_rounds | ((unsigned long long)ulog_iters << 32);
+            pt_unitlog[ulog_seq * 8 + 4] = tsum[4] - ulog_t[0];
+            pt_unitlog[ulog_seq * 8 + 5] = tsum[5] - ulog_t[1];
+            pt_unitlog[ulog_seq * 8 + 6] = tsum[1] + tsum[2] - ulog_t[2];
+            pt_unitlog[ulog_seq * 8 + 7] = tsum[0] - ulog_t[3];
+          }
+          ulog_t[0] = tsum[4];
+          ulog_t[1] = tsum[5];
+          ulog_t[2] = tsum[1] + tsum[2];
+          ulog_t[3] = tsum[0];
+          ulog_seq = seq;
+          ulog_rounds = 0;
+          ulog_iters = 0;
 #endif
           pt_kargs ca = cold_args(a);
           if (seq >= (int)ca->queue[9]) break;  // (written by pt_unit_sort, before this kernel started)
@@ -2473,6 +2495,12 @@ PT_DEV void path_trace(const PtKArgs &a) {
           // lanes [p * L, (p + 1) * L) take the unit's p-th pixel = flagged pixel `first + p` of the region
           L = 64 / count;
           if (L > nsamp) L = nsamp;
+#ifdef PT_DEBUG_TIME
+          if (lane == 0 && seq < PT_UNITLOG_LEN) {
+            pt_unitlog[seq * 8 + 0] = __builtin_amdgcn_s_memtime();
+            pt_unitlog[seq * 8 + 3] = (unsigned long long)count | ((unsigned long long)L << 8) | ((unsigned long long)blockIdx.x << 16);
+          }
+#endif
           const int pidx = lane / L;
           in_unit = pidx < count;
           leader = in_unit ? pidx * L : lane;
@@ -2518,6 +2546,9 @@ PT_DEV void path_trace(const PtKArgs &a) {
     }
 
     PT_STAMP(0);
+#ifdef PT_DEBUG_TIME
+    ulog_iters++;
+#endif
     const int n_start = __popcll(__ballot(mode == 0));
     const int n_path = __popcll(__ballot(mode == 1));
     if (n_start == 0 && n_path == 0) continue;  // TILED: nothing in flight, the round / unit logic above decides

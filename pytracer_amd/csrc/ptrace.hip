@@ -891,6 +891,8 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
     // first pass settles, per pixel, what can only hit that sphere (pt_tile_kernel re-checks every condition
     // from the exact hoisted constants; this only names the candidate).
     a.dome_slot = -1;
+    static const int env_trace = getenv("PTRACE_TRACE_UNIT") ? atoi(getenv("PTRACE_TRACE_UNIT")) : 0;
+    a.dbg_trace_unit = env_trace;
     static const int env_dome = getenv("PTRACE_PIXEL_DOME") ? atoi(getenv("PTRACE_PIXEL_DOME")) : 1;
     if (!ortho && env_dome) {
       const double ox = -cam->screen_distance * cam->m[0] + cam->m[3], oy = -cam->screen_distance * cam->m[4] + cam->m[7],
@@ -1362,6 +1364,11 @@ extern "C" int pt_debug_read_dbg(unsigned long long *out8, int reset) {
     unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(pt_dbg), z, sizeof z));
   }
+  return PT_OK;
+}
+extern "C" int pt_debug_read_unitlog(unsigned long long *out, int n_units) {
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(pt_unitlog), (size_t)std::min(n_units, PT_UNITLOG_LEN) * 8 * sizeof(unsigned long long)));
   return PT_OK;
 }
 extern "C" int pt_debug_read_trace(unsigned long long *out, int n) {

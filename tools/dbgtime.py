@@ -12,7 +12,7 @@ cam = flatten.flatten_camera(scenes.synthetic_camera(W, H))
 par = abi.make_params(W, H, abi.RENDERER_PATHTRACER, samples_per_side=int(os.environ.get('DBG_S', 4)), num_of_rays=int(os.environ.get('DBG_N', 1)), max_depth=int(os.environ.get('DBG_D', 3)), rr_limit=3, path_state=45, path_seq=54,
                       pcg_mode=int(os.environ.get('DBG_MODE', 1)), n_ranks=int(os.environ.get('DBG_RANKS', 1)), rank=int(os.environ.get('DBG_RANK', 0)), row_block=8)
 ds = DeviceScene(flat)
-for _ in range(2):
+for _ in range(1):
     out = ds.render(cam, par)
 q = (C.c_ulonglong * 16)()
 _lib.lib().pt_debug_read_queue(ds._h, q)
