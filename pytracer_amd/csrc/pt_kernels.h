@@ -1548,14 +1548,138 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
 #else
 #define PT_TSTAMP(k) do { } while (0)
 #endif
-  for (int tile = blockIdx.x * (PT_BLOCK / 64) + wib; tile < ntiles; tile += nwaves) {
+  // The value of a pixel all of whose primary rays are certain to end on sphere `only` with the camera well
+  // inside it (hoisted c = hc_ < -0.5; see the comment at the per-tile check below): false when the conditions
+  // do not hold for a tile whose directions are bounded by dmax2 / dmin; else `cum` is the pixel (the S*S
+  // additions and the final scaling of imagetracer.py:83-101 replayed) and `settled` says whether it is final
+  // (PointLight needs the hit point; a path tracer whose dome scatters light goes to the second pass).
+  auto dome_value = [&](int only, double hc_, float dmax2, float dmin, bool all, V3 &cum, bool &settled) -> bool {
+    pt_kargs ca = cold_args(a);
+    const PtShapeAux *ax = ca->aux + only;
+    const float fro2 = (float)PT_KD(&a.recs[only])[13];  // PtShapeRec::fro2
+    settled = false;
+    cum = {0.0, 0.0, 0.0};
+    if (RENDERER == PT_RENDERER_POINTLIGHT) return false;
+    if (!(hc_ < -0.5 && fro2 * dmax2 < 1e6f && dmin > 1e-6f && !all && ax->needs_uv == 0)) return false;
+    V3 c;
+    settled = true;
+    if (RENDERER == PT_RENDERER_ONOFF) {
+      c.x = ca->onoff[0];
+      c.y = ca->onoff[1];
+      c.z = ca->onoff[2];
+    } else if (RENDERER == PT_RENDERER_FLAT) {
+      const V3 p1 = brdf_pigment(a, ax, 0.0, 0.0), p2 = emitted_pigment(a, ax, 0.0, 0.0);
+      c.x = p1.x + p2.x;
+      c.y = p1.y + p2.y;
+      c.z = p1.z + p2.z;
+    } else {
+      const V3 hc = brdf_pigment(a, ax, 0.0, 0.0), em = emitted_pigment(a, ax, 0.0, 0.0);
+      const double lum = max2(max2(hc.x, hc.y), hc.z);
+      settled = !(ca->rr <= 0 || lum > 0.0);  // else every pixel goes to the second pass
+      const double invN = 1.0 / (double)ca->N;
+      c.x = em.x + 0.0 * invN;
+      c.y = em.y + 0.0 * invN;
+      c.z = em.z + 0.0 * invN;
+    }
+    cum = c;
+    if (S > 0) {  // imagetracer.py:83-101: the same additions, the same final scaling
+      cum.x = 0.0;
+      cum.y = 0.0;
+      cum.z = 0.0;
+      for (int s = 0; s < nsamp; ++s) {
+        cum.x = cum.x + c.x;
+        cum.y = cum.y + c.y;
+        cum.z = cum.z + c.z;
+      }
+      const double k = 1.0 / (double)(S * S);
+      cum.x = cum.x * k;
+      cum.y = cum.y * k;
+      cum.z = cum.z * k;
+    }
+    return true;
+  };
+  // A workgroup takes a STRIP of four tiles (32 x 8 pixels, one block of rows), one tile per wave.  Where the
+  // whole strip can only see the dome -- most of a frame under an open sky -- one cull settles all four:
+  // the four waves share its passes (wave w looks at shapes [64 w, 64 w + 64), [64 (w + 4), ...), ...) and add
+  // their survivor counts up through LDS.  Otherwise every wave culls its own tile as before.
+  const int strips_x = (tiles_x + 3) >> 2;
+  const int nstrips = strips_x * tiles_y;
+  (void)ntiles;
+  (void)nwaves;
+  // (with a single pass per cull there is nothing to share: the strip's verdict would only delay the tiles)
+  const bool use_strips = dome_on && !ORTHO && !HIER && RENDERER != PT_RENDERER_POINTLIGHT && npass >= 2;
+  __shared__ int strip_ns[2][PT_BLOCK / 64], strip_only[2][PT_BLOCK / 64];
+  int parity = 0;
+  for (int strip = blockIdx.x; strip < nstrips; strip += gridDim.x) {
+   const int ty = strip / strips_x, tx_first = (strip - ty * strips_x) * 4;
+   const int tx_end = tx_first + 4 < tiles_x ? tx_first + 4 : tiles_x;
+   bool strip_dome = false, strip_settled = false;
+   V3 strip_cum = {0.0, 0.0, 0.0};
+   if (use_strips) {
+     const int sgr0 = global_row(a, ty * 8);
+     const int sgr1 = global_row(a, (ty * 8 + 7 < rows_local) ? ty * 8 + 7 : rows_local - 1);
+     const TileCone sc = tile_cone(a, tx_first * 8, (tx_end * 8 < W) ? tx_end * 8 : W, sgr0, sgr1);
+     int ns_ = 0, only_ = 0;
+     for (int p = wib; p < npass && ns_ <= 1; p += PT_BLOCK / 64) {
+       const int slot = p * 64 + lane;
+       bool keep = false;
+       float4 b = {0.0f, 0.0f, 0.0f, -1.0f};
+       if (slot < a.n_shapes) b = a.bounds[slot];
+       const bool isplane = slot >= a.n_spheres && slot < a.n_shapes;
+       if (slot < a.n_spheres) keep = cone_keeps(sc, b);
+       if (__any(isplane)) {
+         const bool pk = plane_keeps(sc, b, isplane);
+         if (isplane) keep = pk;
+       }
+       const unsigned long long m = __ballot(keep);
+       ns_ += __popcll(m);
+       if (m) only_ = p * 64 + (__ffsll((long long)m) - 1);
+     }
+     if (lane == 0) {
+       strip_ns[parity][wib] = ns_;
+       strip_only[parity][wib] = only_;
+     }
+     __syncthreads();  // (one barrier per strip: the buffers alternate, so nobody overwrites what a slower wave still reads)
+     int tot = 0, only_all = 0;
+#pragma unroll
+     for (int w = 0; w < PT_BLOCK / 64; ++w) {
+       const int nw = strip_ns[parity][w];
+       tot += nw;
+       if (nw) only_all = strip_only[parity][w];
+     }
+     parity ^= 1;
+     if (tot == 1 && only_all < a.n_spheres) {
+       const double hc_ = (only_all < a.n_diag) ? PT_KD(&a.hoist_diag[only_all])[6] : PT_KD(&a.hoist[only_all])[3];
+       strip_dome = dome_value(only_all, hc_, sc.dmax2, sc.dmin, sc.all, strip_cum, strip_settled);
+     }
+   }
+   {
+    const int tx = tx_first + wib;
+    if (tx >= tx_end) continue;
+    const int tile = ty * tiles_x + tx;
     PT_TSTAMP(7);
-    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int col = tx * 8 + (lane & 7), lrow = ty * 8 + (lane >> 3);
     const bool active = col < W && lrow < rows_local;
     // clamp so that idle lanes of edge tiles stand on a real pixel (they only widen nothing)
     const int ccol = col < W ? col : W - 1, clrow = lrow < rows_local ? lrow : rows_local - 1;
     const long long pix = (long long)clrow * W + ccol;
+    if (strip_dome) {  // (settled by the strip's cull: nothing but the dome can be seen from these four tiles)
+      if (strip_settled && active) {
+        store_pixel(a, pix, strip_cum);
+        nrays += (unsigned long long)nsamp;
+        nres += (unsigned long long)nsamp;
+      }
+      if (RENDERER == PT_RENDERER_PATHTRACER) {
+        const unsigned long long todo = strip_settled ? 0ULL : __ballot(active);
+        if (lane == 0) {
+          pt_kargs ca = cold_args(a);
+          ca->region_mask[tile] = todo;
+          ca->region_keys[tile] = (unsigned char)__popcll(todo);
+            if (todo) atomicAdd(ca->queue + 11, (unsigned long long)__popcll(todo));  // F: flagged pixels of the frame
+        }
+      }
+      continue;
+    }
     const int pcol = ccol, grow = global_row(a, clrow);
 
     PT_TSTAMP(0);
@@ -1636,12 +1760,10 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
     // number for the frame.
     if (dome_on && nsurv == 1 && only < a.n_spheres) {
       only = __builtin_amdgcn_readfirstlane(only);
-      pt_kargs ca = cold_args(a);
-      const PtShapeAux *ax = ca->aux + only;
-      const float fro2 = (float)PT_KD(&a.recs[only])[13];  // PtShapeRec::fro2
       double hc_;
       float dmax2 = tc.dmax2, dmin = tc.dmin;
       if (ORTHO) {
+        const float fro2 = (float)PT_KD(&a.recs[only])[13];  // PtShapeRec::fro2
         pt_kdouble m = PT_KD(a.recs[only].invm);
         const float ox = (float)m[0] * tc.kx + (float)m[1] * tc.ky + (float)m[2] * tc.kz + (float)m[3];
         const float oy = (float)m[4] * tc.kx + (float)m[5] * tc.ky + (float)m[6] * tc.kz + (float)m[7];
@@ -1660,62 +1782,25 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
       } else {
         hc_ = (only < a.n_diag) ? PT_KD(&a.hoist_diag[only])[6] : PT_KD(&a.hoist[only])[3];
       }
-      if (hc_ < -0.5 && fro2 * dmax2 < 1e6f && dmin > 1e-6f && !tc.all && ax->needs_uv == 0) {
-        V3 c;
-        bool settled = true;
-        if (RENDERER == PT_RENDERER_ONOFF) {
-          c.x = ca->onoff[0];
-          c.y = ca->onoff[1];
-          c.z = ca->onoff[2];
-        } else if (RENDERER == PT_RENDERER_FLAT) {
-          const V3 p1 = brdf_pigment(a, ax, 0.0, 0.0), p2 = emitted_pigment(a, ax, 0.0, 0.0);
-          c.x = p1.x + p2.x;
-          c.y = p1.y + p2.y;
-          c.z = p1.z + p2.z;
-        } else if (RENDERER == PT_RENDERER_PATHTRACER) {
-          const V3 hc = brdf_pigment(a, ax, 0.0, 0.0), em = emitted_pigment(a, ax, 0.0, 0.0);
-          const double lum = max2(max2(hc.x, hc.y), hc.z);
-          settled = !(ca->rr <= 0 || lum > 0.0);  // else every pixel goes to the second pass
-          const double invN = 1.0 / (double)ca->N;
-          c.x = em.x + 0.0 * invN;
-          c.y = em.y + 0.0 * invN;
-          c.z = em.z + 0.0 * invN;
-        } else {
-          settled = false;  // PointLight needs the hit point: the ordinary path
+      V3 cum;
+      bool settled;
+      if (dome_value(only, hc_, dmax2, dmin, tc.all, cum, settled)) {
+        if (settled && active) {
+          store_pixel(a, pix, cum);
+          nrays += (unsigned long long)nsamp;
+          nres += (unsigned long long)nsamp;
         }
-        if (RENDERER != PT_RENDERER_POINTLIGHT) {
-          if (settled) {
-            V3 cum = c;
-            if (S > 0) {  // imagetracer.py:83-101: the same additions, the same final scaling
-              cum.x = 0.0;
-              cum.y = 0.0;
-              cum.z = 0.0;
-              for (int s = 0; s < nsamp; ++s) {
-                cum.x = cum.x + c.x;
-                cum.y = cum.y + c.y;
-                cum.z = cum.z + c.z;
-              }
-              const double k = 1.0 / (double)(S * S);
-              cum.x = cum.x * k;
-              cum.y = cum.y * k;
-              cum.z = cum.z * k;
-            }
-            if (active) {
-              store_pixel(a, pix, cum);
-              nrays += (unsigned long long)nsamp;
-              nres += (unsigned long long)nsamp;
-            }
+        if (RENDERER == PT_RENDERER_PATHTRACER) {
+          const unsigned long long todo = settled ? 0ULL : __ballot(active);
+          if (lane == 0) {
+            pt_kargs ca = cold_args(a);
+            ca->region_mask[tile] = todo;
+            ca->region_keys[tile] = (unsigned char)__popcll(todo);
+            if (todo) atomicAdd(ca->queue + 11, (unsigned long long)__popcll(todo));  // F: flagged pixels of the frame
           }
-          if (RENDERER == PT_RENDERER_PATHTRACER) {
-            const unsigned long long todo = settled ? 0ULL : __ballot(active);
-            if (lane == 0) {
-              ca->region_mask[tile] = todo;
-              ca->region_keys[tile] = (unsigned char)__popcll(todo);
-            }
-          }
-          __builtin_amdgcn_wave_barrier();  // the next tile overwrites this wave's mask slice
-          continue;
         }
+        __builtin_amdgcn_wave_barrier();  // the next tile overwrites this wave's mask slice
+        continue;
       }
     }
 
@@ -1786,6 +1871,7 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
         if (lane == 0) {
           ca->region_mask[tile] = todo;
           ca->region_keys[tile] = (unsigned char)__popcll(todo);
+            if (todo) atomicAdd(ca->queue + 11, (unsigned long long)__popcll(todo));  // F: flagged pixels of the frame
         }
         __builtin_amdgcn_wave_barrier();  // the next tile overwrites this wave's mask slice
         continue;
@@ -1893,10 +1979,12 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
         pt_kargs c = cold_args(a);
         c->region_mask[tile] = todo;
         c->region_keys[tile] = (unsigned char)__popcll(todo);
+        if (todo) atomicAdd(c->queue + 11, (unsigned long long)__popcll(todo));
       }
     }
     __builtin_amdgcn_wave_barrier();  // the next tile overwrites this wave's mask slice
     PT_TSTAMP(6);
+   }
   }
 #ifdef PT_DEBUG_TIME
   // sampled (every 64th workgroup) so that the report's own atomics do not disturb the other waves
@@ -1915,69 +2003,61 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
 // from the frame's total F of flagged pixels: with few of them (a rank's share of a frame, a sparse frame) a
 // region is cut into several units so that the whole chip works on samples in parallel instead of a few
 // waves walking their pixels' S*S samples one after the other; with many, ppu = 64 (a unit = a region) and
-// nothing is spent on idle lanes.  Units with the most pixels start first (counting sort by size, descending):
-// they have the fewest lanes per pixel, hence the longest chains.  Regions without flagged pixels yield
-// nothing.  The order only changes WHEN a pixel is rendered, never its value.
-// one workgroup: F -> ppu -> histogram of unit sizes -> descending offsets -> scatter
-// queue[0] = queue head (reset), queue[9] = number of units, queue[10] = ppu (for the statistics)
-__global__ void pt_unit_sort(const unsigned char *keys, int n, int2 *units, int units_cap, unsigned long long *queue,
-                             long long lanes_cap, int nsamp) {
-  __shared__ int hist[65];
+// nothing is spent on idle lanes.  Regions without flagged pixels yield nothing.  The order of the units only
+// changes WHEN a pixel is rendered, never its value.
+// Units with the most pixels come first (they have the fewest lanes per pixel, hence the longest chains): a
+// counting sort by size over two launches of any number of workgroups, one region per thread -- pt_unit_hist
+// counts the units of every size, pt_unit_scatter turns the counts into descending offsets (every workgroup for
+// itself: 64 numbers) and places the units.
+// queue[0] = queue head, [9] = number of units, [10] = ppu (for the statistics), [11] = F (summed up by the first
+// pass), [16 + k] = units of k pixels, [96 + k] = of those, placed so far; all zeroed before the first pass.
+#define PT_QUEUE_WORDS 176
+PT_DEV int unit_ppu(const unsigned long long *queue, long long lanes_cap, int nsamp) {
+  // lanes per pixel every unit gets at least: the largest power of two (<= S*S, <= 64) at which all flagged
+  // pixels together still fit the lanes the launch keeps resident
+  const unsigned long long total = queue[11];
+  int lg = 1;
+  while (lg * 2 <= 64 && lg * 2 <= nsamp && (long long)total * (lg * 2) <= lanes_cap) lg *= 2;
+  return 64 / lg;
+}
+__global__ void pt_unit_hist(const unsigned char *keys, int n, unsigned long long *queue, long long lanes_cap, int nsamp) {
+  const int ppu = unit_ppu(queue, lanes_cap, nsamp);
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int k = i < n ? keys[i] : 0;
+  if (k) {  // (a few per cent of the regions of a frame)
+    const int full = k / ppu, rem = k - full * ppu;
+    if (full) atomicAdd(queue + 16 + ppu, (unsigned long long)full);
+    if (rem) atomicAdd(queue + 16 + rem, 1ULL);
+  }
+}
+__global__ void pt_unit_scatter(const unsigned char *keys, int n, int2 *units, int units_cap, unsigned long long *queue,
+                                long long lanes_cap, int nsamp) {
   __shared__ int offs[65];
-  __shared__ unsigned long long total;
-  __shared__ int ppu_s;
-  if (threadIdx.x == 0) {
-    queue[0] = 0ULL;
-    total = 0ULL;
-  }
-  for (int i = threadIdx.x; i < 65; i += blockDim.x) hist[i] = 0;
-  __syncthreads();
-  unsigned long long mine = 0;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) mine += keys[i];
-  for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off, 64);
-  if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&total, mine);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    // lanes per pixel every unit gets at least: the largest power of two (<= S*S, <= 64) at which all flagged
-    // pixels together still fit the lanes the launch keeps resident
-    int lg = 1;
-    while (lg * 2 <= 64 && lg * 2 <= nsamp && (long long)total * (lg * 2) <= lanes_cap) lg *= 2;
-    ppu_s = 64 / lg;
-  }
-  __syncthreads();
-  const int ppu = ppu_s;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    const int k = keys[i];
-    if (k) {
-      const int full = k / ppu, rem = k - full * ppu;
-      if (full) atomicAdd(&hist[ppu], full);
-      if (rem) atomicAdd(&hist[rem], 1);
-    }
-  }
-  __syncthreads();
+  const int ppu = unit_ppu(queue, lanes_cap, nsamp);
   if (threadIdx.x == 0) {
     int run = 0;
     for (int k = 64; k >= 1; --k) {
       offs[k] = run;
-      run += hist[k];
+      run += (int)queue[16 + k];
     }
-    queue[9] = (unsigned long long)(run < units_cap ? run : units_cap);
-    queue[10] = (unsigned long long)ppu;
+    if (blockIdx.x == 0) {
+      queue[9] = (unsigned long long)(run < units_cap ? run : units_cap);
+      queue[10] = (unsigned long long)ppu;
+    }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    const int k = keys[i];
-    if (!k) continue;
-    const int full = k / ppu, rem = k - full * ppu;
-    if (full) {
-      const int at = atomicAdd(&offs[ppu], full);
-      for (int g = 0; g < full; ++g)
-        if (at + g < units_cap) units[at + g] = make_int2(i, (g * ppu) | (ppu << 8));  // (region, first | count << 8)
-    }
-    if (rem) {
-      const int at = atomicAdd(&offs[rem], 1);
-      if (at < units_cap) units[at] = make_int2(i, (full * ppu) | (rem << 8));
-    }
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int k = i < n ? keys[i] : 0;
+  if (!k) return;
+  const int full = k / ppu, rem = k - full * ppu;
+  if (full) {
+    const int at = offs[ppu] + (int)atomicAdd(queue + 96 + ppu, (unsigned long long)full);
+    for (int g = 0; g < full; ++g)
+      if (at + g < units_cap) units[at + g] = make_int2(i, (g * ppu) | (ppu << 8));  // (region, first | count << 8)
+  }
+  if (rem) {
+    const int at = offs[rem] + (int)atomicAdd(queue + 96 + rem, 1ULL);
+    if (at < units_cap) units[at] = make_int2(i, (full * ppu) | (rem << 8));
   }
 }
 

@@ -579,7 +579,7 @@ extern "C" int pt_scene_upload(const pt_scene_desc *d, int device, pt_scene **ou
     return code;
   };
   if ((rc = hip_or_free(hipMalloc((void **)&s->ray_counter, 2 * sizeof(unsigned long long)), "hipMalloc(counter)"))) return rc;
-  if ((rc = hip_or_free(hipMalloc((void **)&s->queue, 16 * sizeof(unsigned long long)), "hipMalloc(queue)"))) return rc;
+  if ((rc = hip_or_free(hipMalloc((void **)&s->queue, PT_QUEUE_WORDS * sizeof(unsigned long long)), "hipMalloc(queue)"))) return rc;
   if ((rc = hip_or_free(hipMalloc((void **)&s->args_dev, sizeof(PtKArgs)), "hipMalloc(args)"))) return rc;
   if ((rc = hip_or_free(hipHostMalloc((void **)&s->ray_counter_host, 2 * sizeof(unsigned long long)), "hipHostMalloc"))) return rc;
   s->ray_counter_host[0] = s->ray_counter_host[1] = 0;
@@ -836,7 +836,7 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
   }
   if (p->renderer == PT_RENDERER_PATHTRACER) {
     // the queue head: zeroed by pt_region_sort between the two passes; by a memset for the one-queue kernel
-    if (!path_tiled) HIP_TRY(hipMemsetAsync(s->queue, 0, 16 * sizeof(unsigned long long), st));
+    HIP_TRY(hipMemsetAsync(s->queue, 0, PT_QUEUE_WORDS * sizeof(unsigned long long), st));
     // step batching (path_trace): the second pass by regions never mixes the two kinds of step (a P step
     // waits until no lane holds a ray: its lanes then move sample by sample); the one-queue kernel, which
     // also carries the cheap background pixels, starts samples while fewer than 48 lanes hold a ray and
@@ -861,7 +861,8 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
   const int nregions = path_tiled ? ((p->width + PT_REGION - 1) / PT_REGION) * ((rows + PT_REGION - 1) / PT_REGION) : 0;
   // lanes the second pass keeps resident: pt_unit_sort cuts regions into smaller units (more lanes per
   // pixel) as long as all flagged pixels together still fit them
-  const long long lanes_cap = (long long)grid * PT_BLOCK;
+  static const int env_lanes_cap = getenv("PTRACE_UNIT_LANES_CAP") ? atoi(getenv("PTRACE_UNIT_LANES_CAP")) : -1;  // 0: a unit = a region
+  const long long lanes_cap = env_lanes_cap >= 0 ? (long long)env_lanes_cap : (long long)grid * PT_BLOCK;
   if (path_tiled) {
     const int units_need = nregions + (int)(lanes_cap / 64) + 64;
     if (nregions > s->region_cap || units_need > s->units_cap) {
@@ -997,10 +998,10 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
       PT_LAUNCH((pt_tile_kernel<PT_RENDERER_PATHTRACER, 4, false>), tgrid, lds, !path_tiled, a, grid);
     if (path_tiled) {
       // second pass: the pixels the first one flagged, fullest regions first
-      static const int env_ppu = getenv("PTRACE_UNIT_LANES_CAP") ? atoi(getenv("PTRACE_UNIT_LANES_CAP")) : -1;  // 0: a unit = a region
       const int nsamp = p->samples_per_side > 0 ? p->samples_per_side * p->samples_per_side : 1;
-      hipLaunchKernelGGL(pt_unit_sort, dim3(1), dim3(1024), 0, st, s->region_keys, nregions, s->units, s->units_cap, s->queue,
-                         env_ppu >= 0 ? (long long)env_ppu : lanes_cap, nsamp);
+      hipLaunchKernelGGL(pt_unit_hist, dim3((nregions + 1023) / 1024), dim3(1024), 0, st, s->region_keys, nregions, s->queue, lanes_cap, nsamp);
+      hipLaunchKernelGGL(pt_unit_scatter, dim3((nregions + 1023) / 1024), dim3(1024), 0, st, s->region_keys, nregions, s->units, s->units_cap,
+                         s->queue, lanes_cap, nsamp);
       if (lds_frames) {
         HIP_TRY(path_lds_limit((const void *)pt_path_regions_kernel<true>, lds + frame_lds + diag_lds_bytes));
         PT_LAUNCH((pt_path_regions_kernel<true>), grid, lds + frame_lds + diag_lds_bytes, true, a);
