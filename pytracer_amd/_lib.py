@@ -110,6 +110,8 @@ def lib():
         L.pt_host_alloc.argtypes = [C.c_size_t, P(C.c_void_p)]
         L.pt_host_free.restype = C.c_int
         L.pt_host_free.argtypes = [C.c_void_p]
+        L.pt_debug_cull_probe.restype = C.c_int
+        L.pt_debug_cull_probe.argtypes = [C.c_void_p, P(abi.Camera)] + [C.c_int] * 8 + [C.c_void_p]
         L.pt_debug_probe.restype = C.c_int
         L.pt_debug_probe.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         _lib = L

@@ -2755,6 +2755,16 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAV
   path_trace<true, LDSF, true>(a);
 }
 
+// ---- culling probe: cone_keeps / pixel_cone exactly as the render kernels evaluate them, one wave ---------------
+__global__ void pt_cull_probe_kernel(const PtKArgs a, int x0, int x1, int row0, int row1, int pixel_x, int pixel_row,
+                                     int *keep) {
+  const ConeCam cam = cone_cam(a);
+  const TileCone tile = tile_cone(cam, x0, x1, row0, row1);
+  const TileCone tc = pixel_x >= 0 ? pixel_cone(cam, tile, pixel_x, pixel_row) : tile;
+  for (int slot = threadIdx.x; slot < a.n_shapes; slot += 64)
+    keep[a.recs[slot].index] = slot >= a.n_spheres ? 1 : (cone_keeps(tc, a.bounds[slot]) ? 1 : 0);
+}
+
 // ---- primitive probe: lets the tests check IEEE exactness of device sqrt / div and measure the ulp
 //      distance of ocml's transcendental functions from glibc's ----------------------------
 __global__ void pt_probe_kernel(int op, const double *x, const double *y, double *out, int n) {

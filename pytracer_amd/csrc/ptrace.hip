@@ -644,6 +644,25 @@ static hipError_t path_lds_limit(const void *kernel, size_t bytes) {
   return hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PT_LDS_BUDGET);
 }
 
+// The fp32 model of the primary rays that the culling cones are built from (tile_cone, pixel_cone):
+// camera.py:116-124 + imagetracer.py:56-58 folded into d(x, y) = d0 + x * dx + y * dy (perspective: directions,
+// common origin in `apex`; orthogonal, camera.py:59-78: the same affine model describes the ORIGINS and the
+// "apex" slot carries the common direction).
+static void fill_cone_model(PtKArgs &a, const pt_camera *cam, int width, int height) {
+  const double *m = cam->m, dist = cam->screen_distance, asp = cam->aspect_ratio;
+  for (int r = 0; r < 3; ++r) {
+    a.cone_d0[r] = (float)(m[r * 4 + 0] * dist + m[r * 4 + 1] * asp + m[r * 4 + 2]);
+    a.cone_dx[r] = (float)(m[r * 4 + 1] * (-2.0 * asp / width));
+    a.cone_dy[r] = (float)(m[r * 4 + 2] * (-2.0 / height));
+    a.cone_apex[r] = (float)(m[r * 4 + 0] * -dist + m[r * 4 + 3]);
+    if (cam->kind != PT_CAMERA_PERSPECTIVE) {
+      a.cone_d0[r] = (float)(-m[r * 4 + 0] + m[r * 4 + 1] * asp + m[r * 4 + 2] + m[r * 4 + 3]);
+      a.cone_apex[r] = (float)m[r * 4 + 0];
+    }
+  }
+  a.cam_kind = cam->kind;
+}
+
 // Launch a kernel of the frame on `st`; the LAST one is the render kernel proper (pt_stats.vgprs).  Timing: the
 // frame's first launch carries the start event and its last one the stop event IN the dispatch itself
 // (hipExtLaunchKernelGGL: the events take the kernel's own begin / end timestamps), so a timed frame costs no
@@ -684,22 +703,7 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
   memcpy(a.cam_m, cam->m, sizeof a.cam_m);
   a.cam_dist = cam->screen_distance;
   a.cam_aspect = cam->aspect_ratio;
-  {
-    // camera.py:116-124 + imagetracer.py:56-58: d = M3 * (dist, (1 - 2x/W) * aspect, 1 - 2y/H)
-    const double *m = cam->m, dist = cam->screen_distance, asp = cam->aspect_ratio;
-    for (int r = 0; r < 3; ++r) {
-      a.cone_d0[r] = (float)(m[r * 4 + 0] * dist + m[r * 4 + 1] * asp + m[r * 4 + 2]);
-      a.cone_dx[r] = (float)(m[r * 4 + 1] * (-2.0 * asp / p->width));
-      a.cone_dy[r] = (float)(m[r * 4 + 2] * (-2.0 / p->height));
-      a.cone_apex[r] = (float)(m[r * 4 + 0] * -dist + m[r * 4 + 3]);
-      if (cam->kind != PT_CAMERA_PERSPECTIVE) {
-        // camera.py:59-78: o = M * (-1, (1 - 2x/W) * aspect, 1 - 2y/H) + t, d = M * (1, 0, 0): the same
-        // affine model describes the ORIGINS, and the "apex" slot carries the common direction
-        a.cone_d0[r] = (float)(-m[r * 4 + 0] + m[r * 4 + 1] * asp + m[r * 4 + 2] + m[r * 4 + 3]);
-        a.cone_apex[r] = (float)m[r * 4 + 0];
-      }
-    }
-  }
+  fill_cone_model(a, cam, p->width, p->height);
   a.W = p->width;
   a.H = p->height;
   a.S = p->samples_per_side;
@@ -1378,6 +1382,35 @@ extern "C" int pt_debug_read_trace(unsigned long long *out, int n) {
   return PT_OK;
 }
 #endif
+
+// ---- diagnostics (not part of the reference seam): the culling predicate on its own ------------------------
+// keep[i] (by World.shapes index) = would the cull of the primary rays through the image rectangle
+// [x0, x1] x [row0, row1 + 1] keep shape i?  pixel_x >= 0: the same for the cone of the single pixel
+// (pixel_x, pixel_row) inside that tile (pixel_cone, perspective only).  Planes answer 1.
+extern "C" int pt_debug_cull_probe(pt_scene *s, const pt_camera *cam, int width, int height, int x0, int x1, int row0,
+                                   int row1, int pixel_x, int pixel_row, int *keep) {
+  if (!s || !cam || !keep || width <= 0 || height <= 0) return fail(PT_ERR_INVALID, "bad probe arguments");
+  HIP_TRY(hipSetDevice(s->device));
+  PtKArgs a;
+  memset(&a, 0, sizeof a);
+  fill_cone_model(a, cam, width, height);
+  PtKArgs *a_dev = nullptr;
+  int *keep_dev = nullptr;
+  HIP_TRY(hipMalloc((void **)&a_dev, sizeof a));
+  HIP_TRY(hipMalloc((void **)&keep_dev, sizeof(int) * std::max(1, s->n_shapes)));
+  a.cold = a_dev;
+  a.recs = s->recs;
+  a.bounds = s->bounds;
+  a.n_shapes = s->n_shapes;
+  a.n_spheres = s->n_spheres;
+  HIP_TRY(hipMemcpy(a_dev, &a, sizeof a, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(pt_cull_probe_kernel, dim3(1), dim3(64), 0, 0, a, x0, x1, row0, row1, pixel_x, pixel_row, keep_dev);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(keep, keep_dev, sizeof(int) * s->n_shapes, hipMemcpyDeviceToHost));
+  (void)hipFree(a_dev);
+  (void)hipFree(keep_dev);
+  return PT_OK;
+}
 
 // ---- diagnostics (not part of the reference seam): device primitive probe used by the tests -------------
 extern "C" int pt_debug_probe(int op, const double *x, const double *y, double *out, int n) {

@@ -101,6 +101,17 @@ class DeviceScene:
         _lib.check(_lib.lib().pt_render_device(self._h, C.byref(cam), C.byref(params), C.c_void_p(dev_ptr),
                                                nbytes, C.c_void_p(stream) if stream else None))
 
+    def cull_probe(self, cam: abi.Camera, width: int, height: int, x0: int, x1: int, row0: int, row1: int,
+                   pixel=None) -> np.ndarray:
+        """Diagnostics: which shapes (by ``World.shapes`` index) the conservative cull of the primary rays through
+        the image rectangle ``[x0, x1] x [row0, row1 + 1]`` keeps -- or, with ``pixel=(x, row)``, the cone of that one
+        pixel inside the rectangle -- evaluated on the device exactly as the render kernels evaluate it."""
+        keep = np.zeros(max(1, self.flat.n_shapes), dtype=np.int32)
+        px, py = pixel if pixel is not None else (-1, -1)
+        _lib.check(_lib.lib().pt_debug_cull_probe(self._h, C.byref(cam), int(width), int(height), int(x0), int(x1), int(row0),
+                                                  int(row1), int(px), int(py), keep.ctypes.data_as(C.c_void_p)))
+        return keep[: self.flat.n_shapes].astype(bool)
+
     def sync(self) -> None:
         _lib.check(_lib.lib().pt_sync(self._h))
 
