@@ -167,6 +167,17 @@ def extra_rows(device: int):
         rows[name] = kernel_row(ds, cam_for(W, H), par, out, reps, flat)
     for ds_old in scene_cache.values():
         ds_old[1].close()
+    # the path tracer's second pass on C3: executed VALU instructions (PMC medians committed under profiles/) against
+    # the SIMD-cycles of its launch -- the same fraction as roofline.frac, for the kernel VERDICT r1 named
+    n_cu, clock_khz = device_info(device)
+    for tag, fname in (("C3_pathtracer_1280x720_32sph_D3_spp16_N1", "pmc_c3_second_pass.json"),
+                       ("C3_same_PT_PCG_SAMPLE", "pmc_c3_second_pass_sample.json")):
+        pmc = load_profile(fname)
+        if pmc is not None and tag in rows:
+            valu, dur = pmc["counters"]["SQ_INSTS_VALU"], pmc["dur_us"] * 1e-6
+            rows[tag]["second_pass_executed"] = {
+                "kernel": "pt_path_regions_kernel", "valu_wave_instructions_per_launch": valu, "kernel_us_under_pmc_collection": pmc["dur_us"],
+                "valu_issue_utilisation": valu * VALU_CYCLES_PER_WAVE_INSTR / (n_cu * 4 * dur * clock_khz * 1e3), "source": pmc.get("source")}
     return rows
 
 
@@ -325,7 +336,7 @@ def run_single(args, local_rank):
             "executed": {"valu_wave_instructions_per_launch": valu,
                          "salu_wave_instructions_per_launch": pmc["counters"].get("SQ_INSTS_SALU"),
                          "fp64_instruction_share": (f64 / valu) if f64 else None,
-                         "kernel_us_under_rocprof": pmc.get("dur_us"), "simds": n_simd, "clock_GHz": clock_hz / 1e9,
+                         "kernel_us_under_pmc_collection": pmc.get("dur_us"), "simds": n_simd, "clock_GHz": clock_hz / 1e9,
                          "source": pmc.get("source")},
         })
     roofline["algorithmic_equivalent"] = {
