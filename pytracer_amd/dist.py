@@ -47,6 +47,25 @@ def shard_blocks(height: int, row_block: int, world_size: int, rank: int) -> Lis
     return out
 
 
+_use_p2p = True  # flips to False (on every rank alike) if the backend refuses batched point-to-point transfers
+
+
+def _gather_padded(local, height, row_block, world, rank, group, dst, out):
+    """The collective of last resort: one ``gather`` of shards padded to a common size, then the block copies."""
+    pad = max_shard_rows(height, row_block, world)
+    shard = local[:pad] if local.shape[0] >= pad else torch.cat(
+        [local, local.new_zeros((pad - local.shape[0],) + tuple(local.shape[1:]))])
+    shard = shard.contiguous()
+    if rank == dst:
+        parts = [torch.empty_like(shard) for _ in range(world)]
+        dist.gather(shard, parts, dst=dst, group=group)
+        for r in range(world):
+            for g0, l0, n in shard_blocks(height, row_block, world, r):
+                out[g0:g0 + n].copy_(parts[r][l0:l0 + n], non_blocking=True)
+    else:
+        dist.gather(shard, None, dst=dst, group=group)
+
+
 def gather_image(local: torch.Tensor, height: int, row_block: int, group=None, dst: int = 0,
                  out: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
     """Assemble the frame on ``dst`` from the ranks' compact row shards.
@@ -64,10 +83,13 @@ def gather_image(local: torch.Tensor, height: int, row_block: int, group=None, d
         dev_out, dev_local = out, local
         local = dev_local.cpu()
         out = torch.empty((height,) + tuple(local.shape[1:]), dtype=local.dtype) if rank == dst else None
+    global _use_p2p
     ops = []
-    if rank == dst:
-        if out is None:
-            out = torch.empty((height,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    if rank == dst and out is None:
+        out = torch.empty((height,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    if not _use_p2p:
+        _gather_padded(local, height, row_block, world, rank, group, dst, out)
+    elif rank == dst:
         for r in range(world):
             blocks = shard_blocks(height, row_block, world, r)
             if r == dst:
@@ -81,8 +103,14 @@ def gather_image(local: torch.Tensor, height: int, row_block: int, group=None, d
         ops = [dist.P2POp(dist.isend, local[l0:l0 + n], peer, group)
                for _, l0, n in shard_blocks(height, row_block, world, rank)]
     if ops:
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()  # (RCCL: returns once the group is enqueued on the current stream)
+        try:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()  # (RCCL: returns once the group is enqueued on the current stream)
+        except (RuntimeError, ValueError, NotImplementedError):
+            # the same call fails the same way on every rank (it is refused before anything is sent): all of them
+            # switch to the padded gather, for this frame and the following ones
+            _use_p2p = False
+            _gather_padded(local, height, row_block, world, rank, group, dst, out)
     if staged and rank == dst:
         if dev_out is None:
             dev_out = torch.empty(out.shape, dtype=out.dtype, device=dev_local.device)

@@ -73,6 +73,39 @@ def test_sharded_render_matches_single_process(world, renderer, S, height, row_b
     assert ret["shape"] == (height, 48, 3)
 
 
+def _gather_worker(rank, world, port, use_p2p, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pytracer_amd import dist as ptdist
+
+        ptdist._use_p2p = use_p2p
+        H, W = 27, 5  # ragged: 8 + 8 + 8 + 3 rows over `world` ranks
+        full = torch.arange(H * W * 3, dtype=torch.float64).reshape(H, W, 3)
+        rows = ptdist.shard_rows(H, 8, world, rank)
+        shard = full[rows].contiguous() if rows else torch.zeros((1, W, 3), dtype=torch.float64)
+        out = ptdist.gather_image(shard, H, 8)
+        if rank == 0:
+            ret["ok"] = bool(torch.equal(out, full))
+        else:
+            assert out is None
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,use_p2p", [(2, True), (3, True), (2, False), (3, False)])
+def test_gather_straight_into_row_blocks_and_the_padded_fallback(world, use_p2p):
+    """Both collectives behind gather_image: the batched point-to-point transfers whose destinations are the row
+    blocks of the final frame, and the padded `gather` the code switches to if the backend refuses those."""
+    port = _free_port()
+    ret = mp.Manager().dict()
+    mp.spawn(_gather_worker, args=(world, port, use_p2p, ret), nprocs=world, join=True)
+    assert ret["ok"] is True
+
+
 def test_partition_helpers():
     from pytracer_amd import dist as ptdist
 
