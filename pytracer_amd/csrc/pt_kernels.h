@@ -453,6 +453,7 @@ PT_DEV int world_query_lanes(const PtKArgs &a, const Ray &r, double tmax, double
   typedef const __attribute__((address_space(4))) f8 *pt_kf8;
   // may this lane's ray touch the balls (cx, cy, cz | radius cr), two at a time?
   auto reject2 = [&](f2 cx, f2 cy, f2 cz, f2 cr, bool &rej0, bool &rej1) {
+#pragma clang fp contract(fast)  // (a conservative fp32 filter, not reference arithmetic: fused multiply-adds only make it more exact)
     const f2 vx = cx - ofx, vy = cy - ofy, vz = cz - ofz;
     const f2 vd = vx * dfx + vy * dfy + vz * dfz;
     const f2 vv = vx * vx + vy * vy + vz * vz;
@@ -480,6 +481,7 @@ PT_DEV int world_query_lanes(const PtKArgs &a, const Ray &r, double tmax, double
   // the same test for ONE ball, the ray's constants given explicitly (scalar form, see the sparse path below)
   auto reject1 = [&](float cx, float cy, float cz, float cr, float sox, float soy, float soz, float sdx, float sdy,
                      float sdz, float sdd, float seo, float sdd8) {
+#pragma clang fp contract(fast)
     const float vx = cx - sox, vy = cy - soy, vz = cz - soz;
     const float vd = vx * sdx + vy * sdy + vz * sdz;
     const float vv = vx * vx + vy * vy + vz * vz;
