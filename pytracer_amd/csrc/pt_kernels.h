@@ -2014,16 +2014,22 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
 // queue[0] = queue head, [9] = number of units, [10] = ppu (for the statistics), [11] = F (summed up by the first
 // pass), [16 + k] = units of k pixels, [96 + k] = of those, placed so far; all zeroed before the first pass.
 #define PT_QUEUE_WORDS 176
-PT_DEV int unit_ppu(const unsigned long long *queue, long long lanes_cap, int nsamp) {
+PT_DEV int unit_ppu(const unsigned long long *queue, long long lanes_cap, int nsamp, int min_rounds) {
   // lanes per pixel every unit gets at least: the largest power of two (<= S*S, <= 64) at which all flagged
-  // pixels together still fit the lanes the launch keeps resident
+  // pixels together still fit the lanes the launch keeps resident ...
   const unsigned long long total = queue[11];
   int lg = 1;
   while (lg * 2 <= 64 && lg * 2 <= nsamp && (long long)total * (lg * 2) <= lanes_cap) lg *= 2;
+  // ... or more, up to four units per resident wave, as long as a unit keeps `min_rounds` rounds of work: many
+  // short units spread over the chip more evenly than few long ones (a unit's time varies a lot with what its
+  // pixels see), but every unit costs a fetch, and lanes beyond what speculation can use are wasted
+  // (PT_PCG_PIXEL asks for more rounds per unit than PT_PCG_SAMPLE for that reason).
+  while (lg * 2 <= 64 && lg * 2 * min_rounds <= nsamp && (long long)total * (lg * 2) <= 4 * lanes_cap) lg *= 2;
   return 64 / lg;
 }
-__global__ void pt_unit_hist(const unsigned char *keys, int n, unsigned long long *queue, long long lanes_cap, int nsamp) {
-  const int ppu = unit_ppu(queue, lanes_cap, nsamp);
+__global__ void pt_unit_hist(const unsigned char *keys, int n, unsigned long long *queue, long long lanes_cap, int nsamp,
+                             int min_rounds) {
+  const int ppu = unit_ppu(queue, lanes_cap, nsamp, min_rounds);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int k = i < n ? keys[i] : 0;
   if (k) {  // (a few per cent of the regions of a frame)
@@ -2033,9 +2039,9 @@ __global__ void pt_unit_hist(const unsigned char *keys, int n, unsigned long lon
   }
 }
 __global__ void pt_unit_scatter(const unsigned char *keys, int n, int2 *units, int units_cap, unsigned long long *queue,
-                                long long lanes_cap, int nsamp) {
+                                long long lanes_cap, int nsamp, int min_rounds) {
   __shared__ int offs[65];
-  const int ppu = unit_ppu(queue, lanes_cap, nsamp);
+  const int ppu = unit_ppu(queue, lanes_cap, nsamp, min_rounds);
   if (threadIdx.x == 0) {
     int run = 0;
     for (int k = 64; k >= 1; --k) {

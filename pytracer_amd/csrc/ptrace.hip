@@ -868,7 +868,7 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
   static const int env_lanes_cap = getenv("PTRACE_UNIT_LANES_CAP") ? atoi(getenv("PTRACE_UNIT_LANES_CAP")) : -1;  // 0: a unit = a region
   const long long lanes_cap = env_lanes_cap >= 0 ? (long long)env_lanes_cap : (long long)grid * PT_BLOCK;
   if (path_tiled) {
-    const int units_need = nregions + (int)(lanes_cap / 64) + 64;
+    const int units_need = nregions + (int)(4 * lanes_cap / 64) + 64;  // (pt_unit_hist may cut up to four units per resident wave)
     if (nregions > s->region_cap || units_need > s->units_cap) {
       HIP_TRY(hipStreamSynchronize(st));
       if (s->region_keys) HIP_TRY(hipFree(s->region_keys));
@@ -1003,9 +1003,12 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
     if (path_tiled) {
       // second pass: the pixels the first one flagged, fullest regions first
       const int nsamp = p->samples_per_side > 0 ? p->samples_per_side * p->samples_per_side : 1;
-      hipLaunchKernelGGL(pt_unit_hist, dim3((nregions + 1023) / 1024), dim3(1024), 0, st, s->region_keys, nregions, s->queue, lanes_cap, nsamp);
+      static const int env_minr = getenv("PTRACE_UNIT_MIN_ROUNDS") ? atoi(getenv("PTRACE_UNIT_MIN_ROUNDS")) : 0;
+      const int min_rounds = env_minr > 0 ? env_minr : (a.pcg_mode == PT_PCG_SAMPLE ? 8 : 16);
+      hipLaunchKernelGGL(pt_unit_hist, dim3((nregions + 1023) / 1024), dim3(1024), 0, st, s->region_keys, nregions, s->queue, lanes_cap, nsamp,
+                         min_rounds);
       hipLaunchKernelGGL(pt_unit_scatter, dim3((nregions + 1023) / 1024), dim3(1024), 0, st, s->region_keys, nregions, s->units, s->units_cap,
-                         s->queue, lanes_cap, nsamp);
+                         s->queue, lanes_cap, nsamp, min_rounds);
       if (lds_frames) {
         HIP_TRY(path_lds_limit((const void *)pt_path_regions_kernel<true>, lds + frame_lds + diag_lds_bytes));
         PT_LAUNCH((pt_path_regions_kernel<true>), grid, lds + frame_lds + diag_lds_bytes, true, a);
