@@ -2788,6 +2788,30 @@ __global__ void pt_probe_kernel(int op, const double *x, const double *y, double
     case 5: r = acos(x[i]); break;
     case 6: r = floor(x[i]); break;
     case 7: r = x[i] * y[i] + x[i]; break;  // must NOT be fused (-ffp-contract=off)
+    case 8:    // pcg.py:23-62: the (int)y[i]-th output of PCG(init_state = 45, init_seq = x[i]), as a double
+    case 9: {  // ... and the matching random_float()
+      Pcg p;
+      pcg_seed(p, 45ULL, (uint64_t)x[i]);
+      uint32_t v = 0;
+      double f = 0.0;
+      for (int k = 0; k <= (int)y[i]; ++k) {
+        if (op == 8)
+          v = pcg_next(p);
+        else
+          f = pcg_float(p);
+      }
+      r = op == 8 ? (double)v : f;
+      break;
+    }
+    case 10: {  // pcg_advance(state, inc, n) == n calls of pcg_next: 1.0 when the states agree (n = y[i])
+      Pcg p, q;
+      pcg_seed(p, 45ULL, (uint64_t)x[i]);
+      q = p;
+      const unsigned nsteps = (unsigned)y[i];
+      for (unsigned k = 0; k < nsteps; ++k) pcg_next(p);
+      r = (pcg_advance(q.state, q.inc, nsteps) == p.state) ? 1.0 : 0.0;
+      break;
+    }
     default: break;
   }
   out[i] = r;

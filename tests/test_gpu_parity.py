@@ -92,6 +92,28 @@ def test_transcendental_ulp_distance(dev):
 
 
 # ---- golden frames ----------------------------------------------------------------------------------------
+def test_pcg_known_answers_and_jump_ahead_on_the_device(dev):
+    """The device generator on its own: the outputs of PCG(45, seq) against the host copy that
+    test_oracle_golden pins to the reference (test_all.py:872-887 and the g1 fixture), and `pcg_advance` -- the
+    jump the second pass of the path tracer speculates with -- against n single steps, n up to 5000."""
+    from pytracer_amd.hostmodel import PCG
+
+    seqs = np.array([54, 55, 54 + 921599, 2 ** 40 + 7, 12345678901], dtype=np.float64)
+    for k in (0, 1, 5, 15):
+        got = dev.probe(8, seqs, np.full_like(seqs, k))
+        gotf = dev.probe(9, seqs, np.full_like(seqs, k))
+        for i, q in enumerate(seqs):
+            g = PCG(45, int(q))
+            outs = [g.random() for _ in range(k + 1)]
+            assert int(got[i]) == outs[-1]
+            g = PCG(45, int(q))
+            fl = [g.random_float() for _ in range(k + 1)]
+            assert gotf[i] == fl[-1]
+    n = np.array([0, 1, 2, 3, 4, 7, 8, 63, 64, 255, 256, 1000, 4095, 4096, 5000], dtype=np.float64)
+    for q in (54.0, 999983.0):
+        assert np.all(dev.probe(10, np.full_like(n, q), n) == 1.0)
+
+
 @pytest.mark.parametrize("name", util.FRAME_FIXTURES)
 def test_frame_vs_reference_golden(dev, oracle, name):
     scene, cam, par, pixels = util.load_frame(name)
