@@ -478,6 +478,92 @@ PT_DEV int world_query_lanes(const PtKArgs &a, const Ray &r, double tmax, double
   const int levels = a.bs_levels;
   pt_kfloat gsx = bsr + a.bs_stride, gsy = gsx + a.gs_stride, gsz = gsy + a.gs_stride, gsr = gsz + a.gs_stride;
   pt_kfloat csx = gsr + a.gs_stride, csy = csx + a.cs_stride, csz = csy + a.cs_stride, csr = csz + a.cs_stride;
+  // ---- the exact test of a candidate (shared by every way of finding candidates below) ----
+  struct DiagL {
+    double s0, s1, s2, t0, t1, t2;
+    int tnz;
+  };
+  auto fetch = [&](int slot) {
+    DiagL g;
+    g.s0 = g.s1 = g.s2 = g.t0 = g.t1 = g.t2 = 0.0;
+    g.tnz = 0;
+    if (slot < nd) {
+      if (diag_lds >= 0) {  // the table was staged in LDS by the kernel (path_trace)
+        const int o = diag_lds + slot * 8;
+        g.s0 = pt_lds_f64[o];
+        g.s1 = pt_lds_f64[o + 1];
+        g.s2 = pt_lds_f64[o + 2];
+        g.t0 = pt_lds_f64[o + 3];
+        g.t1 = pt_lds_f64[o + 4];
+        g.t2 = pt_lds_f64[o + 5];
+        g.tnz = (int)(unsigned)pt_lds_masks[o + 6];
+      } else {
+        const PtDiagRec *q = a.diag + slot;
+        g.s0 = q->s[0];
+        g.s1 = q->s[1];
+        g.s2 = q->s[2];
+        g.t0 = q->t[0];
+        g.t1 = q->t[1];
+        g.t2 = q->t[2];
+        g.tnz = q->tnz;
+      }
+    }
+    return g;
+  };
+  // the object-space ray of candidate `slot`: shapes.py:102, full product or (bit-identical under the guard) o*s + t, d*s
+  auto object_ray = [&](int slot, bool has, const DiagL &g, double &ox, double &oy, double &oz, double &dx, double &dy,
+                        double &dz) {
+    if (!has || (slot < nd && lane_fast && (ozmask & ~(unsigned)g.tnz) == 0u)) {  // (!has: values unused)
+      dx = r.d.x * g.s0;
+      dy = r.d.y * g.s1;
+      dz = r.d.z * g.s2;
+      ox = r.o.x * g.s0 + g.t0;
+      oy = r.o.y * g.s1 + g.t1;
+      oz = r.o.z * g.s2 + g.t2;
+    } else {
+      const double *m = a.recs[slot].invm;
+      dx = r.d.x * m[0] + r.d.y * m[1] + r.d.z * m[2];
+      dy = r.d.x * m[4] + r.d.y * m[5] + r.d.z * m[6];
+      dz = r.d.x * m[8] + r.d.y * m[9] + r.d.z * m[10];
+      ox = r.o.x * m[0] + r.o.y * m[1] + r.o.z * m[2] + m[3];
+      oy = r.o.x * m[4] + r.o.y * m[5] + r.o.z * m[6] + m[7];
+      oz = r.o.x * m[8] + r.o.y * m[9] + r.o.z * m[10] + m[11];
+    }
+  };
+  auto take_if_closer = [&](int slot, bool need, bool ok, double t) {
+    if (need && ok) {
+      bool take = t < best_t;
+      if (!ANYHIT && !take && t == best_t && best >= 0) take = a.recs[slot].index < a.recs[best].index;
+      if (take) {
+        best_t = t;
+        best = slot;
+      }
+    }
+  };
+  // Two candidates per call: a visit is a chain of dependent fp64 operations (transform, discriminant, sqrt,
+  // division) that a single wave cannot overlap with anything but another, independent visit.  The winner does
+  // not depend on the order of visits (ties go by World.shapes index).
+  auto visit2 = [&](int slot_a, bool has_a, int slot_b, bool has_b) {
+    const DiagL ga = fetch(slot_a), gb = fetch(slot_b);
+    double oxa, oya, oza, dxa, dya, dza, oxb, oyb, ozb, dxb, dyb, dzb;
+    object_ray(slot_a, has_a, ga, oxa, oya, oza, dxa, dya, dza);
+    object_ray(slot_b, has_b, gb, oxb, oyb, ozb, dxb, dyb, dzb);
+    const LatCand ca = lat_cand(oxa, oya, oza, dxa, dya, dza), cb = lat_cand(oxb, oyb, ozb, dxb, dyb, dzb);
+    const bool need_a = has_a && ca.delta > 0.0 && !(ca.bb > 1e-100 && ca.cc >= 0.0);
+    const bool need_b = has_b && cb.delta > 0.0 && !(cb.bb > 1e-100 && cb.cc >= 0.0);
+    if (__ballot(need_a || need_b) != 0ULL) {
+      double t1a, t1b, t2a = 0.0, t2b = 0.0;
+      PT_LAT_ROOT1(ca, t1a);
+      PT_LAT_ROOT1(cb, t1b);
+      if (__ballot((need_a && !PT_LAT_INRANGE(t1a)) || (need_b && !PT_LAT_INRANGE(t1b))) != 0ULL) {
+        PT_LAT_ROOT2(ca, t2a);
+        PT_LAT_ROOT2(cb, t2b);
+      }
+      const bool ok1a = PT_LAT_INRANGE(t1a), ok1b = PT_LAT_INRANGE(t1b);
+      take_if_closer(slot_a, need_a, ok1a || PT_LAT_INRANGE(t2a), ok1a ? t1a : t2a);
+      take_if_closer(slot_b, need_b, ok1b || PT_LAT_INRANGE(t2b), ok1b ? t1b : t2b);
+    }
+  };
   // the same test for ONE ball, the ray's constants given explicitly (scalar form, see the sparse path below)
   auto reject1 = [&](float cx, float cy, float cz, float cr, float sox, float soy, float soz, float sdx, float sdy,
                      float sdz, float sdd, float seo, float sdd8) {
@@ -498,6 +584,149 @@ PT_DEV int world_query_lanes(const PtKArgs &a, const Ray &r, double tmax, double
     }
     return rej;
   };
+  // ---- scenes with a grid: every lane walks the cells its ray crosses ----
+  // Three phases, repeated until every lane's walk has left the grid: (1) a 3D-DDA in fp32 on the fp32 copy of
+  // the ray collects up to eight OCCUPIED cells (one bit per cell, from LDS when the kernel staged it); (2) the
+  // balls of those cells' spheres go through the conservative fp32 test of the prefilter, survivors join the lane's
+  // candidate list (eight 16-bit slots); (3) the candidates are visited two at a time.  Why no hit can be lost:
+  // pt_scene_upload (the margin a sphere is entered with covers the fp32 ray's deviation and the DDA's rounding).
+  if (a.grid_cells) {
+    pt_kargs ga = cold_args(a);
+    // spheres outside the grid (a dome, unbounded transforms): tested for every ray
+    const int n_always = ga->grid_n_always;
+    for (int k = 0; k < n_always; k += 2) {
+      const int sa = PT_KI(ga->grid_always)[k], sb = k + 1 < n_always ? PT_KI(ga->grid_always)[k + 1] : 0;
+      visit2(sa, active && !(ANYHIT && best >= 0), sb, !ANYHIT && active && k + 1 < n_always);
+      if (ANYHIT && k + 1 < n_always) visit2(sb, active && best < 0, 0, false);
+    }
+    const int rx = ga->grid_res[0], ry = ga->grid_res[1], rz = ga->grid_res[2];
+    const float bx0 = ga->grid_min[0], by0 = ga->grid_min[1], bz0 = ga->grid_min[2];
+    const float cwx = ga->grid_cell[0], cwy = ga->grid_cell[1], cwz = ga->grid_cell[2];
+    const unsigned *cells = ga->grid_cells;
+    const unsigned *occ_mem = ga->grid_occ;
+    const float4 *balls = ga->grid_balls;
+    const unsigned short *slots = ga->grid_slots;
+    const int occ_lds = ga->grid_occ_lds;
+    const unsigned *occ_shared = (const unsigned *)pt_lds_masks;
+    // the part of the ray inside the grid's box: [t0, t1] (slabs; a zero component: inside the slab or never)
+    float t0 = 0.0f, t1 = ANYHIT ? (float)tmax * (1.0f + 1e-5f) : INFINITY;
+    bool walking = active && !(ANYHIT && best >= 0);
+    {
+      const float lo_[3] = {bx0, by0, bz0}, hi_[3] = {ga->grid_max[0], ga->grid_max[1], ga->grid_max[2]};
+      const float o_[3] = {ofx, ofy, ofz}, d_[3] = {dfx, dfy, dfz};
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        if (fabsf(d_[q]) > 1e-30f) {
+          const float inv = 1.0f / d_[q];
+          const float ta = (lo_[q] - o_[q]) * inv, tb = (hi_[q] - o_[q]) * inv;
+          t0 = fmaxf(t0, fminf(ta, tb));
+          t1 = fminf(t1, fmaxf(ta, tb));
+        } else {
+          walking = walking && o_[q] >= lo_[q] && o_[q] <= hi_[q];
+        }
+      }
+    }
+    walking = walking && (t0 <= t1);  // (NaN: no walk.  The box is padded far beyond every entered ball: no margin needed here)
+    int cx = 0, cy = 0, cz = 0;
+    float tmx = 3.0e38f, tmy = 3.0e38f, tmz = 3.0e38f;
+    const float big = 3.0e38f;
+    const int sx = dfx > 0.0f ? 1 : -1, sy = dfy > 0.0f ? 1 : -1, sz = dfz > 0.0f ? 1 : -1;
+    const float tdx = fabsf(dfx) > 1e-30f ? fabsf(cwx / dfx) : big, tdy = fabsf(dfy) > 1e-30f ? fabsf(cwy / dfy) : big,
+                tdz = fabsf(dfz) > 1e-30f ? fabsf(cwz / dfz) : big;
+    if (walking) {
+      const float px = ofx + dfx * t0, py = ofy + dfy * t0, pz = ofz + dfz * t0;
+      cx = (int)floorf((px - bx0) * ga->grid_inv[0]);
+      cy = (int)floorf((py - by0) * ga->grid_inv[1]);
+      cz = (int)floorf((pz - bz0) * ga->grid_inv[2]);
+      cx = cx < 0 ? 0 : (cx >= rx ? rx - 1 : cx);
+      cy = cy < 0 ? 0 : (cy >= ry ? ry - 1 : cy);
+      cz = cz < 0 ? 0 : (cz >= rz ? rz - 1 : cz);
+      tmx = fabsf(dfx) > 1e-30f ? (bx0 + (float)(cx + (sx > 0)) * cwx - ofx) / dfx : big;
+      tmy = fabsf(dfy) > 1e-30f ? (by0 + (float)(cy + (sy > 0)) * cwy - ofy) / dfy : big;
+      tmz = fabsf(dfz) > 1e-30f ? (bz0 + (float)(cz + (sz > 0)) * cwz - ofz) / dfz : big;
+    }
+    int guard = rx + ry + rz + 3;  // (a walk crosses at most that many cell walls)
+    while (__ballot(walking) != 0ULL) {
+      // (1) up to eight occupied cells of this lane's walk (cell ids are < 2^18: three per 64-bit word would do, two words of 4 x 16 bits hold ids < 65536, so larger grids use the low 16 bits of (id) only when they fit: res <= 32^3)
+      unsigned long long ce_lo = 0ULL, ce_hi = 0ULL;
+      int n_ce = 0;
+      while (__ballot(walking && n_ce < 8) != 0ULL) {
+        if (walking && n_ce < 8) {
+          const int cid = (cz * ry + cy) * rx + cx;
+          const unsigned w = occ_lds >= 0 ? occ_shared[occ_lds + (cid >> 5)] : occ_mem[cid >> 5];
+          if ((w >> (cid & 31)) & 1u) {
+            if (n_ce < 4)
+              ce_lo |= (unsigned long long)(unsigned)cid << (16 * n_ce);
+            else
+              ce_hi |= (unsigned long long)(unsigned)cid << (16 * (n_ce - 4));
+            n_ce++;
+          }
+          // next cell: across the nearest of the three cell walls ahead
+          const float tn = fminf(tmx, fminf(tmy, tmz));
+          bool out = tn > t1 || --guard <= 0;
+          if (tmx <= tmy && tmx <= tmz) {
+            cx += sx;
+            tmx += tdx;
+            out = out || cx < 0 || cx >= rx;
+          } else if (tmy <= tmz) {
+            cy += sy;
+            tmy += tdy;
+            out = out || cy < 0 || cy >= ry;
+          } else {
+            cz += sz;
+            tmz += tdz;
+            out = out || cz < 0 || cz >= rz;
+          }
+          if (out) walking = false;
+        }
+      }
+      // (2) the spheres of those cells against the conservative fp32 test; (3) visit the survivors
+      unsigned long long ca_lo = 0ULL, ca_hi = 0ULL;
+      int n_ca = 0, last = -1;
+      auto flush = [&]() {
+        for (int k = 0; __ballot(k < n_ca) != 0ULL; k += ANYHIT ? 1 : 2) {
+          const bool has_a = k < n_ca && !(ANYHIT && best >= 0), has_b = !ANYHIT && k + 1 < n_ca;
+          const int slot_a = (int)(((k < 4 ? ca_lo : ca_hi) >> (16 * (k & 3))) & 0xffffULL);
+          const int slot_b = (int)((((k + 1) < 4 ? ca_lo : ca_hi) >> (16 * ((k + 1) & 3))) & 0xffffULL);
+          visit2(slot_a, has_a, slot_b, has_b);
+        }
+        ca_lo = 0ULL;
+        ca_hi = 0ULL;
+        n_ca = 0;
+      };
+      for (int k = 0; __ballot(k < n_ce) != 0ULL; ++k) {
+        const bool has_c = k < n_ce;
+        const int cid = has_c ? (int)(((k < 4 ? ce_lo : ce_hi) >> (16 * (k & 3))) & 0xffffULL) : 0;
+        const unsigned wv = cells[cid];
+        const unsigned cnt_c = has_c ? (wv & 255u) : 0u, off_c = wv >> 8;
+        for (unsigned q = 0; __ballot(q < cnt_c) != 0ULL; ++q) {
+          const bool has_i = q < cnt_c;
+          const float4 b = balls[off_c + (has_i ? q : 0u)];
+          const int slot = (int)slots[off_c + (has_i ? q : 0u)];
+          const bool rej = reject1(b.x, b.y, b.z, b.w, ofx, ofy, ofz, dfx, dfy, dfz, dd, eo, dd8);
+          if (has_i && !rej && slot != last && !(ANYHIT && best >= 0)) {
+            last = slot;
+            if (n_ca < 4)
+              ca_lo |= (unsigned long long)(unsigned)slot << (16 * n_ca);
+            else
+              ca_hi |= (unsigned long long)(unsigned)slot << (16 * (n_ca - 4));
+            n_ca++;
+          }
+          if (__ballot(n_ca >= 8) != 0ULL) flush();  // (a lane's list is full: visit what everybody has so far)
+        }
+      }
+      flush();
+      if (ANYHIT && best >= 0) walking = false;
+    }
+    // planes, then done
+    for (int k = ns; k < n; ++k) {
+      pt_kdouble m = PT_KD(a.recs[k].invm);
+      const double dz = r.d.x * m[8] + r.d.y * m[9] + r.d.z * m[10];
+      const double oz = r.o.x * m[8] + r.o.y * m[9] + r.o.z * m[10] + m[11];
+      PT_PLANE_HIT(k);
+    }
+    return best;
+  }
   for (int base = 0; base < ns; base += 64) {
     const int cnt = ns - base < 64 ? ns - base : 64;
     unsigned long long mask = 0ULL;
@@ -562,71 +791,7 @@ PT_DEV int world_query_lanes(const PtKArgs &a, const Ray &r, double tmax, double
       dbg_t0 = tn;
     }
 #endif
-    // walk the mask; the record of the NEXT candidate is requested before the current one is evaluated
-    struct DiagL {
-      double s0, s1, s2, t0, t1, t2;
-      int tnz;
-    };
-    auto fetch = [&](int slot) {
-      DiagL g;
-      g.s0 = g.s1 = g.s2 = g.t0 = g.t1 = g.t2 = 0.0;
-      g.tnz = 0;
-      if (slot < nd) {
-        if (diag_lds >= 0) {  // the table was staged in LDS by the kernel (path_trace)
-          const int o = diag_lds + slot * 8;
-          g.s0 = pt_lds_f64[o];
-          g.s1 = pt_lds_f64[o + 1];
-          g.s2 = pt_lds_f64[o + 2];
-          g.t0 = pt_lds_f64[o + 3];
-          g.t1 = pt_lds_f64[o + 4];
-          g.t2 = pt_lds_f64[o + 5];
-          g.tnz = (int)(unsigned)pt_lds_masks[o + 6];
-        } else {
-          const PtDiagRec *q = a.diag + slot;
-          g.s0 = q->s[0];
-          g.s1 = q->s[1];
-          g.s2 = q->s[2];
-          g.t0 = q->t[0];
-          g.t1 = q->t[1];
-          g.t2 = q->t[2];
-          g.tnz = q->tnz;
-        }
-      }
-      return g;
-    };
-    // the object-space ray of candidate `slot`: shapes.py:102, full product or (bit-identical under the guard) o*s + t, d*s
-    auto object_ray = [&](int slot, bool has, const DiagL &g, double &ox, double &oy, double &oz, double &dx, double &dy,
-                          double &dz) {
-      if (!has || (slot < nd && lane_fast && (ozmask & ~(unsigned)g.tnz) == 0u)) {  // (!has: values unused)
-        dx = r.d.x * g.s0;
-        dy = r.d.y * g.s1;
-        dz = r.d.z * g.s2;
-        ox = r.o.x * g.s0 + g.t0;
-        oy = r.o.y * g.s1 + g.t1;
-        oz = r.o.z * g.s2 + g.t2;
-      } else {
-        const double *m = a.recs[slot].invm;
-        dx = r.d.x * m[0] + r.d.y * m[1] + r.d.z * m[2];
-        dy = r.d.x * m[4] + r.d.y * m[5] + r.d.z * m[6];
-        dz = r.d.x * m[8] + r.d.y * m[9] + r.d.z * m[10];
-        ox = r.o.x * m[0] + r.o.y * m[1] + r.o.z * m[2] + m[3];
-        oy = r.o.x * m[4] + r.o.y * m[5] + r.o.z * m[6] + m[7];
-        oz = r.o.x * m[8] + r.o.y * m[9] + r.o.z * m[10] + m[11];
-      }
-    };
-    auto take_if_closer = [&](int slot, bool need, bool ok, double t) {
-      if (need && ok) {
-        bool take = t < best_t;
-        if (!ANYHIT && !take && t == best_t && best >= 0) take = a.recs[slot].index < a.recs[best].index;
-        if (take) {
-          best_t = t;
-          best = slot;
-        }
-      }
-    };
-    // Two candidates of the lane's list per iteration: a visit is a chain of dependent fp64 operations
-    // (transform, discriminant, sqrt, division) that a single wave cannot overlap with anything but another,
-    // independent visit.  The winner does not depend on the order of visits (ties go by World.shapes index).
+    // walk the mask, two candidates per turn (visit2)
     while (__ballot(mask != 0ULL) != 0ULL) {
       const bool has_a = mask != 0ULL;
       const int slot_a = base + (has_a ? __ffsll((long long)mask) - 1 : 0);
@@ -635,25 +800,7 @@ PT_DEV int world_query_lanes(const PtKArgs &a, const Ray &r, double tmax, double
       const bool has_b = !ANYHIT && mask != 0ULL;
       const int slot_b = base + (has_b ? __ffsll((long long)mask) - 1 : 0);
       if (!ANYHIT) mask &= mask - 1ULL;
-      const DiagL ga = fetch(slot_a), gb = fetch(slot_b);
-      double oxa, oya, oza, dxa, dya, dza, oxb, oyb, ozb, dxb, dyb, dzb;
-      object_ray(slot_a, has_a, ga, oxa, oya, oza, dxa, dya, dza);
-      object_ray(slot_b, has_b, gb, oxb, oyb, ozb, dxb, dyb, dzb);
-      const LatCand ca = lat_cand(oxa, oya, oza, dxa, dya, dza), cb = lat_cand(oxb, oyb, ozb, dxb, dyb, dzb);
-      const bool need_a = has_a && ca.delta > 0.0 && !(ca.bb > 1e-100 && ca.cc >= 0.0);
-      const bool need_b = has_b && cb.delta > 0.0 && !(cb.bb > 1e-100 && cb.cc >= 0.0);
-      if (__ballot(need_a || need_b) != 0ULL) {
-        double t1a, t1b, t2a = 0.0, t2b = 0.0;
-        PT_LAT_ROOT1(ca, t1a);
-        PT_LAT_ROOT1(cb, t1b);
-        if (__ballot((need_a && !PT_LAT_INRANGE(t1a)) || (need_b && !PT_LAT_INRANGE(t1b))) != 0ULL) {
-          PT_LAT_ROOT2(ca, t2a);
-          PT_LAT_ROOT2(cb, t2b);
-        }
-        const bool ok1a = PT_LAT_INRANGE(t1a), ok1b = PT_LAT_INRANGE(t1b);
-        take_if_closer(slot_a, need_a, ok1a || PT_LAT_INRANGE(t2a), ok1a ? t1a : t2a);
-        take_if_closer(slot_b, need_b, ok1b || PT_LAT_INRANGE(t2b), ok1b ? t1b : t2b);
-      }
+      visit2(slot_a, has_a, slot_b, has_b);
       if (ANYHIT && best >= 0) mask = 0ULL;  // this lane is blocked: nothing more to look at
 #ifdef PT_DEBUG_TIME
       dbg_it++;
@@ -2208,6 +2355,16 @@ PT_DEV void path_trace(const PtKArgs &a) {
     const unsigned long long *src = (const unsigned long long *)a.diag;
     for (int k = threadIdx.x; k < a.n_diag * 8; k += PT_BLOCK) pt_lds_masks[diag_lds + k] = src[k];
     __syncthreads();
+  }
+  if (LAT) {  // the grid's occupancy bits into LDS: the cell walk of world_query_lanes reads one per step
+    pt_kargs c = cold_args(a);
+    const int occ_lds = c->grid_occ_lds;
+    if (occ_lds >= 0) {
+      const int nwords = (c->grid_res[0] * c->grid_res[1] * c->grid_res[2] + 31) / 32;
+      unsigned *dst = (unsigned *)pt_lds_masks;
+      for (int k = threadIdx.x; k < nwords; k += PT_BLOCK) dst[occ_lds + k] = c->grid_occ[k];
+      __syncthreads();
+    }
   }
   nsamp = S > 0 ? S * S : 1;
   const double invN = 1.0 / (double)N;

@@ -90,6 +90,19 @@ struct PtKArgs {
                                     // then the balls around every 8 (gs_stride) and every 64 (cs_stride) sphere slots
   int bs_stride, gs_stride, cs_stride;
   int bs_levels;                    // 1: the group/chunk balls are meaningful (>= 128 spheres, slots in Morton order)
+  // Uniform grid over the bounded, ordinary-sized spheres: scattered and shadow rays of scenes of >= 128 spheres walk
+  // it cell by cell (world_query_lanes).  Cell c holds items [grid_cells[c] >> 8, + (grid_cells[c] & 255)): the ball
+  // (x, y, z, r') of a sphere for the conservative fp32 test and its slot; grid_occ has one bit per cell ("holds
+  // something").  Spheres the grid does not hold (much larger than the rest: a sky dome; or without a bound) are
+  // listed in grid_always and tested for every ray.
+  const unsigned *grid_cells;       // null: no grid
+  const unsigned *grid_occ;
+  const float4 *grid_balls;
+  const unsigned short *grid_slots;
+  const int *grid_always;
+  int grid_n_always, grid_occ_lds;  // grid_occ_lds: where the kernel staged grid_occ in LDS (4-byte words), -1: read it from memory
+  int grid_res[3];
+  float grid_min[3], grid_max[3], grid_cell[3], grid_inv[3];
   int diag_lds;                     // second path-tracer pass: where its copy of diag[] starts in LDS (8-byte words), -1 = not staged
   const PtLight *lights;
   const PtTex *tex;

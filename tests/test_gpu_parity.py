@@ -419,6 +419,47 @@ def test_pathtracer_many_spheres_vs_oracle(dev, oracle):
     assert abs(n_dev - n_rays) <= n_rays // 1000  # (a last-bit libm difference may flip a Russian-roulette draw)
 
 
+@pytest.mark.parametrize("n,renderer,lights", [(2000, abi.RENDERER_PATHTRACER, 0), (1500, abi.RENDERER_POINTLIGHT, 2),
+                                               (4000, abi.RENDERER_PATHTRACER, 0)])
+def test_cell_walk_of_large_scenes_vs_oracle(dev, oracle, n, renderer, lights):
+    """Scenes of >= 1024 bounded spheres: scattered rays (path tracer) and shadow rays (point lights) find their
+    candidates by walking a uniform grid (world_query_lanes: 3D-DDA in fp32 with entered margins) instead of
+    testing every bounding sphere.  A few outsized spheres (the dome, two big balls) stay outside the grid on the
+    'always' list; a dense cluster puts many spheres into few cells.  Against the oracle: <= 1e-5, no outliers
+    beyond the libm ones."""
+    from pytracer_amd import flatten, scenes
+    from pytracer_amd import hostmodel as hm
+
+    world = scenes.synthetic_world(n, wide=True)
+    g = hm.PCG(7, n)
+    r = g.random_float
+    for _ in range(2):  # outsized
+        world.add_shape(hm.Sphere(hm.translation(hm.Vec(12.0 + 8 * r(), -6 + 12 * r(), 1.5)) * hm.scaling(hm.Vec(1.5, 1.5, 1.5)),
+                                  hm.Material(hm.DiffuseBRDF(hm.UniformPigment(hm.Color(0.6, 0.7, 0.2))))))
+    for _ in range(60):  # a dense cluster
+        c = hm.Vec(6.0 + 0.4 * r(), 1.0 + 0.4 * r(), 0.6 + 0.4 * r())
+        world.add_shape(hm.Sphere(hm.translation(c) * hm.scaling(hm.Vec(0.05, 0.05, 0.05)),
+                                  hm.Material(hm.SpecularBRDF(hm.UniformPigment(hm.Color(0.8, 0.8, 0.8))) if r() < 0.3 else
+                                              hm.DiffuseBRDF(hm.UniformPigment(hm.Color(0.2 + 0.6 * r(), 0.5, 0.4))))))
+    for k in range(lights):
+        world.add_light(hm.PointLight(hm.Vec(-3.0 + 20.0 * k, 6.0 - 14.0 * k, 9.0), hm.Color(1.0, 0.9, 0.8), 0.0))
+    W, H = 112, 63
+    scene = flatten.flatten_world(world)
+    cam = flatten.flatten_camera(scenes.synthetic_camera(W, H))
+    par = abi.make_params(W, H, renderer, samples_per_side=2, num_of_rays=2 if n < 4000 else 1, max_depth=3, rr_limit=2,
+                          path_state=45, path_seq=54)
+    with dev.DeviceScene(scene) as ds:
+        out = ds.render(cam, par)
+        n_dev = ds.stats().n_rays
+    ora, n_rays = oracle.render(scene, cam, par, sqr_mode=oracle.SQR_MUL)
+    oracle.set_sqr_mode(oracle.SQR_POW)
+    err = util.rel_err(out, ora)
+    bad = int((err > TOL).any(axis=-1).sum())
+    print(f"grid n={n} renderer={renderer}: max rel {err.max():.3e}, outliers {bad}, rays {n_dev} vs {n_rays}")
+    assert bad <= 2
+    assert abs(int(n_dev) - n_rays) <= max(8, n_rays // 1000)
+
+
 def _random_world(seed):
     """Random spheres (scale+translate and rotated ellipsoids, some enclosing the camera), tilted planes,
     mixed materials: a scene generator with no regard for what the culling code finds convenient."""
