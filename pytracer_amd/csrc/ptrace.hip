@@ -976,7 +976,7 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
     return PT_OK;
   }
   if (p->renderer == PT_RENDERER_PATHTRACER) {
-    // the queue head: zeroed by pt_region_sort between the two passes; by a memset for the one-queue kernel
+    // the queue block (head, unit counts, F; pt_kernels.h: pt_unit_hist) starts every frame zeroed
     HIP_TRY(hipMemsetAsync(s->queue, 0, PT_QUEUE_WORDS * sizeof(unsigned long long), st));
     // step batching (path_trace): the second pass by regions never mixes the two kinds of step (a P step
     // waits until no lane holds a ray: its lanes then move sample by sample); the one-queue kernel, which
