@@ -386,7 +386,30 @@ PT_DEV LatCand lat_cand(double ox, double oy, double oz, double dx, double dy, d
 #define PT_SPARSE_MAX_SPHERES 1024  // ... in scenes up to this size (beyond, skipping whole chunks and groups pays more)
 #endif
 #ifdef PT_DEBUG_TIME
-__device__ unsigned long long pt_dbg[8];  // world_query_lanes: prefilter cycles, walk cycles, iterations, calls; 4..7: units / rounds
+__device__ unsigned long long pt_dbg[8];
+#ifdef PT_DEBUG_TIME
+// latency of single vector-memory operations, log2 buckets: [0] the load of a unit's descriptor, [1] what was still
+// outstanding before it, [2] the returning atomic on a shard's head, [3] the sparse path's load of one ball per lane
+__device__ unsigned long long pt_lat_hist[4][32];
+#define PT_VM_DRAIN() __builtin_amdgcn_s_waitcnt(0x0F70)  // vmcnt(0)
+// ... and the slow ones one by one: (100 MHz wall clock at the end, cycles, which | xcc << 8 | HW_ID << 16)
+#define PT_LAT_EVENTS 4096
+__device__ unsigned long long pt_lat_events[PT_LAT_EVENTS * 3 + 1];
+PT_DEV void lat_note(int which, unsigned long long dt) {
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&pt_lat_hist[which][63 - __clzll((long long)(dt | 1ULL))], 1ULL);
+    if (dt >= 8192ULL) {
+      const unsigned long long at = atomicAdd(&pt_lat_events[PT_LAT_EVENTS * 3], 1ULL);
+      if (at < PT_LAT_EVENTS) {
+        pt_lat_events[at * 3] = __builtin_amdgcn_s_memrealtime();
+        pt_lat_events[at * 3 + 1] = dt;
+        pt_lat_events[at * 3 + 2] = (unsigned long long)which | ((unsigned long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xf) << 8) |
+                                    ((unsigned long long)(unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 16);
+      }
+    }
+  }
+}
+#endif  // world_query_lanes: prefilter cycles, walk cycles, iterations, calls; 4..7: units / rounds
 #define PT_DBG_WAVES 16384
 __device__ unsigned long long pt_dbg_wave[PT_DBG_WAVES * 8];  // the same, per wave, summed up at the end of the kernel
 static __device__ void pt_dbg_flush() {
@@ -740,8 +763,16 @@ PT_DEV int world_query_lanes(const PtKArgs &a, const Ray &r, double tmax, double
       // lane, all 64 balls are tested at once, and the ballot IS that ray's candidate mask.  ~35 instructions
       // per ray and chunk instead of ~800 per chunk for the whole wave.
       const int sl = base + (threadIdx.x & 63);
+#ifdef PT_DEBUG_TIME
+      PT_VM_DRAIN();
+      const unsigned long long lt0 = __builtin_amdgcn_s_memtime();
+#endif
       const float bx = ((const float *)a.bsoa)[sl], by = ((const float *)a.bsoa)[a.bs_stride + sl],
                   bz = ((const float *)a.bsoa)[2 * a.bs_stride + sl], br = ((const float *)a.bsoa)[3 * a.bs_stride + sl];
+#ifdef PT_DEBUG_TIME
+      asm volatile("s_waitcnt vmcnt(0)" : : "v"(bx), "v"(by), "v"(bz), "v"(br) : "memory");
+      lat_note(3, __builtin_amdgcn_s_memtime() - lt0);
+#endif
       const bool mine = (int)(threadIdx.x & 63) < cnt;
       unsigned long long todo = live_lanes;
       while (todo) {
@@ -838,8 +869,10 @@ PT_DEV int world_query_lanes(const PtKArgs &a, const Ray &r, double tmax, double
 // it equals what the reference computed for that candidate.
 // INL: the transcendental functions inline (the latency-bound second pass of the path tracer, which has
 // registers to spare) instead of behind a call (everything that runs at 4-5 waves per SIMD).
-template <bool INL = false>
-PT_DEV void hit_details(const PtShapeRec *rec, const PtShapeAux *ax, const Ray &r, double t, Hit &h, bool need_uv) {
+// (RP / AP: where the records live -- generic pointers into HBM, or address_space(3) pointers when the second
+//  pass of the path tracer has staged the scene in LDS)
+template <bool INL = false, typename RP = const PtShapeRec *, typename AP = const PtShapeAux *>
+PT_DEV void hit_details(RP rec, AP ax, const Ray &r, double t, Hit &h, bool need_uv) {
   // rec / ax: the winner's records (same grouped slot in both tables)
   double im[12];
 #pragma unroll
@@ -886,15 +919,9 @@ PT_NOINLINE void hit_details_call(const PtShapeRec *rec, const PtShapeAux *ax, c
 }
 
 // ---- pigments (materials.py:50-100) --------------------------------------------------------------------
-PT_DEV V3 pigment_color(const PtKArgs &a, int kind, const double *c1, const double *c2, double steps,
-                        int tex, double u, double v) {
-  const double *c = c1;
-  if (kind == PT_PIGMENT_CHECKERED) {
-    const long long iu = (long long)floor(u * steps);
-    const long long iv = (long long)floor(v * steps);
-    // Python's % 2 is non-negative; (x & 1) is the same parity for negative x in two's complement
-    c = ((iu & 1LL) == (iv & 1LL)) ? c1 : c2;
-  } else if (kind == PT_PIGMENT_IMAGE) {
+template <typename CP>
+PT_DEV V3 pigment_color(const PtKArgs &a, int kind, CP c1, CP c2, double steps, int tex, double u, double v) {
+  if (kind == PT_PIGMENT_IMAGE) {
     pt_kargs ca = cold_args(a);
     const PtTex *tx = ca->tex + tex;
     const int w = tx->w, hh = tx->h;
@@ -902,16 +929,27 @@ PT_DEV V3 pigment_color(const PtKArgs &a, int kind, const double *c1, const doub
     long long row = (long long)(v * (double)hh);
     if (col >= w) col = w - 1;
     if (row >= hh) row = hh - 1;
-    c = ca->tex_data + tx->offset + (row * w + col) * 3;
+    const double *c = ca->tex_data + tx->offset + (row * w + col) * 3;
+    V3 r = {c[0], c[1], c[2]};
+    return r;
+  }
+  CP c = c1;
+  if (kind == PT_PIGMENT_CHECKERED) {
+    const long long iu = (long long)floor(u * steps);
+    const long long iv = (long long)floor(v * steps);
+    // Python's % 2 is non-negative; (x & 1) is the same parity for negative x in two's complement
+    c = ((iu & 1LL) == (iv & 1LL)) ? c1 : c2;
   }
   V3 r = {c[0], c[1], c[2]};
   return r;
 }
-PT_DEV V3 brdf_pigment(const PtKArgs &a, const PtShapeAux *ax, double u, double v) {
-  return pigment_color(a, ax->pig_kind, ax->pig_c1, ax->pig_c2, ax->pig_steps, ax->pig_tex, u, v);
+template <typename AP>
+PT_DEV V3 brdf_pigment(const PtKArgs &a, AP ax, double u, double v) {
+  return pigment_color(a, ax->pig_kind, &ax->pig_c1[0], &ax->pig_c2[0], ax->pig_steps, ax->pig_tex, u, v);
 }
-PT_DEV V3 emitted_pigment(const PtKArgs &a, const PtShapeAux *ax, double u, double v) {
-  return pigment_color(a, ax->emi_kind, ax->emi_c1, ax->emi_c2, ax->emi_steps, ax->emi_tex, u, v);
+template <typename AP>
+PT_DEV V3 emitted_pigment(const PtKArgs &a, AP ax, double u, double v) {
+  return pigment_color(a, ax->emi_kind, &ax->emi_c1[0], &ax->emi_c2[0], ax->emi_steps, ax->emi_tex, u, v);
 }
 
 // ---- BRDF.scatter_ray (materials.py:132-152, 175-196; geometry.py:247-262) -------------------------
@@ -1017,6 +1055,12 @@ PT_DEV void store_pixel(const PtKArgs &a, long long pix, V3 v) {
 // into a.ray_counter[blockIdx.x]; pt_sum_counts folds the per-workgroup partials afterwards.
 // A partial carries two counts: all rays of the workgroup and, of those, the rays that were RESOLVED without
 // being traced (tiles / pixels settled by the dome shortcut, pt_tile_kernel).
+// first pass of the path tracer: a region with k flagged pixels -> F (queue[11]) and the histogram over k
+// (queue[16 + k]) that pt_unit_scatter turns into the offsets of the work units
+PT_DEV void note_flagged(unsigned long long *queue, int k) {
+  atomicAdd(queue + 11, (unsigned long long)k);
+  atomicAdd(queue + 16 + k, 1ULL);
+}
 PT_DEV void add_ray_count(const PtKArgs &a, unsigned long long n, int base = 0, unsigned long long resolved = 0) {
   unsigned long long *counter = cold_args(a)->ray_counter;
   if (counter) {
@@ -1824,7 +1868,7 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
           pt_kargs ca = cold_args(a);
           ca->region_mask[tile] = todo;
           ca->region_keys[tile] = (unsigned char)__popcll(todo);
-            if (todo) atomicAdd(ca->queue + 11, (unsigned long long)__popcll(todo));  // F: flagged pixels of the frame
+            if (todo) note_flagged(ca->queue, __popcll(todo));
         }
       }
       continue;
@@ -1945,7 +1989,7 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
             pt_kargs ca = cold_args(a);
             ca->region_mask[tile] = todo;
             ca->region_keys[tile] = (unsigned char)__popcll(todo);
-            if (todo) atomicAdd(ca->queue + 11, (unsigned long long)__popcll(todo));  // F: flagged pixels of the frame
+            if (todo) note_flagged(ca->queue, __popcll(todo));
           }
         }
         __builtin_amdgcn_wave_barrier();  // the next tile overwrites this wave's mask slice
@@ -2020,7 +2064,7 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
         if (lane == 0) {
           ca->region_mask[tile] = todo;
           ca->region_keys[tile] = (unsigned char)__popcll(todo);
-            if (todo) atomicAdd(ca->queue + 11, (unsigned long long)__popcll(todo));  // F: flagged pixels of the frame
+            if (todo) note_flagged(ca->queue, __popcll(todo));
         }
         __builtin_amdgcn_wave_barrier();  // the next tile overwrites this wave's mask slice
         continue;
@@ -2128,7 +2172,7 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
         pt_kargs c = cold_args(a);
         c->region_mask[tile] = todo;
         c->region_keys[tile] = (unsigned char)__popcll(todo);
-        if (todo) atomicAdd(c->queue + 11, (unsigned long long)__popcll(todo));
+        if (todo) note_flagged(c->queue, __popcll(todo));
       }
     }
     __builtin_amdgcn_wave_barrier();  // the next tile overwrites this wave's mask slice
@@ -2155,12 +2199,19 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
 // nothing is spent on idle lanes.  Regions without flagged pixels yield nothing.  The order of the units only
 // changes WHEN a pixel is rendered, never its value.
 // Units with the most pixels come first (they have the fewest lanes per pixel, hence the longest chains): a
-// counting sort by size over two launches of any number of workgroups, one region per thread -- pt_unit_hist
-// counts the units of every size, pt_unit_scatter turns the counts into descending offsets (every workgroup for
-// itself: 64 numbers) and places the units.
+// counting sort by size over any number of workgroups, one region per thread -- the first pass counts the regions
+// by their number of flagged pixels, pt_unit_scatter turns the counts into descending offsets of the unit sizes
+// (every workgroup for itself: 64 numbers) and places the units.
 // queue[0] = queue head, [9] = number of units, [10] = ppu (for the statistics), [11] = F (summed up by the first
-// pass), [16 + k] = units of k pixels, [96 + k] = of those, placed so far; all zeroed before the first pass.
-#define PT_QUEUE_WORDS 176
+// pass), [16 + k] = regions with k flagged pixels (first pass), [96 + s] = units of s pixels placed so far; [PT_QUEUE_HEADS + 32 s] = head of shard s
+// of the unit list (the second pass pulls units through PT_UNIT_SHARDS heads, 256 B apart: one word takes ~88
+// dequeues/us, and thousands of waves pull); all zeroed before the first pass.
+#define PT_QUEUE_WORDS 512
+#define PT_QUEUE_HEADS 256
+#ifndef PT_UNIT_SHARDS
+#define PT_UNIT_SHARDS 8
+#endif
+static_assert(PT_QUEUE_HEADS + 32 * PT_UNIT_SHARDS <= PT_QUEUE_WORDS, "the shard heads must lie inside the queue block");
 PT_DEV int unit_ppu(const unsigned long long *queue, long long lanes_cap, int nsamp, int min_rounds) {
   // lanes per pixel every unit gets at least: the largest power of two (<= S*S, <= 64) at which all flagged
   // pixels together still fit the lanes the launch keeps resident ...
@@ -2169,31 +2220,43 @@ PT_DEV int unit_ppu(const unsigned long long *queue, long long lanes_cap, int ns
   while (lg * 2 <= 64 && lg * 2 <= nsamp && (long long)total * (lg * 2) <= lanes_cap) lg *= 2;
   // ... or more, up to four units per resident wave, as long as a unit keeps `min_rounds` rounds of work: many
   // short units spread over the chip more evenly than few long ones (a unit's time varies a lot with what its
-  // pixels see), but every unit costs a fetch, and lanes beyond what speculation can use are wasted
-  // (PT_PCG_PIXEL asks for more rounds per unit than PT_PCG_SAMPLE for that reason).
-  while (lg * 2 <= 64 && lg * 2 * min_rounds <= nsamp && (long long)total * (lg * 2) <= 4 * lanes_cap) lg *= 2;
+  // pixels see), but every unit costs a fetch and a cull, and lanes beyond what speculation can use are wasted
+  // (PT_PCG_PIXEL asks for more rounds per unit than PT_PCG_SAMPLE for that reason).  min_rounds < 0: -min_rounds
+  // rounds, and single-round units where even those come to three or more per resident wave (a full frame of
+  // PT_PCG_SAMPLE: the fetch is cheap next to what finer balancing saves; with fewer units it is not).
+  const int mr = min_rounds < 0 ? -min_rounds : min_rounds;
+  while (lg * 2 <= 64 && lg * 2 * mr <= nsamp && (long long)total * (lg * 2) <= 4 * lanes_cap) lg *= 2;
+  if (min_rounds < 0 && lg * 2 <= 64 && lg * 2 <= nsamp && (long long)total * (lg * 2) <= 4 * lanes_cap &&
+      (long long)total * (lg * 2) >= 3 * lanes_cap)
+    lg *= 2;
   return 64 / lg;
 }
-__global__ void pt_unit_hist(const unsigned char *keys, int n, unsigned long long *queue, long long lanes_cap, int nsamp,
-                             int min_rounds) {
+__global__ void pt_unit_scatter(const unsigned char *keys, const unsigned long long *masks, int n, int4 *units, int units_cap,
+                                unsigned long long *queue, long long lanes_cap, int nsamp, int min_rounds) {
+  __shared__ int hist[65], cnt[65], offs[65];
   const int ppu = unit_ppu(queue, lanes_cap, nsamp, min_rounds);
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int k = i < n ? keys[i] : 0;
-  if (k) {  // (a few per cent of the regions of a frame)
-    const int full = k / ppu, rem = k - full * ppu;
-    if (full) atomicAdd(queue + 16 + ppu, (unsigned long long)full);
-    if (rem) atomicAdd(queue + 16 + rem, 1ULL);
+  // regions with k flagged pixels (counted by the first pass) -> units of s pixels: a region yields k / ppu units
+  // of ppu pixels and one of k % ppu
+  if (threadIdx.x < 65) {
+    hist[threadIdx.x] = threadIdx.x ? (int)queue[16 + threadIdx.x] : 0;
+    cnt[threadIdx.x] = 0;
   }
-}
-__global__ void pt_unit_scatter(const unsigned char *keys, int n, int2 *units, int units_cap, unsigned long long *queue,
-                                long long lanes_cap, int nsamp, int min_rounds) {
-  __shared__ int offs[65];
-  const int ppu = unit_ppu(queue, lanes_cap, nsamp, min_rounds);
+  __syncthreads();
+  if (threadIdx.x >= 1 && threadIdx.x <= 64) {
+    const int sz = threadIdx.x;
+    int c = 0;
+    if (sz == ppu)
+      for (int k = ppu; k <= 64; ++k) c += hist[k] * (k / ppu);
+    else if (sz < ppu)
+      for (int k = sz; k <= 64; k += ppu) c += hist[k];
+    cnt[sz] = c;
+  }
+  __syncthreads();
   if (threadIdx.x == 0) {
     int run = 0;
     for (int k = 64; k >= 1; --k) {
       offs[k] = run;
-      run += (int)queue[16 + k];
+      run += cnt[k];
     }
     if (blockIdx.x == 0) {
       queue[9] = (unsigned long long)(run < units_cap ? run : units_cap);
@@ -2204,15 +2267,17 @@ __global__ void pt_unit_scatter(const unsigned char *keys, int n, int2 *units, i
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int k = i < n ? keys[i] : 0;
   if (!k) return;
+  const unsigned long long m = masks[i];  // carried in the unit: one dependent load less when a wave fetches it
+  const int mlo = (int)(unsigned)m, mhi = (int)(unsigned)(m >> 32);
   const int full = k / ppu, rem = k - full * ppu;
   if (full) {
     const int at = offs[ppu] + (int)atomicAdd(queue + 96 + ppu, (unsigned long long)full);
     for (int g = 0; g < full; ++g)
-      if (at + g < units_cap) units[at + g] = make_int2(i, (g * ppu) | (ppu << 8));  // (region, first | count << 8)
+      if (at + g < units_cap) units[at + g] = make_int4(i, (g * ppu) | (ppu << 8), mlo, mhi);  // (region, first | count << 8, mask)
   }
   if (rem) {
     const int at = offs[rem] + (int)atomicAdd(queue + 96 + rem, 1ULL);
-    if (at < units_cap) units[at] = make_int2(i, (full * ppu) | (rem << 8));
+    if (at < units_cap) units[at] = make_int4(i, (full * ppu) | (rem << 8), mlo, mhi);
   }
 }
 
@@ -2302,7 +2367,7 @@ PT_DEV long long next_pixel(const PtKArgs &a, bool need, long long npix) {
 // !TILED (orthogonal camera): 1 lane = 1 pixel, pixels come from one global queue, a lane walks its pixel's
 // samples one after the other and P-steps run the full shape loop.
 //
-// TILED (perspective camera, second pass): a wave works through UNITS (pt_unit_sort): up to 64 flagged pixels
+// TILED (perspective camera, second pass): a wave works through UNITS (pt_unit_scatter): up to 64 flagged pixels
 // of one 8x8 region.  The unit's P-steps use the hoisted, culled tile query against the region's survivor
 // masks.  The wave's lanes are shared out L = min(S*S, 64 / pixels) to a pixel, and the L lanes of a pixel
 // trace L consecutive samples of it AT THE SAME TIME (a "round"):
@@ -2325,9 +2390,12 @@ PT_DEV long long next_pixel(const PtKArgs &a, bool need, long long npix) {
 #ifndef PT_REGIONS_INLINE
 #define PT_REGIONS_INLINE 1  // second pass: HitRecord / scatter / transcendental code inline (1) or behind calls (0)
 #endif
-template <bool TILED, bool LDSF, bool LAT>
+typedef const __attribute__((address_space(3))) PtShapeRec *pt_lds_rec;
+typedef const __attribute__((address_space(3))) PtShapeAux *pt_lds_aux;
+template <bool TILED, bool LDSF, bool LAT, bool SLDS = false>
 PT_DEV void path_trace(const PtKArgs &a) {
   constexpr bool INL = LAT && PT_REGIONS_INLINE;
+  static_assert(!SLDS || INL, "the scene is staged in LDS for the second pass only");
   PathCtx w;
   int S, nsamp, N, W = 0, rows_local = 0, npass = 0, D = 0, rr = 0, diag_lds = -1, pcg_mode = PT_PCG_PIXEL;
   bool ortho = false;
@@ -2356,6 +2424,17 @@ PT_DEV void path_trace(const PtKArgs &a) {
     for (int k = threadIdx.x; k < a.n_diag * 8; k += PT_BLOCK) pt_lds_masks[diag_lds + k] = src[k];
     __syncthreads();
   }
+  int scene_lds = 0;
+  if (SLDS) {
+    // the shapes' records (128 B + 256 B each) into LDS: shading gathers ~20 values of the hit shape per lane, and a
+    // gather from LDS costs a fraction of one through the vector memory path (8 waves of a CU share one of those)
+    scene_lds = cold_args(a)->scene_lds;
+    const unsigned long long *src = (const unsigned long long *)a.recs;
+    for (int k = threadIdx.x; k < a.n_shapes * 16; k += PT_BLOCK) pt_lds_masks[scene_lds + k] = src[k];
+    src = (const unsigned long long *)a.aux;
+    for (int k = threadIdx.x; k < a.n_shapes * 32; k += PT_BLOCK) pt_lds_masks[scene_lds + a.n_shapes * 16 + k] = src[k];
+    __syncthreads();
+  }
   if (LAT) {  // the grid's occupancy bits into LDS: the cell walk of world_query_lanes reads one per step
     pt_kargs c = cold_args(a);
     const int occ_lds = c->grid_occ_lds;
@@ -2373,6 +2452,8 @@ PT_DEV void path_trace(const PtKArgs &a) {
   const int regions_x = (W + PT_REGION - 1) / PT_REGION;
   bool exhausted = false;           // !TILED: the global queue is empty
   bool first_unit = true;           // TILED (wave-uniform)
+  // TILED: units of the frame (written by pt_unit_scatter before this kernel started; read once -- not from the heads' lines)
+  const int n_units = TILED ? (int)cold_args(a)->queue[9] : 0;
   unsigned long long nrays = 0;
 
   // lane state.  mode 0: starts a sample at the next P-step; 1: inside a path (S-steps); 2: nothing to do;
@@ -2439,16 +2520,7 @@ PT_DEV void path_trace(const PtKArgs &a) {
 
   // render.py:103-139 up to (not including) the recursion: sets `ret`, or pushes frame `sp` and asks
   // for child 0 (`spawn`).  `ray` is the ray that was queried, at depth `sp`.
-  auto shade = [&](int hit, double best_t) {
-    spawn = false;
-    if (hit < 0) {  // render.py:103-105
-      pt_kargs c = cold_args(a);
-      ret.x = c->bg[0];
-      ret.y = c->bg[1];
-      ret.z = c->bg[2];
-      return;
-    }
-    const PtShapeAux *ax = cold_args(a)->aux + hit;
+  auto shade_hit = [&](auto rec, auto ax, double best_t) {
     V3 hc, em;
     double lum;
     Hit h;
@@ -2457,10 +2529,10 @@ PT_DEV void path_trace(const PtKArgs &a) {
     const bool uv = ax->needs_uv != 0;
     bool details = false;
     if (uv) {
-      if (INL)
-        hit_details<true>(a.recs + hit, ax, ray, best_t, h, true);
+      if constexpr (INL)
+        hit_details<true>(rec, ax, ray, best_t, h, true);
       else
-        hit_details_call(a.recs + hit, ax, &ray, best_t, &h, true);
+        hit_details_call(rec, ax, &ray, best_t, &h, true);
       details = true;
     }
     hc = brdf_pigment(a, ax, h.u, h.v);
@@ -2507,10 +2579,10 @@ PT_DEV void path_trace(const PtKArgs &a) {
     }
     // render.py:126-137: push the frame, child 0 is scattered at the next S-step
     if (!details) {
-      if (INL)
-        hit_details<true>(a.recs + hit, ax, ray, best_t, h, false);
+      if constexpr (INL)
+        hit_details<true>(rec, ax, ray, best_t, h, false);
       else
-        hit_details_call(a.recs + hit, ax, &ray, best_t, &h, false);
+        hit_details_call(rec, ax, &ray, best_t, &h, false);
     }
     ws_put<LDSF>(w, sp, 0, hc.x);
     ws_put<LDSF>(w, sp, 1, hc.y);
@@ -2540,6 +2612,21 @@ PT_DEV void path_trace(const PtKArgs &a) {
     f_brdf = ax->brdf_kind;
     sp++;
     spawn = true;
+  };
+  auto shade = [&](int hit, double best_t) {
+    spawn = false;
+    if (hit < 0) {  // render.py:103-105
+      pt_kargs c = cold_args(a);
+      ret.x = c->bg[0];
+      ret.y = c->bg[1];
+      ret.z = c->bg[2];
+      return;
+    }
+    if constexpr (SLDS)
+      shade_hit((pt_lds_rec)(const void *)(pt_lds_f64 + scene_lds) + hit,
+                (pt_lds_aux)(const void *)(pt_lds_f64 + scene_lds + a.n_shapes * 16) + hit, best_t);
+    else
+      shade_hit(a.recs + hit, cold_args(a)->aux + hit, best_t);
   };
 
   // the primary call returned `ret`: one sample done (imagetracer.py:94-104)
@@ -2579,6 +2666,7 @@ PT_DEV void path_trace(const PtKArgs &a) {
   int trace_n = 0;
   int ulog_seq = -1, ulog_rounds = 0, ulog_iters = 0;
   unsigned long long ulog_t[4] = {0, 0, 0, 0};
+  unsigned long long dbg_q[3] = {0, 0, 0};
 #define PT_STAMP(k)                                                                        \
   do {                                                                                     \
     const unsigned long long tn = __builtin_amdgcn_s_memtime();                            \
@@ -2684,20 +2772,41 @@ PT_DEV void path_trace(const PtKArgs &a) {
             }
           }
         }
+        PT_STAMP(3);
         if (!__any(mode == 0)) {
-          // next unit for this wave, then its region's cone and survivor masks.  The first one is the
-          // wave's own index (thousands of waves start together: one atomic each on the queue head would
-          // serialise them); later ones come from the queue, one atomic by lane 0.
+          // next unit for this wave, then its region's cone and survivor masks.  The sorted unit list is dealt out
+          // to PT_UNIT_SHARDS shards (unit u belongs to shard u % shards: every shard the same mix of sizes) and a
+          // workgroup pulls from shard blockIdx % shards only: a returning atomic on ONE head word saturates near 88
+          // dequeues/us -- with thousands of waves pulling, queueing at the head costs more than a unit's work.  A
+          // wave's first unit is its own rank in the shard (no atomic at all), later ones come from the shard's head,
+          // one atomic by lane 0.
           unsigned uid = 0;
+          const unsigned nsh = gridDim.x < PT_UNIT_SHARDS ? gridDim.x : PT_UNIT_SHARDS;  // (every shard needs a puller)
+          const unsigned shard = blockIdx.x % nsh;
           if (first_unit) {
-            uid = blockIdx.x * (PT_BLOCK / 64) + (threadIdx.x >> 6);
+            uid = (blockIdx.x / nsh) * (PT_BLOCK / 64) + (threadIdx.x >> 6);
             first_unit = false;
           } else {
-            if (lane == 0) uid = gridDim.x * (PT_BLOCK / 64) + (unsigned)atomicAdd(cold_args(a)->queue, 1ULL);
+            const unsigned pullers = (gridDim.x - shard + nsh - 1) / nsh * (PT_BLOCK / 64);
+#ifdef PT_DEBUG_TIME
+            PT_VM_DRAIN();
+            const unsigned long long lt0 = __builtin_amdgcn_s_memtime();
+#endif
+            if (lane == 0) uid = pullers + (unsigned)atomicAdd(cold_args(a)->queue + PT_QUEUE_HEADS + 32 * shard, 1ULL);
+#ifdef PT_DEBUG_TIME
+            asm volatile("s_waitcnt vmcnt(0)" : : "v"(uid) : "memory");
+            lat_note(2, __builtin_amdgcn_s_memtime() - lt0);
+#endif
           }
+          uid = uid * nsh + shard;
           const int seq = (int)__builtin_amdgcn_readfirstlane((int)uid);
+          PT_STAMP(6);
 #ifdef PT_DEBUG_TIME
           tracing = seq == cold_args(a)->dbg_trace_unit;
+          if (LAT && tracing && lane == 0) {
+            const unsigned long long *wv = pt_dbg_wave + (size_t)((blockIdx.x * PT_BLOCK + threadIdx.x) >> 6) * 8;
+            for (int q = 0; q < 3; ++q) dbg_q[q] = __hip_atomic_load(wv + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
           if (lane == 0 && ulog_seq >= 0 && ulog_seq < PT_UNITLOG_LEN) {  // close the log entry of the unit just finished
             pt_unitlog[ulog_seq * 8 + 1] = __builtin_amdgcn_s_memtime();
             pt_unitlog[ulog_seq * 8 + 2] = (unsigned long long)ulog_rounds | ((unsigned long long)ulog_iters << 32);
@@ -2715,13 +2824,23 @@ PT_DEV void path_trace(const PtKArgs &a) {
           ulog_iters = 0;
 #endif
           pt_kargs ca = cold_args(a);
-          if (seq >= (int)ca->queue[9]) break;  // (written by pt_unit_sort, before this kernel started)
+          if (seq >= n_units) break;
 #ifdef PT_DEBUG_TIME
           if (lane == 0) pt_dbg_wave[(size_t)((blockIdx.x * PT_BLOCK + threadIdx.x) >> 6) * 8 + 7] += 1ULL;
 #endif
-          const int2 unit = ca->units[seq];
+#ifdef PT_DEBUG_TIME
+          const unsigned long long lt0 = __builtin_amdgcn_s_memtime();
+          PT_VM_DRAIN();
+          const unsigned long long lt1 = __builtin_amdgcn_s_memtime();
+          const int4 unit = ca->units[seq];
+          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : : "v"(unit.x) : "memory");
+          lat_note(0, __builtin_amdgcn_s_memtime() - lt1);
+          lat_note(1, lt1 - lt0);
+#else
+          const int4 unit = ca->units[seq];
+#endif
           const int region = unit.x, first = unit.y & 0xff, count = (unit.y >> 8) & 0xff;
-          const unsigned long long todo = ca->region_mask[region];  // left over by the first pass
+          const unsigned long long todo = (unsigned long long)(unsigned)unit.z | ((unsigned long long)(unsigned)unit.w << 32);  // the region's flagged pixels
           const int ry = region / regions_x, rx = region - ry * regions_x;
           const int gr0 = global_row(a, ry * PT_REGION);
           const int gr1 = global_row(a, (ry * PT_REGION + PT_REGION - 1 < rows_local) ? ry * PT_REGION + PT_REGION - 1 : rows_local - 1);
@@ -2829,6 +2948,19 @@ PT_DEV void path_trace(const PtKArgs &a) {
         best_t = ts;
       }
       PT_STAMP(4);
+#ifdef PT_DEBUG_TIME
+      if (LAT && tracing && lane == 0) {  // the traced unit: this query's prefilter cycles (8), walk cycles (9), walk turns (10)
+        const unsigned long long *wv = pt_dbg_wave + (size_t)((blockIdx.x * PT_BLOCK + threadIdx.x) >> 6) * 8;
+        for (int q = 0; q < 3; ++q) {
+          const unsigned long long now = __hip_atomic_load(wv + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (trace_n < PT_TRACE_LEN) pt_trace[trace_n] = ((now - dbg_q[q]) << 16) | (unsigned long long)(8 + q);
+          dbg_q[q] = now;
+          trace_n++;
+        }
+      } else if (LAT && tracing) {
+        trace_n += 3;
+      }
+#endif
     }
 
     // ---- shade the hit, then unwind: deliver radiance up the stack / scatter the next child, until
@@ -2915,9 +3047,9 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAV
 #ifndef PT_WAVES_REGIONS
 #define PT_WAVES_REGIONS 2
 #endif
-template <bool LDSF>
+template <bool LDSF, bool SLDS = false>
 __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAVES_REGIONS, 8))) void pt_path_regions_kernel(const PtKArgs a) {
-  path_trace<true, LDSF, true>(a);
+  path_trace<true, LDSF, true, SLDS>(a);
 }
 
 // ---- culling probe: cone_keeps / pixel_cone exactly as the render kernels evaluate them, one wave ---------------

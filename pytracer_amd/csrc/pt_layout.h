@@ -103,6 +103,7 @@ struct PtKArgs {
   int grid_n_always, grid_occ_lds;  // grid_occ_lds: where the kernel staged grid_occ in LDS (4-byte words), -1: read it from memory
   int grid_res[3];
   float grid_min[3], grid_max[3], grid_cell[3], grid_inv[3];
+  int scene_lds;                    // second path-tracer pass: where recs[] then aux[] are staged in LDS (8-byte words, 256-B aligned), -1 = not
   int diag_lds;                     // second path-tracer pass: where its copy of diag[] starts in LDS (8-byte words), -1 = not staged
   const PtLight *lights;
   const PtTex *tex;
@@ -111,7 +112,7 @@ struct PtKArgs {
   double *ws;                      // path-tracer frame stack: [slot][field][thread]
   unsigned long long *ray_counter; // per-workgroup partial counts; may be null
   unsigned long long *queue;       // path tracer: next unassigned pixel (zeroed per launch)
-  const int2 *units;               // path tracer, second pass: (region, first flagged pixel | pixels << 8) per work unit
+  const int4 *units;               // path tracer, second pass: (region, first flagged pixel | pixels << 8, region mask) per work unit
   int dome_slot;                   // path tracer, first pass: the sphere the camera is deepest inside (uniform pigments), or -1
   int dome_shortcut;               // 0: every tile goes through rays (pt_set_dome_shortcut; a measurement switch)
   int dbg_trace_unit;              // -DPT_DEBUG_TIME builds: the unit whose steps are traced (PTRACE_TRACE_UNIT)

@@ -76,7 +76,7 @@ struct pt_scene {
     double invm[12];
   };
   std::vector<DomeCand> dome_cands;  // spheres that may serve as "the dome" of a view: uniform pigments, sane scale
-  int2 *units = nullptr;  // second pass: work units (pt_unit_sort)
+  int4 *units = nullptr;  // second pass: work units (pt_unit_scatter)
   int units_cap = 0;
   unsigned long long *region_mask = nullptr;
   int region_cap = 0;
@@ -814,6 +814,7 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
   a.grid_always = s->grid_always;
   a.grid_n_always = s->grid_n_always;
   a.grid_occ_lds = -1;
+  a.scene_lds = -1;
   for (int q = 0; q < 3; ++q) {
     a.grid_res[q] = s->grid_res[q];
     a.grid_min[q] = s->grid_min[q];
@@ -904,6 +905,17 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
       a.grid_occ_lds = (int)((base_lds + diag_lds_bytes) / 4);
       diag_lds_bytes += occ_bytes;  // (from here on: everything staged behind the frames)
     }
+    // ... and the shapes' own records (what shading gathers per lane), while two workgroups still fit a CU
+    static const int env_slds = getenv("PTRACE_SCENE_LDS") ? atoi(getenv("PTRACE_SCENE_LDS")) : 1;
+    a.scene_lds = -1;
+    if (regions && lds_frames && env_slds) {
+      const size_t at = (base_lds + diag_lds_bytes + 255) / 256 * 256;
+      const size_t scene_bytes = (size_t)s->n_shapes * (sizeof(PtShapeRec) + sizeof(PtShapeAux));
+      if (at + scene_bytes <= PT_LDS_BUDGET / 2) {
+        a.scene_lds = (int)(at / 8);
+        diag_lds_bytes = at + scene_bytes - base_lds;
+      }
+    }
     if (lds_frames || diag_lds_bytes)
       wg_per_cu = std::min<int>(wg_per_cu, (int)(PT_LDS_BUDGET / std::max<size_t>(1, base_lds + diag_lds_bytes)));
     cap = (long long)s->n_cu * wg_per_cu;
@@ -976,7 +988,7 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
     return PT_OK;
   }
   if (p->renderer == PT_RENDERER_PATHTRACER) {
-    // the queue block (head, unit counts, F; pt_kernels.h: pt_unit_hist) starts every frame zeroed
+    // the queue block (head, unit counts, F; pt_kernels.h: pt_unit_scatter) starts every frame zeroed
     HIP_TRY(hipMemsetAsync(s->queue, 0, PT_QUEUE_WORDS * sizeof(unsigned long long), st));
     // step batching (path_trace): the second pass by regions never mixes the two kinds of step (a P step
     // waits until no lane holds a ray: its lanes then move sample by sample); the one-queue kernel, which
@@ -998,14 +1010,14 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
     a.ws = s->ws;
   }
 
-  // path tracer: per-region masks/keys from the first pass, work units for the second from pt_unit_sort
+  // path tracer: per-region masks/keys from the first pass, work units for the second from pt_unit_scatter
   const int nregions = path_tiled ? ((p->width + PT_REGION - 1) / PT_REGION) * ((rows + PT_REGION - 1) / PT_REGION) : 0;
-  // lanes the second pass keeps resident: pt_unit_sort cuts regions into smaller units (more lanes per
+  // lanes the second pass keeps resident: pt_unit_scatter cuts regions into smaller units (more lanes per
   // pixel) as long as all flagged pixels together still fit them
   static const int env_lanes_cap = getenv("PTRACE_UNIT_LANES_CAP") ? atoi(getenv("PTRACE_UNIT_LANES_CAP")) : -1;  // 0: a unit = a region
   const long long lanes_cap = env_lanes_cap >= 0 ? (long long)env_lanes_cap : (long long)grid * PT_BLOCK;
   if (path_tiled) {
-    const int units_need = nregions + (int)(4 * lanes_cap / 64) + 64;  // (pt_unit_hist may cut up to four units per resident wave)
+    const int units_need = nregions + (int)(4 * lanes_cap / 64) + 64;  // (pt_unit_scatter may cut up to four units per resident wave)
     if (nregions > s->region_cap || units_need > s->units_cap) {
       HIP_TRY(hipStreamSynchronize(st));
       if (s->region_keys) HIP_TRY(hipFree(s->region_keys));
@@ -1017,7 +1029,7 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
       s->region_cap = 0;
       s->units_cap = 0;
       HIP_TRY(hipMalloc((void **)&s->region_keys, (size_t)nregions));
-      HIP_TRY(hipMalloc((void **)&s->units, (size_t)units_need * sizeof(int2)));
+      HIP_TRY(hipMalloc((void **)&s->units, (size_t)units_need * sizeof(int4)));
       HIP_TRY(hipMalloc((void **)&s->region_mask, (size_t)nregions * sizeof(unsigned long long)));
       s->region_cap = nregions;
       s->units_cap = units_need;
@@ -1141,12 +1153,13 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
       // second pass: the pixels the first one flagged, fullest regions first
       const int nsamp = p->samples_per_side > 0 ? p->samples_per_side * p->samples_per_side : 1;
       static const int env_minr = getenv("PTRACE_UNIT_MIN_ROUNDS") ? atoi(getenv("PTRACE_UNIT_MIN_ROUNDS")) : 0;
-      const int min_rounds = env_minr > 0 ? env_minr : (a.pcg_mode == PT_PCG_SAMPLE ? 8 : 16);
-      hipLaunchKernelGGL(pt_unit_hist, dim3((nregions + 1023) / 1024), dim3(1024), 0, st, s->region_keys, nregions, s->queue, lanes_cap, nsamp,
-                         min_rounds);
-      hipLaunchKernelGGL(pt_unit_scatter, dim3((nregions + 1023) / 1024), dim3(1024), 0, st, s->region_keys, nregions, s->units, s->units_cap,
+      const int min_rounds = env_minr != 0 ? env_minr : (a.pcg_mode == PT_PCG_SAMPLE ? -2 : 16);  // (< 0: see unit_ppu)
+      hipLaunchKernelGGL(pt_unit_scatter, dim3((nregions + 1023) / 1024), dim3(1024), 0, st, s->region_keys, s->region_mask, nregions, s->units, s->units_cap,
                          s->queue, lanes_cap, nsamp, min_rounds);
-      if (lds_frames) {
+      if (lds_frames && a.scene_lds >= 0) {
+        HIP_TRY(path_lds_limit((const void *)pt_path_regions_kernel<true, true>, lds + frame_lds + diag_lds_bytes));
+        PT_LAUNCH((pt_path_regions_kernel<true, true>), grid, lds + frame_lds + diag_lds_bytes, true, a);
+      } else if (lds_frames) {
         HIP_TRY(path_lds_limit((const void *)pt_path_regions_kernel<true>, lds + frame_lds + diag_lds_bytes));
         PT_LAUNCH((pt_path_regions_kernel<true>), grid, lds + frame_lds + diag_lds_bytes, true, a);
       } else {
@@ -1508,6 +1521,30 @@ extern "C" int pt_debug_read_dbg(unsigned long long *out8, int reset) {
   if (reset) {
     unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(pt_dbg), z, sizeof z));
+  }
+  return PT_OK;
+}
+extern "C" int pt_debug_read_lat_hist(unsigned long long *out128, int clear) {
+#ifdef PT_DEBUG_TIME
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpyFromSymbol(out128, HIP_SYMBOL(pt_lat_hist), 128 * sizeof(unsigned long long)));
+  if (clear) {
+    static const unsigned long long zeros[128] = {0};
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(pt_lat_hist), zeros, sizeof(zeros)));
+  }
+  return PT_OK;
+#else
+  (void)out128;
+  (void)clear;
+  return PT_ERR_INVALID;
+#endif
+}
+extern "C" int pt_debug_read_lat_events(unsigned long long *out, int clear) {  // out: PT_LAT_EVENTS * 3 + 1 words
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(pt_lat_events), (PT_LAT_EVENTS * 3 + 1) * sizeof(unsigned long long)));
+  if (clear) {
+    const unsigned long long zero = 0;
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(pt_lat_events), &zero, sizeof(zero), (PT_LAT_EVENTS * 3) * sizeof(unsigned long long)));
   }
   return PT_OK;
 }

@@ -17,7 +17,7 @@ for _ in range(1):
 q = (C.c_ulonglong * 16)()
 _lib.lib().pt_debug_read_queue(ds._h, q)
 t = np.array([q[i] for i in range(1, 9)], dtype=np.float64)
-names = ["0 handout", "1 start_sample", "2 tile query (P)", "3 -", "4 full query (S)", "5 shade+unwind+scatter", "6 -", "7 loop top"]
+names = ["0 unit setup", "1 start_sample", "2 tile query (P)", "3 round commit", "4 full query (S)", "5 shade+unwind+scatter", "6 unit fetch (atomic)", "7 loop top"]
 print("kernel ms", ds.stats().kernel_ms, "rays", ds.stats().n_rays)
 for n, v in zip(names, t):
     print(f"{n:22s} {v:12.0f} cycles")

@@ -50,4 +50,36 @@ for name in sys.argv[1:]:
         sel = (dur >= np.percentile(dur, lo)) & (dur <= np.percentile(dur, hi))
         print(f"   duration quartile {lo}-{hi}: rounds {rounds[sel].mean():.1f} iterations {iters[sel].mean():.1f} count {count[sel].mean():.1f} per-iteration {(dur[sel] / np.maximum(1, iters[sel])).mean():.1f} kcyc"
               f" | kcyc in: scattered queries {a[sel, 4].mean() / 1e3:.0f}, shade {a[sel, 5].mean() / 1e3:.0f}, start+primary {a[sel, 6].mean() / 1e3:.0f}, commit+fetch {a[sel, 7].mean() / 1e3:.0f}")
+    if os.environ.get("DBG_LAT"):  # latency histograms of single vector-memory operations (cycles, log2 buckets)
+        hb = (C.c_ulonglong * 128)()
+        _lib.lib().pt_debug_read_lat_hist(hb, 1)
+        h = np.array(list(hb), dtype=np.int64).reshape(4, 32)
+        for k, what in enumerate(("load of a unit descriptor", "  outstanding before it", "atomic on a shard head", "sparse path: one ball per lane")):
+            tot = max(1, h[k].sum())
+            print(f"   {what:32s} n={h[k].sum():6d} " + " ".join(f"2^{b}:{h[k, b]}" for b in range(32) if h[k, b]))
+    if os.environ.get("DBG_LAT"):  # the slow operations one by one: do they cluster in time (per XCD, per CU)?
+        ne = 4096
+        eb = (C.c_ulonglong * (ne * 3 + 1))()
+        _lib.lib().pt_debug_read_lat_events(eb, 1)
+        nev = min(ne, int(eb[ne * 3]))
+        ev = np.array(list(eb)[: nev * 3], dtype=np.int64).reshape(nev, 3)
+        if nev:
+            if os.path.isdir("gpurun_out"):
+                np.save("gpurun_out/lat_events.npy", ev)
+            t = (ev[:, 0] - ev[:, 0].min()) / 100.0  # us (100 MHz)
+            which, xcc, hwid = ev[:, 2] & 0xff, (ev[:, 2] >> 8) & 0xff, ev[:, 2] >> 16
+            cu, se = (hwid >> 8) & 0xf, (hwid >> 13) & 0x7
+            print(f"   {nev} operations of >= 8192 cycles; end time (us) histogram in 20-us bins: {np.histogram(t, bins=np.arange(0, t.max() + 20, 20))[0].tolist()}")
+            for x in range(8):
+                sel = xcc == x
+                print(f"     xcc {x}: {sel.sum()} slow ops, by 20-us bin {np.histogram(t[sel], bins=np.arange(0, t.max() + 20, 20))[0].tolist()}, distinct (se,cu) {len(set(zip(se[sel].tolist(), cu[sel].tolist())))}")
+            o = np.argsort(t)
+            print("     first 40 by time: " + " ".join(f"{t[i]:.1f}us/x{xcc[i]}s{se[i]}c{cu[i]}/k{which[i]}/{ev[i, 1] // 1000}k" for i in o[:40]))
+    if os.environ.get("DBG_TRACE"):  # the per-step trace of unit PTRACE_TRACE_UNIT: (cycles since the previous stamp, lanes holding a ray, section)
+        nt = 8192
+        tb = (C.c_ulonglong * nt)()
+        _lib.lib().pt_debug_read_trace(tb, nt)
+        rows = [(tb[i] >> 16, (tb[i] >> 8) & 0xff, tb[i] & 0xff) for i in range(nt) if tb[i]]
+        print(f"   trace of unit {os.environ.get('PTRACE_TRACE_UNIT')}: {len(rows)} stamps; section:cycles(lanes with a ray)")
+        print("   " + " ".join(f"{k}:{t}({npth})" for t, npth, k in rows[:400]))
     ds.close()
