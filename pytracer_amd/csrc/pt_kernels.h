@@ -63,6 +63,18 @@ PT_DEV pt_kargs cold_args(const PtKArgs &a) {
   return (pt_kargs)p;
 }
 
+// The path tracer's queue block (layout: see pt_unit_scatter) exists twice; frame f uses block f & 1 (a.qpar, a
+// by-value argument so that the device copy of the argument block stays the same from frame to frame) and its
+// path kernel zeroes the other one for the next frame.
+#define PT_QUEUE_WORDS 512
+#define PT_QUEUE_HEADS 256
+#ifndef PT_UNIT_SHARDS
+#define PT_UNIT_SHARDS 8
+#endif
+static_assert(PT_QUEUE_HEADS + 32 * PT_UNIT_SHARDS <= PT_QUEUE_WORDS, "the shard heads must lie inside the queue block");
+PT_DEV unsigned long long *pt_queue(const PtKArgs &a) { return cold_args(a)->queue + (size_t)a.qpar * PT_QUEUE_WORDS; }
+PT_DEV unsigned long long *pt_queue_next(const PtKArgs &a) { return cold_args(a)->queue + (size_t)(a.qpar ^ 1) * PT_QUEUE_WORDS; }
+
 struct V3 {
   double x, y, z;
 };
@@ -1868,7 +1880,7 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
           pt_kargs ca = cold_args(a);
           ca->region_mask[tile] = todo;
           ca->region_keys[tile] = (unsigned char)__popcll(todo);
-            if (todo) note_flagged(ca->queue, __popcll(todo));
+            if (todo) note_flagged(pt_queue(a), __popcll(todo));
         }
       }
       continue;
@@ -1989,7 +2001,7 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
             pt_kargs ca = cold_args(a);
             ca->region_mask[tile] = todo;
             ca->region_keys[tile] = (unsigned char)__popcll(todo);
-            if (todo) note_flagged(ca->queue, __popcll(todo));
+            if (todo) note_flagged(pt_queue(a), __popcll(todo));
           }
         }
         __builtin_amdgcn_wave_barrier();  // the next tile overwrites this wave's mask slice
@@ -2064,7 +2076,7 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
         if (lane == 0) {
           ca->region_mask[tile] = todo;
           ca->region_keys[tile] = (unsigned char)__popcll(todo);
-            if (todo) note_flagged(ca->queue, __popcll(todo));
+            if (todo) note_flagged(pt_queue(a), __popcll(todo));
         }
         __builtin_amdgcn_wave_barrier();  // the next tile overwrites this wave's mask slice
         continue;
@@ -2172,7 +2184,7 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
         pt_kargs c = cold_args(a);
         c->region_mask[tile] = todo;
         c->region_keys[tile] = (unsigned char)__popcll(todo);
-        if (todo) note_flagged(c->queue, __popcll(todo));
+        if (todo) note_flagged(pt_queue(a), __popcll(todo));
       }
     }
     __builtin_amdgcn_wave_barrier();  // the next tile overwrites this wave's mask slice
@@ -2182,7 +2194,7 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
 #ifdef PT_DEBUG_TIME
   // sampled (every 64th workgroup) so that the report's own atomics do not disturb the other waves
   if (RENDERER != PT_RENDERER_PATHTRACER && (threadIdx.x & 63) == 0 && (blockIdx.x & 63) == 0)
-    for (int q = 0; q < 8; ++q) atomicAdd(cold_args(a)->queue + 1 + q, tsum[q]);
+    for (int q = 0; q < 8; ++q) atomicAdd(pt_queue(a) + 1 + q, tsum[q]);
   pt_dbg_flush();
 #endif
   add_ray_count(a, nrays, count_base, nres);
@@ -2206,12 +2218,6 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
 // pass), [16 + k] = regions with k flagged pixels (first pass), [96 + s] = units of s pixels placed so far; [PT_QUEUE_HEADS + 32 s] = head of shard s
 // of the unit list (the second pass pulls units through PT_UNIT_SHARDS heads, 256 B apart: one word takes ~88
 // dequeues/us, and thousands of waves pull); all zeroed before the first pass.
-#define PT_QUEUE_WORDS 512
-#define PT_QUEUE_HEADS 256
-#ifndef PT_UNIT_SHARDS
-#define PT_UNIT_SHARDS 8
-#endif
-static_assert(PT_QUEUE_HEADS + 32 * PT_UNIT_SHARDS <= PT_QUEUE_WORDS, "the shard heads must lie inside the queue block");
 PT_DEV int unit_ppu(const unsigned long long *queue, long long lanes_cap, int nsamp, int min_rounds) {
   // lanes per pixel every unit gets at least: the largest power of two (<= S*S, <= 64) at which all flagged
   // pixels together still fit the lanes the launch keeps resident ...
@@ -2233,45 +2239,57 @@ PT_DEV int unit_ppu(const unsigned long long *queue, long long lanes_cap, int ns
 }
 __global__ void pt_unit_scatter(const unsigned char *keys, const unsigned long long *masks, int n, int4 *units, int units_cap,
                                 unsigned long long *queue, long long lanes_cap, int nsamp, int min_rounds) {
-  __shared__ int hist[65], cnt[65], offs[65];
+  __shared__ int cnt[65], offs[65];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int k = i < n ? keys[i] : 0;
+  const unsigned long long m = i < n ? masks[i] : 0ULL;  // carried in the unit: one dependent load less when a wave fetches it
   const int ppu = unit_ppu(queue, lanes_cap, nsamp, min_rounds);
   // regions with k flagged pixels (counted by the first pass) -> units of s pixels: a region yields k / ppu units
-  // of ppu pixels and one of k % ppu
-  if (threadIdx.x < 65) {
-    hist[threadIdx.x] = threadIdx.x ? (int)queue[16 + threadIdx.x] : 0;
-    cnt[threadIdx.x] = 0;
-  }
+  // of ppu pixels and one of k % ppu.  The first wave does it, lane k - 1 for the regions of k pixels.
+  if (threadIdx.x < 65) cnt[threadIdx.x] = 0;
   __syncthreads();
-  if (threadIdx.x >= 1 && threadIdx.x <= 64) {
-    const int sz = threadIdx.x;
-    int c = 0;
-    if (sz == ppu)
-      for (int k = ppu; k <= 64; ++k) c += hist[k] * (k / ppu);
-    else if (sz < ppu)
-      for (int k = sz; k <= 64; k += ppu) c += hist[k];
-    cnt[sz] = c;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int run = 0;
-    for (int k = 64; k >= 1; --k) {
-      offs[k] = run;
-      run += cnt[k];
+  if (threadIdx.x < 64) {
+    const int kk = threadIdx.x + 1;
+    const int h = (int)queue[16 + kk];
+    if (h) {
+      if (kk >= ppu) atomicAdd(&cnt[ppu], h * (kk / ppu));
+      if (kk % ppu) atomicAdd(&cnt[kk % ppu], h);
     }
-    if (blockIdx.x == 0) {
-      queue[9] = (unsigned long long)(run < units_cap ? run : units_cap);
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {  // offs[s] = units of more than s pixels (descending order of size)
+    const int sz = 64 - threadIdx.x;  // lane 0 holds the largest size
+    const int c = cnt[sz];
+    int upto = c;
+    for (int off = 1; off < 64; off <<= 1) {
+      const int v = __shfl_up(upto, off, 64);
+      if ((int)threadIdx.x >= off) upto += v;
+    }
+    offs[sz] = upto - c;
+    if (threadIdx.x == 63 && blockIdx.x == 0) {
+      queue[9] = (unsigned long long)(upto < units_cap ? upto : units_cap);
       queue[10] = (unsigned long long)ppu;
     }
   }
   __syncthreads();
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  const int k = i < n ? keys[i] : 0;
-  if (!k) return;
-  const unsigned long long m = masks[i];  // carried in the unit: one dependent load less when a wave fetches it
-  const int mlo = (int)(unsigned)m, mhi = (int)(unsigned)(m >> 32);
   const int full = k / ppu, rem = k - full * ppu;
+  // the units of ppu pixels (most of them): one returning atomic per wave, the lanes share out what it reserved
+  const int lane = threadIdx.x & 63;
+  int upto = full;  // inclusive prefix sum over the wave
+  for (int off = 1; off < 64; off <<= 1) {
+    const int v = __shfl_up(upto, off, 64);
+    if (lane >= off) upto += v;
+  }
+  const int wave_total = __shfl(upto, 63, 64);
+  int base = 0;
+  if (wave_total) {
+    if (lane == 63) base = (int)atomicAdd(queue + 96 + ppu, (unsigned long long)wave_total);
+    base = __shfl(base, 63, 64);
+  }
+  if (!k) return;
+  const int mlo = (int)(unsigned)m, mhi = (int)(unsigned)(m >> 32);
   if (full) {
-    const int at = offs[ppu] + (int)atomicAdd(queue + 96 + ppu, (unsigned long long)full);
+    const int at = offs[ppu] + base + upto - full;
     for (int g = 0; g < full; ++g)
       if (at + g < units_cap) units[at + g] = make_int4(i, (g * ppu) | (ppu << 8), mlo, mhi);  // (region, first | count << 8, mask)
   }
@@ -2347,7 +2365,7 @@ PT_DEV long long next_pixel(const PtKArgs &a, bool need, long long npix) {
     const int leader = __ffsll((long long)mask) - 1;
     const int rank = __popcll(mask & ((1ULL << lane) - 1ULL));
     unsigned long long base = 0;
-    if (lane == leader) base = atomicAdd(cold_args(a)->queue, (unsigned long long)__popcll(mask));
+    if (lane == leader) base = atomicAdd(pt_queue(a), (unsigned long long)__popcll(mask));
     base = __shfl(base, leader, 64);
     const long long p = (long long)(base + rank);
     pix = p < npix ? p : -1;
@@ -2418,6 +2436,10 @@ PT_DEV void path_trace(const PtKArgs &a) {
     D = c->D;
     rr = c->rr;
   }
+  if (blockIdx.x == gridDim.x - 1) {  // the next frame's queue block (nothing of this frame reads it)
+    unsigned long long *qn = pt_queue_next(a);
+    for (int k = threadIdx.x; k < PT_QUEUE_WORDS; k += PT_BLOCK) qn[k] = 0ULL;
+  }
   if (LAT && diag_lds >= 0) {
     // scale+translate records into LDS: world_query_lanes fetches them by lane-private index
     const unsigned long long *src = (const unsigned long long *)a.diag;
@@ -2453,7 +2475,7 @@ PT_DEV void path_trace(const PtKArgs &a) {
   bool exhausted = false;           // !TILED: the global queue is empty
   bool first_unit = true;           // TILED (wave-uniform)
   // TILED: units of the frame (written by pt_unit_scatter before this kernel started; read once -- not from the heads' lines)
-  const int n_units = TILED ? (int)cold_args(a)->queue[9] : 0;
+  const int n_units = TILED ? (int)pt_queue(a)[9] : 0;
   unsigned long long nrays = 0;
 
   // lane state.  mode 0: starts a sample at the next P-step; 1: inside a path (S-steps); 2: nothing to do;
@@ -2792,7 +2814,7 @@ PT_DEV void path_trace(const PtKArgs &a) {
             PT_VM_DRAIN();
             const unsigned long long lt0 = __builtin_amdgcn_s_memtime();
 #endif
-            if (lane == 0) uid = pullers + (unsigned)atomicAdd(cold_args(a)->queue + PT_QUEUE_HEADS + 32 * shard, 1ULL);
+            if (lane == 0) uid = pullers + (unsigned)atomicAdd(pt_queue(a) + PT_QUEUE_HEADS + 32 * shard, 1ULL);
 #ifdef PT_DEBUG_TIME
             asm volatile("s_waitcnt vmcnt(0)" : : "v"(uid) : "memory");
             lat_note(2, __builtin_amdgcn_s_memtime() - lt0);
@@ -3032,7 +3054,7 @@ PT_DEV void path_trace(const PtKArgs &a) {
   }
 #ifdef PT_DEBUG_TIME
   if ((threadIdx.x & 63) == 0)
-    for (int q = 0; q < 8; ++q) atomicAdd(cold_args(a)->queue + 1 + q, tsum[q]);
+    for (int q = 0; q < 8; ++q) atomicAdd(pt_queue(a) + 1 + q, tsum[q]);
   pt_dbg_flush();
 #endif
   add_ray_count(a, nrays);

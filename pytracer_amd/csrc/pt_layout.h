@@ -111,7 +111,8 @@ struct PtKArgs {
   void *out;                       // this rank's rows, compact
   double *ws;                      // path-tracer frame stack: [slot][field][thread]
   unsigned long long *ray_counter; // per-workgroup partial counts; may be null
-  unsigned long long *queue;       // path tracer: next unassigned pixel (zeroed per launch)
+  unsigned long long *queue;       // path tracer: the two queue blocks (pt_kernels.h: pt_queue)
+  int qpar;                        // ... and which of them this frame uses (by value; the device copy of the block holds 0)
   const int4 *units;               // path tracer, second pass: (region, first flagged pixel | pixels << 8, region mask) per work unit
   int dome_slot;                   // path tracer, first pass: the sphere the camera is deepest inside (uniform pigments), or -1
   int dome_shortcut;               // 0: every tile goes through rays (pt_set_dome_shortcut; a measurement switch)

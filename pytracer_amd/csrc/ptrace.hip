@@ -68,7 +68,13 @@ struct pt_scene {
   unsigned long long *ray_counter = nullptr;   // totals: all rays, rays resolved by the dome shortcut
   unsigned long long *ray_partials = nullptr;  // the same two per workgroup
   int ray_partials_n = 0;
-  unsigned long long *queue = nullptr;  // path-tracer pixel queue head
+  // path tracer: two queue blocks (pixel queue head / work units of the second pass, PT_QUEUE_WORDS each).  A frame
+  // uses one and its last kernel zeroes the other for the next frame: no memset (and no launch gap after it) in front
+  // of a frame.  queue_clean: the block the next frame will use is known to be zero.
+  unsigned long long *queue = nullptr;
+  unsigned long long *queue_last = nullptr;  // the block the most recent frame used (debug read-back)
+  int queue_parity = 0;
+  bool queue_clean = false;
   PtKArgs *args_dev = nullptr;          // device copy of the argument block (cold fields)
   unsigned char *region_keys = nullptr;  // path tracer region ordering
   struct DomeCand {
@@ -696,7 +702,7 @@ extern "C" int pt_scene_upload(const pt_scene_desc *d, int device, pt_scene **ou
     return code;
   };
   if ((rc = hip_or_free(hipMalloc((void **)&s->ray_counter, 2 * sizeof(unsigned long long)), "hipMalloc(counter)"))) return rc;
-  if ((rc = hip_or_free(hipMalloc((void **)&s->queue, PT_QUEUE_WORDS * sizeof(unsigned long long)), "hipMalloc(queue)"))) return rc;
+  if ((rc = hip_or_free(hipMalloc((void **)&s->queue, 2 * PT_QUEUE_WORDS * sizeof(unsigned long long)), "hipMalloc(queue)"))) return rc;
   if ((rc = hip_or_free(hipMalloc((void **)&s->args_dev, sizeof(PtKArgs)), "hipMalloc(args)"))) return rc;
   if ((rc = hip_or_free(hipHostMalloc((void **)&s->ray_counter_host, 2 * sizeof(unsigned long long)), "hipHostMalloc"))) return rc;
   s->ray_counter_host[0] = s->ray_counter_host[1] = 0;
@@ -988,8 +994,12 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
     return PT_OK;
   }
   if (p->renderer == PT_RENDERER_PATHTRACER) {
-    // the queue block (head, unit counts, F; pt_kernels.h: pt_unit_scatter) starts every frame zeroed
-    HIP_TRY(hipMemsetAsync(s->queue, 0, PT_QUEUE_WORDS * sizeof(unsigned long long), st));
+    // the queue block (head, unit counts, F; pt_kernels.h: pt_unit_scatter) starts every frame zeroed: by the path
+    // kernel of the frame before (it clears the OTHER block), by a memset after anything went wrong in between
+    a.qpar = s->queue_parity;
+    s->queue_last = s->queue + (size_t)a.qpar * PT_QUEUE_WORDS;
+    if (!s->queue_clean) HIP_TRY(hipMemsetAsync(s->queue_last, 0, PT_QUEUE_WORDS * sizeof(unsigned long long), st));
+    s->queue_clean = false;  // (true again once this frame's path kernel is enqueued)
     // step batching (path_trace): the second pass by regions never mixes the two kinds of step (a P step
     // waits until no lane holds a ray: its lanes then move sample by sample); the one-queue kernel, which
     // also carries the cheap background pixels, starts samples while fewer than 48 lanes hold a ray and
@@ -1096,6 +1106,7 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
   a.cold = s->args_dev;
   PtKArgs cold = a;
   cold.out = nullptr;
+  cold.qpar = 0;
   if (!(s->args_valid && s->args_stream == st && memcmp(&s->args_last, &cold, sizeof cold) == 0)) {
     // pageable source: the runtime stages the bytes before returning, so `cold` may go out of scope
     HIP_TRY(hipMemcpyAsync(s->args_dev, &cold, sizeof cold, hipMemcpyHostToDevice, st));
@@ -1110,7 +1121,11 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
   bool ev_started = false;
   if (tile || path_tiled) {
 #ifdef PT_DEBUG_TIME
-    HIP_TRY(hipMemsetAsync(s->queue, 0, 16 * sizeof(unsigned long long), st));
+    if (p->renderer != PT_RENDERER_PATHTRACER) {
+      s->queue_last = s->queue;  // (a.qpar = 0)
+      HIP_TRY(hipMemsetAsync(s->queue, 0, 16 * sizeof(unsigned long long), st));
+      if (s->queue_parity == 0) s->queue_clean = false;  // the section sums land in block 0
+    }
 #endif
     const size_t lds = (size_t)4 * a.npass * sizeof(unsigned long long);
     s->stats.lds_bytes = (int)lds;
@@ -1155,7 +1170,7 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
       static const int env_minr = getenv("PTRACE_UNIT_MIN_ROUNDS") ? atoi(getenv("PTRACE_UNIT_MIN_ROUNDS")) : 0;
       const int min_rounds = env_minr != 0 ? env_minr : (a.pcg_mode == PT_PCG_SAMPLE ? -2 : 16);  // (< 0: see unit_ppu)
       hipLaunchKernelGGL(pt_unit_scatter, dim3((nregions + 1023) / 1024), dim3(1024), 0, st, s->region_keys, s->region_mask, nregions, s->units, s->units_cap,
-                         s->queue, lanes_cap, nsamp, min_rounds);
+                         s->queue_last, lanes_cap, nsamp, min_rounds);
       if (lds_frames && a.scene_lds >= 0) {
         HIP_TRY(path_lds_limit((const void *)pt_path_regions_kernel<true, true>, lds + frame_lds + diag_lds_bytes));
         PT_LAUNCH((pt_path_regions_kernel<true, true>), grid, lds + frame_lds + diag_lds_bytes, true, a);
@@ -1197,6 +1212,10 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
       break;
   }
   HIP_TRY(hipGetLastError());
+  if (p->renderer == PT_RENDERER_PATHTRACER) {  // its path kernel is enqueued: the other queue block will be zero
+    s->queue_parity ^= 1;
+    s->queue_clean = true;
+  }
   if (main_fn) {
     // registers per lane of that kernel (hipFuncGetAttributes; looked up once per kernel)
     static std::vector<std::pair<const void *, int>> known;
@@ -1510,7 +1529,7 @@ extern "C" int pt_debug_read_queue(pt_scene *s, unsigned long long *out16) {
   if (!s || !out16) return fail(PT_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(s->device));
   HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpy(out16, s->queue, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(out16, s->queue_last ? s->queue_last : s->queue, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   return PT_OK;
 }
 
