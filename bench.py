@@ -441,25 +441,29 @@ def run_multi(args, rank, local_rank, world_size, dist):
             "ms_per_step": None, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": "C4 path tracer 3840x2160, 256 spheres, N=1, D=5, rr=3, S=8 (64 spp), fp32 RGB assembled on rank 0",
-                       "width": W, "height": H, "n_shapes": flat.n_shapes, "renderer": "PathTracer", "pcg_mode": "PT_PCG_PIXEL",
+                       "width": W, "height": H, "n_shapes": flat.n_shapes, "renderer": "PathTracer",
+                       "pcg_mode": "PT_PCG_SAMPLE (one generator per sample = per lane of the second pass: 'PCG random state per-thread' of the north star; the same frame with one generator per PIXEL is the row pcg_pixel)",
                        "partition": f"interleaved 8-row blocks over {world_size} ranks, one batched RCCL send/recv group per frame "
                                     "into row-block order on rank 0, double-buffered behind the next frame's render"},
         }
-        if err is None and (abi.PCG_PIXEL, True) in rows:
-            head = line(abi.PCG_PIXEL, True)
+        HEAD, SIDE = abi.PCG_SAMPLE, abi.PCG_PIXEL
+        if err is None and (HEAD, True) in rows:
+            head = line(HEAD, True)
             result["value"], result["ms_per_step"] = head["value"], head["ms_per_step"]
             result["avg_render_kernels_ms_max_over_ranks"] = head["avg_render_kernels_ms_max_over_ranks"]
-            result["gather_check"] = rows.get((abi.PCG_PIXEL, "check"))
-            result["without_gather"] = line(abi.PCG_PIXEL, False)
-            result["one_gpu_same_frame_kernel_ms"] = rows.get((abi.PCG_PIXEL, "one_gpu_kernel_ms"))
-            result["rays_per_frame"] = rays_frame[abi.PCG_PIXEL]
-            if (abi.PCG_SAMPLE, True) in rows:
-                result["pcg_sample"] = dict(line(abi.PCG_SAMPLE, True), without_gather=line(abi.PCG_SAMPLE, False),
-                                            gather_check=rows.get((abi.PCG_SAMPLE, "check")),
-                                            one_gpu_same_frame_kernel_ms=rows.get((abi.PCG_SAMPLE, "one_gpu_kernel_ms")),
-                                            rays_per_frame=rays_frame[abi.PCG_SAMPLE],
-                                            note="the same frame with one generator per SAMPLE (SURVEY.md 8c Mode SAMPLE): a pixel's "
-                                                 "64 samples are independent, so a rank's share keeps all its lanes busy")
+            result["gather_check"] = rows.get((HEAD, "check"))
+            result["without_gather"] = line(HEAD, False)
+            result["one_gpu_same_frame_kernel_ms"] = rows.get((HEAD, "one_gpu_kernel_ms"))
+            result["rays_per_frame"] = rays_frame[HEAD]
+            if (SIDE, True) in rows:
+                result["pcg_pixel"] = dict(line(SIDE, True), without_gather=line(SIDE, False),
+                                           gather_check=rows.get((SIDE, "check")),
+                                           one_gpu_same_frame_kernel_ms=rows.get((SIDE, "one_gpu_kernel_ms")),
+                                           rays_per_frame=rays_frame[SIDE],
+                                           note="the same frame with one generator per PIXEL (SURVEY.md 8c Mode PIXEL): a pixel's 64 "
+                                                "samples consume ONE stream in order, so the lanes of a pixel speculate on where each "
+                                                "sample starts (DESIGN.md 4 item 10) and a rank's share of the frame is bounded by its "
+                                                "slowest pixel's rounds, not by its share of the work")
             result["gather_bytes_per_frame"] = W * H * 3 * 4 * (world_size - 1) // world_size
         else:
             result["error"] = err or "incomplete"

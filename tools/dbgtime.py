@@ -7,9 +7,10 @@ import ctypes as C
 from pytracer_amd import _lib
 W, H = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1280, 720)
 nsph = int(sys.argv[3]) if len(sys.argv) > 3 else 32
-flat = flatten.flatten_world(scenes.synthetic_world(nsph, wide=nsph > 64))
+flat = flatten.flatten_world(scenes.synthetic_world(nsph, wide=nsph > 64, with_plane=bool(int(os.environ.get('DBG_PLANE', 0)))))
 cam = flatten.flatten_camera(scenes.synthetic_camera(W, H))
-par = abi.make_params(W, H, abi.RENDERER_PATHTRACER, samples_per_side=int(os.environ.get('DBG_S', 4)), num_of_rays=int(os.environ.get('DBG_N', 1)), max_depth=int(os.environ.get('DBG_D', 3)), rr_limit=3, path_state=45, path_seq=54,
+REND = {'path': abi.RENDERER_PATHTRACER, 'flat': abi.RENDERER_FLAT, 'onoff': abi.RENDERER_ONOFF}[os.environ.get('DBG_RENDERER', 'path')]
+par = abi.make_params(W, H, REND, samples_per_side=int(os.environ.get('DBG_S', 4)), num_of_rays=int(os.environ.get('DBG_N', 1)), max_depth=int(os.environ.get('DBG_D', 3)), rr_limit=3, path_state=45, path_seq=54,
                       pcg_mode=int(os.environ.get('DBG_MODE', 1)), n_ranks=int(os.environ.get('DBG_RANKS', 1)), rank=int(os.environ.get('DBG_RANK', 0)), row_block=8)
 ds = DeviceScene(flat)
 for _ in range(1):
@@ -18,6 +19,8 @@ q = (C.c_ulonglong * 16)()
 _lib.lib().pt_debug_read_queue(ds._h, q)
 t = np.array([q[i] for i in range(1, 9)], dtype=np.float64)
 names = ["0 unit setup", "1 start_sample", "2 tile query (P)", "3 round commit", "4 full query (S)", "5 shade+unwind+scatter", "6 unit fetch (atomic)", "7 loop top"]
+if REND != abi.RENDERER_PATHTRACER:
+    names = ["0 tile setup", "1 tile cone", "2 cull", "3 dome check + ray generation", "4 tile query", "5 shade + store", "6 after the pixel loop", "7 strip / loop top"]
 print("kernel ms", ds.stats().kernel_ms, "rays", ds.stats().n_rays)
 for n, v in zip(names, t):
     print(f"{n:22s} {v:12.0f} cycles")
