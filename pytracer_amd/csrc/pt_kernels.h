@@ -1758,16 +1758,30 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
   // do not hold for a tile whose directions are bounded by dmax2 / dmin; else `cum` is the pixel (the S*S
   // additions and the final scaling of imagetracer.py:83-101 replayed) and `settled` says whether it is final
   // (PointLight needs the hit point; a path tracer whose dome scatters light goes to the second pass).
-  auto dome_value = [&](int only, double hc_, float dmax2, float dmin, bool all, V3 &cum, bool &settled) -> bool {
+  // The shape-dependent half of that (records, pigments, the replayed sum) is the same for every tile that meets
+  // the same sphere -- in practice ONE sky dome per frame: it is worked out once per wave and kept (dc_*), so that
+  // a dome tile or strip costs no dependent loads, only the few comparisons below.
+  // (Path tracer's first pass only: there strips and dome tiles are nearly all of the work and the kernel runs at
+  //  four waves per SIMD anyway; OnOff / Flat would pay for the ~25 registers with their fifth wave: C2 +8 %.)
+  constexpr bool KEEP = RENDERER == PT_RENDERER_PATHTRACER;
+  int dc_slot = -1;
+  bool dc_usable = false, dc_settled = false;
+  float dc_fro2 = 0.0f;
+  double dc_hc = 0.0;  // perspective camera: the hoisted c = |o'|^2 - 1 of the sphere
+  V3 dc_cum = {0.0, 0.0, 0.0};
+  auto dome_prepare = [&](int only) {  // (`only` wave-uniform)
+    if (KEEP && only == dc_slot) return;
+    dc_slot = only;
     pt_kargs ca = cold_args(a);
     const PtShapeAux *ax = ca->aux + only;
-    const float fro2 = (float)PT_KD(&a.recs[only])[13];  // PtShapeRec::fro2
-    settled = false;
-    cum = {0.0, 0.0, 0.0};
-    if (RENDERER == PT_RENDERER_POINTLIGHT) return false;
-    if (!(hc_ < -0.5 && fro2 * dmax2 < 1e6f && dmin > 1e-6f && !all && ax->needs_uv == 0)) return false;
+    dc_fro2 = (float)PT_KD(&a.recs[only])[13];  // PtShapeRec::fro2
+    dc_hc = ORTHO ? 0.0 : ((only < a.n_diag) ? PT_KD(&a.hoist_diag[only])[6] : PT_KD(&a.hoist[only])[3]);
+    dc_settled = false;
+    dc_cum = {0.0, 0.0, 0.0};
+    dc_usable = RENDERER != PT_RENDERER_POINTLIGHT && ax->needs_uv == 0;
+    if (!dc_usable) return;
     V3 c;
-    settled = true;
+    dc_settled = true;
     if (RENDERER == PT_RENDERER_ONOFF) {
       c.x = ca->onoff[0];
       c.y = ca->onoff[1];
@@ -1780,27 +1794,35 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
     } else {
       const V3 hc = brdf_pigment(a, ax, 0.0, 0.0), em = emitted_pigment(a, ax, 0.0, 0.0);
       const double lum = max2(max2(hc.x, hc.y), hc.z);
-      settled = !(ca->rr <= 0 || lum > 0.0);  // else every pixel goes to the second pass
+      dc_settled = !(ca->rr <= 0 || lum > 0.0);  // else every pixel goes to the second pass
       const double invN = 1.0 / (double)ca->N;
       c.x = em.x + 0.0 * invN;
       c.y = em.y + 0.0 * invN;
       c.z = em.z + 0.0 * invN;
     }
-    cum = c;
+    dc_cum = c;
     if (S > 0) {  // imagetracer.py:83-101: the same additions, the same final scaling
-      cum.x = 0.0;
-      cum.y = 0.0;
-      cum.z = 0.0;
+      V3 sum = {0.0, 0.0, 0.0};
       for (int s = 0; s < nsamp; ++s) {
-        cum.x = cum.x + c.x;
-        cum.y = cum.y + c.y;
-        cum.z = cum.z + c.z;
+        sum.x = sum.x + c.x;
+        sum.y = sum.y + c.y;
+        sum.z = sum.z + c.z;
       }
       const double k = 1.0 / (double)(S * S);
-      cum.x = cum.x * k;
-      cum.y = cum.y * k;
-      cum.z = cum.z * k;
+      dc_cum.x = sum.x * k;
+      dc_cum.y = sum.y * k;
+      dc_cum.z = sum.z * k;
     }
+  };
+  // (hc_: the caller's |o'|^2 - 1 for an orthogonal camera, where it depends on the tile; else dc_hc is used)
+  auto dome_value = [&](int only, double hc_, float dmax2, float dmin, bool all, V3 &cum, bool &settled) -> bool {
+    dome_prepare(only);
+    settled = false;
+    cum = {0.0, 0.0, 0.0};
+    if (!ORTHO) hc_ = dc_hc;
+    if (!dc_usable || !(hc_ < -0.5 && dc_fro2 * dmax2 < 1e6f && dmin > 1e-6f && !all)) return false;
+    settled = dc_settled;
+    cum = dc_cum;
     return true;
   };
   // A workgroup takes a STRIP of four tiles (32 x 8 pixels, one block of rows), one tile per wave.  Where the
@@ -1815,6 +1837,12 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
   const bool use_strips = dome_on && !ORTHO && !HIER && RENDERER != PT_RENDERER_POINTLIGHT && npass >= 2;
   __shared__ int strip_ns[2][PT_BLOCK / 64], strip_only[2][PT_BLOCK / 64];
   int parity = 0;
+  // the bounding spheres a wave looks at first are the same for every tile and strip it takes: loaded once
+  float4 b_kept = {0.0f, 0.0f, 0.0f, -1.0f}, sb_kept = {0.0f, 0.0f, 0.0f, -1.0f};
+  if (KEEP) {
+    b_kept = a.bounds[(!HIER && lane < a.n_shapes) ? lane : 0];
+    if (use_strips && wib * 64 + lane < a.n_shapes) sb_kept = a.bounds[wib * 64 + lane];
+  }
   for (int strip = blockIdx.x; strip < nstrips; strip += gridDim.x) {
    const int ty = strip / strips_x, tx_first = (strip - ty * strips_x) * 4;
    const int tx_end = tx_first + 4 < tiles_x ? tx_first + 4 : tiles_x;
@@ -1829,7 +1857,7 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
        const int slot = p * 64 + lane;
        bool keep = false;
        float4 b = {0.0f, 0.0f, 0.0f, -1.0f};
-       if (slot < a.n_shapes) b = a.bounds[slot];
+       if (slot < a.n_shapes) b = (KEEP && p == wib) ? sb_kept : a.bounds[slot];
        const bool isplane = slot >= a.n_spheres && slot < a.n_shapes;
        if (slot < a.n_spheres) keep = cone_keeps(sc, b);
        if (__any(isplane)) {
@@ -1853,10 +1881,8 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
        if (nw) only_all = strip_only[parity][w];
      }
      parity ^= 1;
-     if (tot == 1 && only_all < a.n_spheres) {
-       const double hc_ = (only_all < a.n_diag) ? PT_KD(&a.hoist_diag[only_all])[6] : PT_KD(&a.hoist[only_all])[3];
-       strip_dome = dome_value(only_all, hc_, sc.dmax2, sc.dmin, sc.all, strip_cum, strip_settled);
-     }
+     if (tot == 1 && only_all < a.n_spheres)
+       strip_dome = dome_value(__builtin_amdgcn_readfirstlane(only_all), 0.0, sc.dmax2, sc.dmin, sc.all, strip_cum, strip_settled);
    }
    {
     const int tx = tx_first + wib;
@@ -1892,8 +1918,8 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
     // tile rectangle: columns [tx*8, ..), global rows of its first/last local row
     const int gr0 = global_row(a, ty * 8);
     const int gr1 = global_row(a, (ty * 8 + 7 < rows_local) ? ty * 8 + 7 : rows_local - 1);
-    // the first pass's bounding sphere is requested before the cone arithmetic so that the two overlap
-    const float4 b_first = a.bounds[(!HIER && lane < a.n_shapes) ? lane : 0];
+    // (else: the first pass's bounding sphere is requested before the cone arithmetic so that the two overlap)
+    const float4 b_first = KEEP ? b_kept : a.bounds[(!HIER && lane < a.n_shapes) ? lane : 0];
     const TileCone tc = tile_cone(a, tx * 8, (tx * 8 + 8 < W) ? tx * 8 + 8 : W, gr0, gr1);
     PT_TSTAMP(1);
     int tpass = npass;
@@ -1985,7 +2011,7 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
         dmax2 = d2 * (1.0f + 1e-5f);
         dmin = __fsqrt_rn(d2) * (1.0f - 1e-5f);
       } else {
-        hc_ = (only < a.n_diag) ? PT_KD(&a.hoist_diag[only])[6] : PT_KD(&a.hoist[only])[3];
+        hc_ = 0.0;  // (dome_value takes the hoisted constant of `only` itself)
       }
       V3 cum;
       bool settled;
@@ -2019,12 +2045,9 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
     // survived in is always left over.)
     if (RENDERER == PT_RENDERER_PATHTRACER && !ORTHO && dome_on && dome_here && nsurv > 1) {
       pt_kargs ca = cold_args(a);
-      const PtShapeAux *ax = ca->aux + dome_slot;
-      const float fro2 = (float)PT_KD(&a.recs[dome_slot])[13];  // PtShapeRec::fro2
-      const double hc_ = (dome_slot < a.n_diag) ? PT_KD(&a.hoist_diag[dome_slot])[6] : PT_KD(&a.hoist[dome_slot])[3];
-      const V3 hc = brdf_pigment(a, ax, 0.0, 0.0), em = emitted_pigment(a, ax, 0.0, 0.0);
-      const double lum = max2(max2(hc.x, hc.y), hc.z);
-      if (hc_ < -0.5 && fro2 * tc.dmax2 < 1e6f && tc.dmin > 1e-6f && !tc.all && ax->needs_uv == 0 && ca->rr > 0 && !(lum > 0.0)) {
+      dome_prepare(dome_slot);
+      // (dc_settled for the path tracer: Russian roulette on and a black BRDF pigment -- the sample ends on the dome)
+      if (dc_usable && dc_settled && dc_hc < -0.5 && dc_fro2 * tc.dmax2 < 1e6f && tc.dmin > 1e-6f && !tc.all) {
         const TileCone pc = pixel_cone(cone_cam(a), tc, pcol, grow);
         bool hitable = pc.all;
         for (int p = 0; p < tpass; ++p) {
@@ -2047,26 +2070,7 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
             }
           }
         }
-        const double invN = 1.0 / (double)ca->N;
-        V3 c;  // render.py:139 with cum_radiance = 0
-        c.x = em.x + 0.0 * invN;
-        c.y = em.y + 0.0 * invN;
-        c.z = em.z + 0.0 * invN;
-        V3 cum = c;
-        if (S > 0) {  // imagetracer.py:83-101: the same additions, the same final scaling
-          cum.x = 0.0;
-          cum.y = 0.0;
-          cum.z = 0.0;
-          for (int s = 0; s < nsamp; ++s) {
-            cum.x = cum.x + c.x;
-            cum.y = cum.y + c.y;
-            cum.z = cum.z + c.z;
-          }
-          const double k = 1.0 / (double)(S * S);
-          cum.x = cum.x * k;
-          cum.y = cum.y * k;
-          cum.z = cum.z * k;
-        }
+        const V3 cum = dc_cum;  // render.py:139 with cum_radiance = 0, imagetracer.py:83-101 replayed
         if (active && !hitable) {
           store_pixel(a, pix, cum);
           nrays += (unsigned long long)nsamp;
