@@ -66,7 +66,9 @@ PT_DEV pt_kargs cold_args(const PtKArgs &a) {
 // The path tracer's queue block (layout: see pt_unit_scatter) exists twice; frame f uses block f & 1 (a.qpar, a
 // by-value argument so that the device copy of the argument block stays the same from frame to frame) and its
 // path kernel zeroes the other one for the next frame.
+#ifndef PT_QUEUE_WORDS
 #define PT_QUEUE_WORDS 512
+#endif
 #define PT_QUEUE_HEADS 256
 #ifndef PT_UNIT_SHARDS
 #define PT_UNIT_SHARDS 8
