@@ -927,3 +927,40 @@ def test_pinned_and_pageable_host_outputs_agree(dev):
             c = ds.render(cam, par)  # the pool hands the same page-locked buffer out again
             assert np.array_equal(c, keep)
 
+
+
+def test_queue_blocks_alternate_cleanly(dev):
+    """The path tracer's queue block exists twice; a frame's path kernel zeroes the block of the NEXT frame (no
+    memset per frame).  Path-traced frames of different sizes and modes, Flat frames, a refused call and an
+    orthogonal-camera path frame (the one-queue kernel) in any order must each equal the frame rendered by a fresh
+    scene, and an odd/even number of frames must not matter."""
+    from pytracer_amd import flatten, hostmodel as hm
+    from pytracer_amd._lib import PtraceError
+
+    scene, cam = _synthetic(32, False, False, 256, 144)
+    cam_small = _synthetic(32, False, False, 64, 40)[1]
+    cam_ortho = flatten.flatten_camera(hm.OrthogonalCamera(96 / 64, hm.translation(hm.Vec(-1.0, 0.0, 1.0)) * hm.scaling(hm.Vec(1.0, 4.0, 3.0))))
+    kw = dict(num_of_rays=1, max_depth=3, rr_limit=3, path_state=45, path_seq=54)
+    jobs = {
+        "pixel": (cam, abi.make_params(256, 144, abi.RENDERER_PATHTRACER, samples_per_side=4, **kw)),
+        "sample": (cam, abi.make_params(256, 144, abi.RENDERER_PATHTRACER, samples_per_side=4, pcg_mode=abi.PCG_SAMPLE, **kw)),
+        "small": (cam_small, abi.make_params(64, 40, abi.RENDERER_PATHTRACER, samples_per_side=2, **kw)),
+        "n2": (cam_small, abi.make_params(64, 40, abi.RENDERER_PATHTRACER, samples_per_side=1, num_of_rays=2, max_depth=2,
+                                          rr_limit=2, path_state=3, path_seq=5)),
+        "ortho": (cam_ortho, abi.make_params(96, 64, abi.RENDERER_PATHTRACER, samples_per_side=2, **kw)),
+        "flat": (cam, abi.make_params(256, 144, abi.RENDERER_FLAT)),
+    }
+    want = {}
+    for name, (c, p) in jobs.items():
+        with dev.DeviceScene(scene) as fresh:
+            want[name] = fresh.render(c, p).copy()
+    order = ["pixel", "sample", "flat", "small", "small", "ortho", "pixel", "n2", "flat", "sample", "ortho", "ortho", "small",
+             "pixel", "pixel", "sample"]
+    with dev.DeviceScene(scene) as ds:
+        for k, name in enumerate(order):
+            if k in (3, 9):  # a refused frame in between leaves the queue state alone
+                with pytest.raises(PtraceError):
+                    ds.render(cam, abi.make_params(256, 144, abi.RENDERER_PATHTRACER, num_of_rays=0))
+            c, p = jobs[name]
+            got = ds.render(c, p)
+            assert util.bits_equal(got, want[name]), (k, name)
