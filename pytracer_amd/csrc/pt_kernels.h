@@ -2249,6 +2249,7 @@ __global__ void pt_unit_scatter(const unsigned char *keys, const unsigned long l
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int k = i < n ? keys[i] : 0;
   const unsigned long long m = i < n ? masks[i] : 0ULL;  // carried in the unit: one dependent load less when a wave fetches it
+  const int h = threadIdx.x < 64 ? (int)queue[16 + threadIdx.x + 1] : 0;  // (requested together with F: one round trip)
   const int ppu = unit_ppu(queue, lanes_cap, nsamp, min_rounds);
   // regions with k flagged pixels (counted by the first pass) -> units of s pixels: a region yields k / ppu units
   // of ppu pixels and one of k % ppu.  The first wave does it, lane k - 1 for the regions of k pixels.
@@ -2256,7 +2257,6 @@ __global__ void pt_unit_scatter(const unsigned char *keys, const unsigned long l
   __syncthreads();
   if (threadIdx.x < 64) {
     const int kk = threadIdx.x + 1;
-    const int h = (int)queue[16 + kk];
     if (h) {
       if (kk >= ppu) atomicAdd(&cnt[ppu], h * (kk / ppu));
       if (kk % ppu) atomicAdd(&cnt[kk % ppu], h);
