@@ -404,7 +404,7 @@ __device__ unsigned long long pt_dbg[8];
 #ifdef PT_DEBUG_TIME
 // latency of single vector-memory operations, log2 buckets: [0] the load of a unit's descriptor, [1] what was still
 // outstanding before it, [2] the returning atomic on a shard's head, [3] the sparse path's load of one ball per lane
-__device__ unsigned long long pt_lat_hist[4][32];
+__device__ unsigned long long pt_lat_hist[5][32];  // ([4]: scattered-ray queries by the number of live rays, bins of 2)
 #define PT_VM_DRAIN() __builtin_amdgcn_s_waitcnt(0x0F70)  // vmcnt(0)
 // ... and the slow ones one by one: (100 MHz wall clock at the end, cycles, which | xcc << 8 | HW_ID << 16)
 #define PT_LAT_EVENTS 4096
@@ -485,6 +485,10 @@ PT_DEV int world_query_lanes(const PtKArgs &a, const Ray &r, double tmax, double
 
 #ifdef PT_DEBUG_TIME
   unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime(), dbg_pre = 0, dbg_walk = 0, dbg_it = 0;
+  {
+    const int np_ = __popcll(__ballot(active));
+    if (!ANYHIT && (threadIdx.x & 63) == 0) atomicAdd(&pt_lat_hist[4][np_ >= 62 ? 31 : np_ >> 1], 1ULL);
+  }
 #endif
   typedef float f8 __attribute__((ext_vector_type(8)));
   typedef const __attribute__((address_space(4))) f8 *pt_kf8;

@@ -1543,17 +1543,17 @@ extern "C" int pt_debug_read_dbg(unsigned long long *out8, int reset) {
   }
   return PT_OK;
 }
-extern "C" int pt_debug_read_lat_hist(unsigned long long *out128, int clear) {
+extern "C" int pt_debug_read_lat_hist(unsigned long long *out160, int clear) {
 #ifdef PT_DEBUG_TIME
   HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpyFromSymbol(out128, HIP_SYMBOL(pt_lat_hist), 128 * sizeof(unsigned long long)));
+  HIP_TRY(hipMemcpyFromSymbol(out160, HIP_SYMBOL(pt_lat_hist), 160 * sizeof(unsigned long long)));
   if (clear) {
-    static const unsigned long long zeros[128] = {0};
+    static const unsigned long long zeros[160] = {0};
     HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(pt_lat_hist), zeros, sizeof(zeros)));
   }
   return PT_OK;
 #else
-  (void)out128;
+  (void)out160;
   (void)clear;
   return PT_ERR_INVALID;
 #endif

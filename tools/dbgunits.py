@@ -51,12 +51,13 @@ for name in sys.argv[1:]:
         print(f"   duration quartile {lo}-{hi}: rounds {rounds[sel].mean():.1f} iterations {iters[sel].mean():.1f} count {count[sel].mean():.1f} per-iteration {(dur[sel] / np.maximum(1, iters[sel])).mean():.1f} kcyc"
               f" | kcyc in: scattered queries {a[sel, 4].mean() / 1e3:.0f}, shade {a[sel, 5].mean() / 1e3:.0f}, start+primary {a[sel, 6].mean() / 1e3:.0f}, commit+fetch {a[sel, 7].mean() / 1e3:.0f}")
     if os.environ.get("DBG_LAT"):  # latency histograms of single vector-memory operations (cycles, log2 buckets)
-        hb = (C.c_ulonglong * 128)()
+        hb = (C.c_ulonglong * 160)()
         _lib.lib().pt_debug_read_lat_hist(hb, 1)
-        h = np.array(list(hb), dtype=np.int64).reshape(4, 32)
+        h = np.array(list(hb), dtype=np.int64).reshape(5, 32)
         for k, what in enumerate(("load of a unit descriptor", "  outstanding before it", "atomic on a shard head", "sparse path: one ball per lane")):
             tot = max(1, h[k].sum())
             print(f"   {what:32s} n={h[k].sum():6d} " + " ".join(f"2^{b}:{h[k, b]}" for b in range(32) if h[k, b]))
+        print(f"   scattered-ray queries by live rays (bins of 2, the last: 62-64): {h[4].tolist()}; <= 16: {h[4, :9].sum()}, 17-32: {h[4, 9:17].sum()}, > 32: {h[4, 17:].sum()}")
     if os.environ.get("DBG_LAT"):  # the slow operations one by one: do they cluster in time (per XCD, per CU)?
         ne = 4096
         eb = (C.c_ulonglong * (ne * 3 + 1))()
