@@ -178,6 +178,18 @@ def extra_rows(device: int):
             rows[tag]["second_pass_executed"] = {
                 "kernel": "pt_path_regions_kernel", "valu_wave_instructions_per_launch": valu, "kernel_us_under_pmc_collection": pmc["dur_us"],
                 "valu_issue_utilisation": valu * VALU_CYCLES_PER_WAVE_INSTR / (n_cu * 4 * dur * clock_khz * 1e3), "source": pmc.get("source")}
+    # C5: HBM bytes per frame of its two kernels (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 passes, medians
+    # committed under profiles/) over the kernel time measured here
+    c5 = rows.get("C5_flat_1280x720_10k_spheres")
+    tile, cell = load_profile("pmc_c5_tile.json"), load_profile("pmc_c5_cell.json")
+    if c5 is not None and tile is not None and cell is not None and "hbm_bytes_per_launch" in tile and "hbm_bytes_per_launch" in cell:
+        nbytes = tile["hbm_bytes_per_launch"] + cell["hbm_bytes_per_launch"]
+        gbs = nbytes / (c5["ms_per_frame"] * 1e-3) / 1e9
+        c5["hbm"] = {"bytes_per_frame": nbytes, "achieved_GB_s": gbs, "peak_GB_s": PEAK_HBM_GBS, "frac": gbs / PEAK_HBM_GBS,
+                     "algorithmic_bytes_per_frame": 1280 * 720 * 12 + 10000 * (128 + 256 + 16),
+                     "note": "pt_cell_kernel + pt_tile_kernel<FLAT, HIER>: pixels written once, the 10 000 shapes' bounds read per "
+                             "32x32-pixel cell group, survivor lists written and re-read -- far from the HBM roof: the frame is "
+                             "bound by the culling arithmetic", "source": tile.get("source")}
     return rows
 
 
