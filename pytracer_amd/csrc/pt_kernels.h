@@ -1930,6 +1930,7 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
     PT_TSTAMP(1);
     int tpass = npass;
     const unsigned int *list = nullptr;
+    int list_cnt = 0;         // HIER: entries of the cell's list
     int nsurv = 0, only = 0;  // survivors of this tile; the slot of the last one (wave-uniform)
     bool dome_here = false;   // PATHTRACER: the frame's dome candidate (a.dome_slot) is among them
     if (HIER) {
@@ -1937,6 +1938,7 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
       // row_block % 8 == 0), so they lie in one cell row
       const int cell = __builtin_amdgcn_readfirstlane((gr0 / PT_CELL) * a.cells_x + (tx * 8) / PT_CELL);
       const int cnt = PT_KI(a.cell_count)[cell];
+      list_cnt = cnt;
       list = a.cell_list + (size_t)cell * a.cell_stride;
       tpass = (cnt + 63) >> 6;
       for (int p = 0; p < tpass; ++p) {
@@ -2061,17 +2063,26 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
           const unsigned m_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(mv >> 32));
           const unsigned m_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)mv);
           unsigned long long mask = ((unsigned long long)m_hi << 32) | (unsigned long long)m_lo;
+          if (!mask) continue;
+          // this pass's 64 bounding spheres, one per lane (one coalesced load), handed out by v_readlane: a
+          // dependent scalar load per survivor would cost its latency per survivor -- dozens per tile where the
+          // spheres crowd
+          const int myi = p * 64 + lane;
+          int slot_q = myi;
+          if (HIER) slot_q = myi < list_cnt ? (int)list[myi] : 0;
+          const float4 bq = a.bounds[slot_q < a.n_shapes ? slot_q : 0];
           while (mask) {
-            const int idx = p * 64 + (__ffsll((long long)mask) - 1);
+            const int bit = __ffsll((long long)mask) - 1;
             mask &= mask - 1;
-            const int slot = HIER ? PT_KI(list)[idx] : idx;
+            const int slot = __builtin_amdgcn_readlane(slot_q, bit);
             if (slot == dome_slot) continue;
             if (slot >= a.n_spheres) {
               hitable = true;
             } else {
-              typedef const __attribute__((address_space(4))) float *pt_kfloat;
-              pt_kfloat bp = (pt_kfloat)(const void *)(a.bounds + slot);  // (wave-uniform slot: scalar loads)
-              const float4 b = {bp[0], bp[1], bp[2], bp[3]};
+              const float4 b = {__int_as_float(__builtin_amdgcn_readlane(__float_as_int(bq.x), bit)),
+                                __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bq.y), bit)),
+                                __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bq.z), bit)),
+                                __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bq.w), bit))};
               hitable = hitable || cone_keeps(pc, b);
             }
           }
