@@ -1733,7 +1733,8 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_cell_kernel(const PtKArgs a, int 
 //
 // ORTHO: orthogonal camera -- the tile's rays fill a beam instead of a cone (tile_cone), nothing is
 // hoisted (HOISTED = false queries), no dome shortcut.
-template <int RENDERER, int WAVES, bool HIER, bool ORTHO = false>
+// BLOCKS (path tracer's first pass on big frames; chosen by the host): four strips at a time, see below.
+template <int RENDERER, int WAVES, bool HIER, bool ORTHO = false, bool BLOCKS = false>
 __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) void pt_tile_kernel(const PtKArgs a, int count_base) {
   int S, W, rows_local, npass, dome_slot;
   bool dome_on;
@@ -1849,47 +1850,66 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
     b_kept = a.bounds[(!HIER && lane < a.n_shapes) ? lane : 0];
     if (use_strips && wib * 64 + lane < a.n_shapes) sb_kept = a.bounds[wib * 64 + lane];
   }
-  for (int strip = blockIdx.x; strip < nstrips; strip += gridDim.x) {
-   const int ty = strip / strips_x, tx_first = (strip - ty * strips_x) * 4;
-   const int tx_end = tx_first + 4 < tiles_x ? tx_first + 4 : tiles_x;
-   bool strip_dome = false, strip_settled = false;
-   V3 strip_cum = {0.0, 0.0, 0.0};
-   if (use_strips) {
-     const int sgr0 = global_row(a, ty * 8);
-     const int sgr1 = global_row(a, (ty * 8 + 7 < rows_local) ? ty * 8 + 7 : rows_local - 1);
-     const TileCone sc = tile_cone(a, tx_first * 8, (tx_end * 8 < W) ? tx_end * 8 : W, sgr0, sgr1);
-     int ns_ = 0, only_ = 0;
-     for (int p = wib; p < npass && ns_ <= 1; p += PT_BLOCK / 64) {
-       const int slot = p * 64 + lane;
-       bool keep = false;
-       float4 b = {0.0f, 0.0f, 0.0f, -1.0f};
-       if (slot < a.n_shapes) b = (KEEP && p == wib) ? sb_kept : a.bounds[slot];
-       const bool isplane = slot >= a.n_spheres && slot < a.n_shapes;
-       if (slot < a.n_spheres) keep = cone_keeps(sc, b);
-       if (__any(isplane)) {
-         const bool pk = plane_keeps(sc, b, isplane);
-         if (isplane) keep = pk;
-       }
-       const unsigned long long m = __ballot(keep);
-       ns_ += __popcll(m);
-       if (m) only_ = p * 64 + (__ffsll((long long)m) - 1);
-     }
-     if (lane == 0) {
-       strip_ns[parity][wib] = ns_;
-       strip_only[parity][wib] = only_;
-     }
-     __syncthreads();  // (one barrier per strip: the buffers alternate, so nobody overwrites what a slower wave still reads)
-     int tot = 0, only_all = 0;
+  // The cull the four waves of a workgroup share: the shapes the cone over tile columns [tx0, tx1) and local rows
+  // [lr0, lr1] can touch are counted (wave w looks at passes w, w + 4, ...); true if that is one sphere and the dome
+  // shortcut holds for it (then `cum` / `settled` as dome_value gives them).  One workgroup barrier per call.
+  auto shared_cull = [&](int tx0, int tx1, int lr0, int lr1, V3 &cum, bool &settled) -> bool {
+    const int sgr0 = global_row(a, lr0);
+    const int sgr1 = global_row(a, lr1 < rows_local ? lr1 : rows_local - 1);
+    // (a rank's rows interleave with other ranks': the cone over [sgr0, sgr1] covers those too -- a superset)
+    const TileCone sc = tile_cone(a, tx0 * 8, (tx1 * 8 < W) ? tx1 * 8 : W, sgr0, sgr1);
+    int ns_ = 0, only_ = 0;
+    for (int p = wib; p < npass && ns_ <= 1; p += PT_BLOCK / 64) {
+      const int slot = p * 64 + lane;
+      bool keep = false;
+      float4 b = {0.0f, 0.0f, 0.0f, -1.0f};
+      if (slot < a.n_shapes) b = (KEEP && p == wib) ? sb_kept : a.bounds[slot];
+      const bool isplane = slot >= a.n_spheres && slot < a.n_shapes;
+      if (slot < a.n_spheres) keep = cone_keeps(sc, b);
+      if (__any(isplane)) {
+        const bool pk = plane_keeps(sc, b, isplane);
+        if (isplane) keep = pk;
+      }
+      const unsigned long long m = __ballot(keep);
+      ns_ += __popcll(m);
+      if (m) only_ = p * 64 + (__ffsll((long long)m) - 1);
+    }
+    if (lane == 0) {
+      strip_ns[parity][wib] = ns_;
+      strip_only[parity][wib] = only_;
+    }
+    __syncthreads();  // (one barrier per cull: the buffers alternate, so nobody overwrites what a slower wave still reads)
+    int tot = 0, only_all = 0;
 #pragma unroll
-     for (int w = 0; w < PT_BLOCK / 64; ++w) {
-       const int nw = strip_ns[parity][w];
-       tot += nw;
-       if (nw) only_all = strip_only[parity][w];
-     }
-     parity ^= 1;
-     if (tot == 1 && only_all < a.n_spheres)
-       strip_dome = dome_value(__builtin_amdgcn_readfirstlane(only_all), 0.0, sc.dmax2, sc.dmin, sc.all, strip_cum, strip_settled);
-   }
+    for (int w = 0; w < PT_BLOCK / 64; ++w) {
+      const int nw = strip_ns[parity][w];
+      tot += nw;
+      if (nw) only_all = strip_only[parity][w];
+    }
+    parity ^= 1;
+    settled = false;
+    if (tot == 1 && only_all < a.n_spheres)
+      return dome_value(__builtin_amdgcn_readfirstlane(only_all), 0.0, sc.dmax2, sc.dmin, sc.all, cum, settled);
+    return false;
+  };
+  // Path tracer's first pass on frames with many more strips than workgroups (4K): a workgroup takes a BLOCK of four
+  // strips, one below the other (32 x 32 pixels), and culls the block first -- under an open sky that one cull
+  // settles sixteen tiles, which then cost a store each.  A block that sees more than the dome is worked through
+  // strip by strip as before.
+  const int blocks_y = (tiles_y + 3) >> 2;
+  const bool use_blocks = BLOCKS && KEEP && use_strips;  // (the host asks for it where blocks outnumber workgroups 2 : 1)
+  const int nwork = use_blocks ? strips_x * blocks_y : nstrips;
+  for (int work = blockIdx.x; work < nwork; work += gridDim.x) {
+   const int wy = work / strips_x, tx_first = (work - wy * strips_x) * 4;
+   const int tx_end = tx_first + 4 < tiles_x ? tx_first + 4 : tiles_x;
+   const int ty_first = use_blocks ? wy * 4 : wy;
+   const int ty_end = use_blocks ? (ty_first + 4 < tiles_y ? ty_first + 4 : tiles_y) : ty_first + 1;
+   bool block_dome = false, block_settled = false;
+   V3 strip_cum = {0.0, 0.0, 0.0};  // (KEEP: the dome's value is dc_cum, this copy is not used)
+   if (use_blocks) block_dome = shared_cull(tx_first, tx_end, ty_first * 8, ty_end * 8 - 1, strip_cum, block_settled);
+   for (int ty = ty_first; ty < ty_end; ++ty) {
+   bool strip_dome = block_dome, strip_settled = block_settled;
+   if (use_strips && !block_dome) strip_dome = shared_cull(tx_first, tx_end, ty * 8, ty * 8 + 7, strip_cum, strip_settled);
    {
     const int tx = tx_first + wib;
     if (tx >= tx_end) continue;
@@ -1902,7 +1922,7 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
     const long long pix = (long long)clrow * W + ccol;
     if (strip_dome) {  // (settled by the strip's cull: nothing but the dome can be seen from these four tiles)
       if (strip_settled && active) {
-        store_pixel(a, pix, strip_cum);
+        store_pixel(a, pix, KEEP ? dc_cum : strip_cum);
         nrays += (unsigned long long)nsamp;
         nres += (unsigned long long)nsamp;
       }
@@ -2210,6 +2230,7 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
     }
     __builtin_amdgcn_wave_barrier();  // the next tile overwrites this wave's mask slice
     PT_TSTAMP(6);
+   }
    }
   }
 #ifdef PT_DEBUG_TIME

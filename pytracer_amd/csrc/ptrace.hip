@@ -1163,7 +1163,15 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
     else if (p->renderer == PT_RENDERER_POINTLIGHT)
       PT_LAUNCH((pt_tile_kernel<PT_RENDERER_POINTLIGHT, 3, false>), tgrid, lds, !path_tiled, a, 0);
     else
-      PT_LAUNCH((pt_tile_kernel<PT_RENDERER_PATHTRACER, 4, false>), tgrid, lds, !path_tiled, a, grid);
+    {
+      // big frames: a workgroup culls a block of four strips (32 x 32 pixels) before it looks at the strips
+      const int tiles_x = (p->width + 7) / 8, tiles_y = (rows + 7) / 8;
+      const long long nblocks = (long long)((tiles_x + 3) / 4) * ((tiles_y + 3) / 4);
+      if (a.npass >= 2 && s->dome_shortcut && nblocks >= 2LL * tgrid)
+        PT_LAUNCH((pt_tile_kernel<PT_RENDERER_PATHTRACER, 4, false, false, true>), tgrid, lds, !path_tiled, a, grid);
+      else
+        PT_LAUNCH((pt_tile_kernel<PT_RENDERER_PATHTRACER, 4, false>), tgrid, lds, !path_tiled, a, grid);
+    }
     if (path_tiled) {
       // second pass: the pixels the first one flagged, fullest regions first
       const int nsamp = p->samples_per_side > 0 ? p->samples_per_side * p->samples_per_side : 1;
