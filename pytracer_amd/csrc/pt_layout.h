@@ -112,6 +112,7 @@ struct PtKArgs {
   double *ws;                      // path-tracer frame stack: [slot][field][thread]
   unsigned long long *ray_counter; // per-workgroup partial counts; may be null
   unsigned long long *queue;       // path tracer: the two queue blocks (pt_kernels.h: pt_queue)
+  int block_h;                     // path tracer's first pass, BLOCKS variant: strips per block (4 or 2)
   int qpar;                        // ... and which of them this frame uses (by value; the device copy of the block holds 0)
   const int4 *units;               // path tracer, second pass: (region, first flagged pixel | pixels << 8, region mask) per work unit
   int dome_slot;                   // path tracer, first pass: the sphere the camera is deepest inside (uniform pigments), or -1

@@ -1101,6 +1101,19 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
     a.cells_x = cells_x;
     a.cell_stride = cell_stride;
   }
+  a.block_h = 1;
+  if (path_tiled && !ortho && !hier) {
+    // first pass: a workgroup culls a block of four (two) strips, 32 x 32 (32 x 16) pixels, before it looks at the
+    // strips -- where that still leaves a block for every other workgroup: pt_tile_kernel<..., BLOCKS>
+    static const int env_bh = getenv("PTRACE_BLOCK_H") ? atoi(getenv("PTRACE_BLOCK_H")) : 0;
+    const int tiles_x = (p->width + 7) / 8, tiles_y = (rows + 7) / 8;
+    const long long strips_x = (tiles_x + 3) / 4;
+    if (2 * strips_x * ((tiles_y + 3) / 4) >= (long long)grid_first)  // (measured: still ahead with one block per two workgroups)
+      a.block_h = 4;
+    else if (2 * strips_x * ((tiles_y + 1) / 2) >= (long long)grid_first)
+      a.block_h = 2;
+    if (env_bh > 0) a.block_h = env_bh;
+  }
   // the cold half of the argument block is read from device memory: refresh the copy when it changed
   // (the output pointer stays a by-value argument: double-buffered frames alternate it every launch)
   a.cold = s->args_dev;
@@ -1164,10 +1177,7 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
       PT_LAUNCH((pt_tile_kernel<PT_RENDERER_POINTLIGHT, 3, false>), tgrid, lds, !path_tiled, a, 0);
     else
     {
-      // big frames: a workgroup culls a block of four strips (32 x 32 pixels) before it looks at the strips
-      const int tiles_x = (p->width + 7) / 8, tiles_y = (rows + 7) / 8;
-      const long long nblocks = (long long)((tiles_x + 3) / 4) * ((tiles_y + 3) / 4);
-      if (a.npass >= 2 && s->dome_shortcut && nblocks >= 2LL * tgrid)
+      if (a.npass >= 2 && s->dome_shortcut && a.block_h > 1)  // (big frames: blocks of strips, see a.block_h above)
         PT_LAUNCH((pt_tile_kernel<PT_RENDERER_PATHTRACER, 4, false, false, true>), tgrid, lds, !path_tiled, a, grid);
       else
         PT_LAUNCH((pt_tile_kernel<PT_RENDERER_PATHTRACER, 4, false>), tgrid, lds, !path_tiled, a, grid);
