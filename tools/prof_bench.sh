@@ -27,12 +27,12 @@ KB="python3 $ROOT/tools/kbench.py c5 --rounds 4"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_c5f -- $KB > $OUT/pmc_c5f.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_c5w -- $KB > $OUT/pmc_c5w.log 2>&1
 cd $ROOT
-python3 tools/pmc_summary.py $OUT/pmc_c5f $OUT/pmc_c5w --kernel "pt_tile_kernel<1, 4, true, false>" --json $OUT/pmc_c5_tile.json --source "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate runs) on 'python3 tools/kbench.py c5 --rounds 4' (C5: 1280x720, 10 000 spheres, Flat); medians over the launches; tools/prof_bench.sh $TAG" > /dev/null
+python3 tools/pmc_summary.py $OUT/pmc_c5f $OUT/pmc_c5w --kernel "pt_tile_kernel<1, 4, true, false" --json $OUT/pmc_c5_tile.json --source "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate runs) on 'python3 tools/kbench.py c5 --rounds 4' (C5: 1280x720, 10 000 spheres, Flat); medians over the launches; tools/prof_bench.sh $TAG" > /dev/null
 python3 tools/pmc_summary.py $OUT/pmc_c5f $OUT/pmc_c5w --kernel "pt_cell_kernel" --json $OUT/pmc_c5_cell.json --source "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate runs) on 'python3 tools/kbench.py c5 --rounds 4'; medians over the launches; tools/prof_bench.sh $TAG" > /dev/null
 python3 tools/pmc_summary.py $OUT/pmc_c3 --kernel "pt_path_regions_kernel" --json $OUT/pmc_c3_second_pass.json --source "rocprofv3 --pmc on 'python3 tools/kbench.py c3 --rounds 4' (C3, PT_PCG_PIXEL); medians over the launches; tools/prof_bench.sh $TAG" > /dev/null
 python3 tools/pmc_summary.py $OUT/pmc_c3s --kernel "pt_path_regions_kernel" --json $OUT/pmc_c3_second_pass_sample.json --source "rocprofv3 --pmc on 'python3 tools/kbench.py c3:sample --rounds 4' (C3, PT_PCG_SAMPLE); medians over the launches; tools/prof_bench.sh $TAG" > /dev/null
 SRC="rocprofv3 --pmc (four separate passes: SQ issue counters, fp64 instruction classes, FETCH_SIZE, WRITE_SIZE) on 'python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline'; medians over the dispatches of the kernel; tools/prof_bench.sh $TAG"
-python3 tools/pmc_summary.py $OUT/pmc1 $OUT/pmc2 $OUT/pmc3 $OUT/pmc4 --kernel "pt_tile_kernel<1, 4, false, false>" --grid 524288 --json $OUT/pmc_c2.json --source "$SRC" > /dev/null
+python3 tools/pmc_summary.py $OUT/pmc1 $OUT/pmc2 $OUT/pmc3 $OUT/pmc4 --kernel "pt_tile_kernel<1, 4, false, false" --grid 524288 --json $OUT/pmc_c2.json --source "$SRC" > /dev/null
 python3 tools/pmc_summary.py $OUT/pmc1 $OUT/pmc2 $OUT/pmc3 $OUT/pmc4 --kernel "pt_path_regions_kernel" --grid 131072 --json $OUT/pmc_path_second_pass.json --source "$SRC (all second-pass launches of the run: C3, C4, shares)" > /dev/null || true
 f=$(find $OUT/trace -name "*kernel_stats.csv" | head -1)
 cp $f $OUT/kernel_stats.csv
