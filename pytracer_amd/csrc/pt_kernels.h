@@ -1897,14 +1897,15 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
   // settles sixteen tiles, which then cost a store each.  A block that sees more than the dome is worked through
   // strip by strip as before.
   const bool use_blocks = BLOCKS && KEEP && use_strips;  // (the host asks for it where there are blocks enough for the workgroups)
-  const int block_h = use_blocks ? cold_args(a)->block_h : 1;  // strips per block: 4 or 2
+  int block_h = 1;  // strips per block: 4 or 2
+  if constexpr (BLOCKS) block_h = use_blocks ? cold_args(a)->block_h : 1;
   const int blocks_y = (tiles_y + block_h - 1) / block_h;
   const int nwork = use_blocks ? strips_x * blocks_y : nstrips;
   for (int work = blockIdx.x; work < nwork; work += gridDim.x) {
    const int wy = work / strips_x, tx_first = (work - wy * strips_x) * 4;
    const int tx_end = tx_first + 4 < tiles_x ? tx_first + 4 : tiles_x;
-   const int ty_first = wy * block_h;
-   const int ty_end = ty_first + block_h < tiles_y ? ty_first + block_h : tiles_y;
+   const int ty_first = BLOCKS ? wy * block_h : wy;
+   const int ty_end = BLOCKS ? (ty_first + block_h < tiles_y ? ty_first + block_h : tiles_y) : ty_first + 1;
    bool block_dome = false, block_settled = false;
    V3 strip_cum = {0.0, 0.0, 0.0};  // (KEEP: the dome's value is dc_cum, this copy is not used)
    if (use_blocks) block_dome = shared_cull(tx_first, tx_end, ty_first * 8, ty_end * 8 - 1, strip_cum, block_settled);

@@ -964,3 +964,17 @@ def test_queue_blocks_alternate_cleanly(dev):
             c, p = jobs[name]
             got = ds.render(c, p)
             assert util.bits_equal(got, want[name]), (k, name)
+
+
+def test_tile_kernels_keep_their_occupancy(dev):
+    """The C2-class kernels are issue-bound at five (Flat) / six (OnOff) waves per SIMD: a change that pushes them over
+    96 / 80 registers costs a wave and ~8 % of the headline (it has happened through code shared with the path
+    tracer's first pass).  pt_stats.vgprs is what hipFuncGetAttributes reports for the kernel just launched."""
+    import torch
+
+    scene, cam = _synthetic(32, True, False, 320, 180)
+    out = torch.empty((180, 320, 3), dtype=torch.float32, device="cuda")
+    with dev.DeviceScene(scene) as ds:
+        for renderer, limit in ((abi.RENDERER_FLAT, 96), (abi.RENDERER_ONOFF, 80)):
+            ds.render_into(cam, abi.make_params(320, 180, renderer, out_format=abi.OUT_F32), out.data_ptr(), out.numel() * 4, None)
+            assert 0 < ds.stats().vgprs <= limit, (renderer, ds.stats().vgprs)
