@@ -2771,10 +2771,14 @@ PT_DEV void path_trace(const PtKArgs &a) {
 #endif
           for (int jj = 0; jj < L; ++jj) {
             const int src = (leader + jj) & 63;
-            const uint64_t s_from = __shfl((unsigned long long)st_start, src, 64);
-            const uint64_t s_to = __shfl((unsigned long long)pcg.state, src, 64);
+            uint64_t s_from = 0, s_to = 0;  // (PT_PCG_SAMPLE validates nothing: five cross-lane reads less per turn)
+            unsigned s_draws = 0;
+            if (pcg_mode != PT_PCG_SAMPLE) {
+              s_from = __shfl((unsigned long long)st_start, src, 64);
+              s_to = __shfl((unsigned long long)pcg.state, src, 64);
+              s_draws = (unsigned)__shfl((int)pcg.n, src, 64);
+            }
             const int s_fin = __shfl((int)fin, src, 64);
-            const unsigned s_draws = (unsigned)__shfl((int)pcg.n, src, 64);
             const unsigned s_rays = (unsigned)__shfl((int)srays, src, 64);
             const double rx_ = __shfl(ret.x, src, 64), ry_ = __shfl(ret.y, src, 64), rz_ = __shfl(ret.z, src, 64);
             chain = chain && s_fin != 0 && (pcg_mode == PT_PCG_SAMPLE || s_from == vstate);
