@@ -2281,6 +2281,9 @@ PT_DEV int unit_ppu(const unsigned long long *queue, long long lanes_cap, int ns
     lg *= 2;
   return 64 / lg;
 }
+#ifndef PT_SCATTER_BLOCK
+#define PT_SCATTER_BLOCK 256
+#endif
 __global__ void pt_unit_scatter(const unsigned char *keys, const unsigned long long *masks, int n, int4 *units, int units_cap,
                                 unsigned long long *queue, long long lanes_cap, int nsamp, int min_rounds) {
   __shared__ int cnt[65], offs[65];

@@ -1187,7 +1187,7 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
       const int nsamp = p->samples_per_side > 0 ? p->samples_per_side * p->samples_per_side : 1;
       static const int env_minr = getenv("PTRACE_UNIT_MIN_ROUNDS") ? atoi(getenv("PTRACE_UNIT_MIN_ROUNDS")) : 0;
       const int min_rounds = env_minr != 0 ? env_minr : (a.pcg_mode == PT_PCG_SAMPLE ? -2 : 16);  // (< 0: see unit_ppu)
-      hipLaunchKernelGGL(pt_unit_scatter, dim3((nregions + 1023) / 1024), dim3(1024), 0, st, s->region_keys, s->region_mask, nregions, s->units, s->units_cap,
+      hipLaunchKernelGGL(pt_unit_scatter, dim3((nregions + PT_SCATTER_BLOCK - 1) / PT_SCATTER_BLOCK), dim3(PT_SCATTER_BLOCK), 0, st, s->region_keys, s->region_mask, nregions, s->units, s->units_cap,
                          s->queue_last, lanes_cap, nsamp, min_rounds);
       if (lds_frames && a.scene_lds >= 0) {
         HIP_TRY(path_lds_limit((const void *)pt_path_regions_kernel<true, true>, lds + frame_lds + diag_lds_bytes));
