@@ -7,12 +7,17 @@ compact ``[rows_r, W, 3]`` buffer — there is no exchange inside a frame — an
 frame assembles the ``HdrImage`` on rank 0.  Per-pixel PCG seeds depend only on the global pixel
 index, so the assembled image is bit-identical for every world size.
 
-The gather writes straight into the final image: a row block is ``row_block * W * 3`` contiguous values
-both in the sender's compact shard (its k-th block) and in the ``[H, W, 3]`` frame (rows
-``[b * row_block, (b + 1) * row_block)``), so rank 0 posts one receive per remote block whose destination
-IS that slice of the frame, every other rank one send per block, all of them in one batched
-point-to-point group (``batch_isend_irecv``: a single ncclGroupStart/End on RCCL).  No padded scratch
-copy of the frame, no de-interleave pass; rank 0's own blocks are one strided device copy.
+The gather moves ONE message per remote rank (round 3; round 2 posted one receive per remote 8-row block: 236
+transfers of 368 KB per 4K frame at 8 ranks): a rank's compact shard is contiguous, so it is sent whole into a
+staging buffer on rank 0, and a strided device copy per rank then drops its blocks into row-block order
+(``frame.view(groups, world, row_block, W, 3)[:, r] = shard.view(groups, row_block, W, 3)`` plus at most one ragged
+tail block).  The render granularity (8-row blocks, for load balance) and the gather granularity (a rank's whole
+share) are thereby independent: ``world - 1`` transfers per frame, all in one batched point-to-point group
+(``batch_isend_irecv``: a single ncclGroupStart/End on RCCL), and ``gather_plan()`` reports their number and bytes.
+
+Which transport a process group uses is decided ONCE and COLLECTIVELY (``choose_transport``): every rank, also one
+that owns no rows, runs the same probe and the verdicts are all-reduced, so no rank can end up in a different
+collective from the others; an error inside a frame's gather is raised, never retried on another transport.
 
 The local renderer is pluggable (``render_local(params) -> tensor``) so the partition/gather logic is
 exercised on CPU with the ``gloo`` backend in the tests; in production it is ``DeviceScene.render_into``.
@@ -47,11 +52,82 @@ def shard_blocks(height: int, row_block: int, world_size: int, rank: int) -> Lis
     return out
 
 
-_use_p2p = True  # flips to False (on every rank alike) if the backend refuses batched point-to-point transfers
+P2P, PADDED = "p2p", "padded"
+_transport = {}  # process group (None = the default one) -> P2P | PADDED, agreed on by all its ranks
+
+
+def choose_transport(group=None, force: Optional[str] = None) -> str:
+    """Agree, once per process group, on how shards travel: batched point-to-point transfers (one per remote rank),
+    or -- for a backend that refuses those -- one ``gather`` of shards padded to a common size.
+
+    A collective: EVERY rank of the group must call it (``gather_image`` does, on first use), whether or not it owns
+    rows.  The probe is a one-element send from every rank to the last one's neighbour ring; the ranks' verdicts
+    meet in an all-reduce, so either all ranks use point-to-point transfers or none does.  ``force`` (or the
+    environment variable ``PT_GATHER``) pins the choice without a probe -- it must then be the same on every rank."""
+    import os
+
+    if group in _transport and force is None:
+        return _transport[group]
+    force = force or os.environ.get("PT_GATHER")
+    if force in (P2P, PADDED):
+        _transport[group] = force
+        return force
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    ok = 1
+    try:
+        nxt = (rank + 1) % world
+        prv = (rank - 1) % world
+        if group is not None:
+            nxt, prv = dist.get_global_rank(group, nxt), dist.get_global_rank(group, prv)
+        a = torch.full((1,), float(rank), device=dev)
+        b = torch.empty((1,), device=dev)
+        for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, a, nxt, group), dist.P2POp(dist.irecv, b, prv, group)]):
+            req.wait()
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+        if int(b.item()) != (rank - 1) % world:
+            ok = 0
+    except (RuntimeError, ValueError, NotImplementedError):
+        ok = 0  # refused before anything was sent; the all-reduce below is still entered by this rank
+    flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    _transport[group] = P2P if int(flag.item()) == 1 else PADDED
+    return _transport[group]
+
+
+def gather_plan(height: int, width: int, row_block: int, world: int, itemsize: int = 4, transport: str = P2P) -> dict:
+    """What one frame's gather moves: transfers into rank 0 and their bytes (for the bench line)."""
+    rows = [len(shard_rows(height, row_block, world, r)) for r in range(world)]
+    if transport == P2P:
+        ops = sum(1 for r in range(1, world) if rows[r] > 0)
+        nbytes = sum(rows[1:]) * width * 3 * itemsize
+    else:
+        ops = 1
+        nbytes = max(rows) * (world - 1) * width * 3 * itemsize
+    return {"transport": transport, "gather_ops_per_frame": ops, "gather_bytes_per_frame": nbytes,
+            "rows_per_rank": rows}
+
+
+def place_shard(out: torch.Tensor, shard: torch.Tensor, height: int, row_block: int, world: int, r: int) -> None:
+    """Drop rank ``r``'s compact shard into row-block order: one strided copy for the complete groups of
+    ``world`` blocks, one more for a ragged tail block."""
+    rb = max(1, int(row_block))
+    G = rb * world
+    ng = height // G
+    tail_shape = tuple(out.shape[1:])
+    if ng:
+        out[: ng * G].view((ng, world, rb) + tail_shape)[:, r].copy_(shard[: ng * rb].view((ng, rb) + tail_shape),
+                                                                     non_blocking=True)
+    g0 = ng * G + r * rb  # first row of r's block in the incomplete last group
+    n = min(rb, height - g0)
+    if n > 0:
+        out[g0:g0 + n].copy_(shard[ng * rb: ng * rb + n], non_blocking=True)
 
 
 def _gather_padded(local, height, row_block, world, rank, group, dst, out):
-    """The collective of last resort: one ``gather`` of shards padded to a common size, then the block copies."""
+    """The collective for a backend without batched point-to-point: one ``gather`` of shards padded to a common size."""
     pad = max_shard_rows(height, row_block, world)
     shard = local[:pad] if local.shape[0] >= pad else torch.cat(
         [local, local.new_zeros((pad - local.shape[0],) + tuple(local.shape[1:]))])
@@ -60,57 +136,54 @@ def _gather_padded(local, height, row_block, world, rank, group, dst, out):
         parts = [torch.empty_like(shard) for _ in range(world)]
         dist.gather(shard, parts, dst=dst, group=group)
         for r in range(world):
-            for g0, l0, n in shard_blocks(height, row_block, world, r):
-                out[g0:g0 + n].copy_(parts[r][l0:l0 + n], non_blocking=True)
+            place_shard(out, parts[r], height, row_block, world, r)
     else:
         dist.gather(shard, None, dst=dst, group=group)
 
 
 def gather_image(local: torch.Tensor, height: int, row_block: int, group=None, dst: int = 0,
-                 out: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+                 out: Optional[torch.Tensor] = None, staging: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
     """Assemble the frame on ``dst`` from the ranks' compact row shards.
 
     ``local`` is this rank's ``[>= rows_of_this_rank, W, 3]`` shard (rows beyond its own are ignored).
+    ``staging`` (``dst`` only, optional): a ``[world, max_shard_rows, W, 3]`` buffer the remote shards land in.
     Returns the ``[H, W, 3]`` image on ``dst`` (``out`` when given) and ``None`` elsewhere."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     if world == 1:
         rows = shard_rows(height, row_block, 1, 0)
         return local[: len(rows)]
+    transport = choose_transport(group)  # (collective on first use: every rank gets here, with or without rows)
     # rehearsal on a box with fewer GPUs than ranks (PT_DIST_BACKEND=gloo): gloo moves host memory only
     staged = dist.get_backend(group) == "gloo" and local.is_cuda
     if staged:
         dev_out, dev_local = out, local
         local = dev_local.cpu()
         out = torch.empty((height,) + tuple(local.shape[1:]), dtype=local.dtype) if rank == dst else None
-    global _use_p2p
-    ops = []
+        staging = None
     if rank == dst and out is None:
         out = torch.empty((height,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    if not _use_p2p:
+    nrows = [len(shard_rows(height, row_block, world, r)) for r in range(world)]
+    if transport == PADDED:
         _gather_padded(local, height, row_block, world, rank, group, dst, out)
     elif rank == dst:
+        if staging is None:
+            staging = torch.empty((world, max(nrows)) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        ops = []
         for r in range(world):
-            blocks = shard_blocks(height, row_block, world, r)
-            if r == dst:
-                for g0, l0, n in blocks:  # (a handful of strided copies on the device; no communication)
-                    out[g0:g0 + n].copy_(local[l0:l0 + n], non_blocking=True)
-            else:
+            if r != dst and nrows[r] > 0:
                 peer = dist.get_global_rank(group, r) if group is not None else r
-                ops += [dist.P2POp(dist.irecv, out[g0:g0 + n], peer, group) for g0, _, n in blocks]
-    else:
-        peer = dist.get_global_rank(group, dst) if group is not None else dst
-        ops = [dist.P2POp(dist.isend, local[l0:l0 + n], peer, group)
-               for _, l0, n in shard_blocks(height, row_block, world, rank)]
-    if ops:
-        try:
+                ops.append(dist.P2POp(dist.irecv, staging[r, : nrows[r]], peer, group))
+        if ops:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()  # (RCCL: returns once the group is enqueued on the current stream)
-        except (RuntimeError, ValueError, NotImplementedError):
-            # the same call fails the same way on every rank (it is refused before anything is sent): all of them
-            # switch to the padded gather, for this frame and the following ones
-            _use_p2p = False
-            _gather_padded(local, height, row_block, world, rank, group, dst, out)
+        for r in range(world):
+            if nrows[r] > 0:
+                place_shard(out, local if r == dst else staging[r], height, row_block, world, r)
+    elif nrows[rank] > 0:
+        peer = dist.get_global_rank(group, dst) if group is not None else dst
+        for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, local[: nrows[rank]], peer, group)]):
+            req.wait()
     if staged and rank == dst:
         if dev_out is None:
             dev_out = torch.empty(out.shape, dtype=out.dtype, device=dev_local.device)
@@ -157,8 +230,15 @@ class ShardedFrameLoop:
         self.stream = torch.cuda.Stream(device=self.device)
         self.comm = torch.cuda.Stream() if self.world > 1 else None
         self.full = None
+        self.staging = None
         if self.world > 1 and self.rank == 0:
             self.full = [torch.empty((self.height, self.width, 3), dtype=dt, device=self.device) for _ in range(2)]
+            # the remote shards of a frame land here; the comm stream runs receive -> placement copies -> next receive
+            # in order, so one staging buffer serves both frame buffers
+            self.staging = torch.empty((self.world, max_shard_rows(self.height, row_block, self.world), self.width, 3),
+                                       dtype=dt, device=self.device)
+        if self.world > 1:
+            choose_transport(group)  # collective, before the first frame
         self._free = [None, None]  # event: the gather that last read buffer b is done
         self.last = 0
 
@@ -176,7 +256,8 @@ class ShardedFrameLoop:
             with torch.cuda.stream(self.comm):
                 self.comm.wait_event(rendered)
                 gather_image(self.bufs[b], self.height, self.row_block, group=self.group, dst=0,
-                             out=self.full[b] if self.rank == 0 else None)
+                             out=self.full[b] if self.rank == 0 else None,
+                             staging=self.staging if self.rank == 0 else None)
                 done = torch.cuda.Event()
                 done.record(self.comm)
                 self._free[b] = done

@@ -2,7 +2,7 @@
 
 The GPU kernel cannot run here, so each rank's local renderer is the CPU oracle (allowed: tests may
 use the oracle as a stand-in); what is under test is pytracer_amd.dist — the interleaved row-block
-partition and the gather straight into row-block order (one point-to-point transfer per remote block) — and the invariant that the assembled frame is
+partition and the gather (one point-to-point transfer per remote rank, then a strided placement into row-block order) — and the invariant that the assembled frame is
 bit-identical to the single-process frame (per-pixel seeds depend only on the global pixel index)."""
 import os
 import socket
@@ -73,7 +73,7 @@ def test_sharded_render_matches_single_process(world, renderer, S, height, row_b
     assert ret["shape"] == (height, 48, 3)
 
 
-def _gather_worker(rank, world, port, use_p2p, ret):
+def _gather_worker(rank, world, port, transport, H, ret):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -81,29 +81,66 @@ def _gather_worker(rank, world, port, use_p2p, ret):
     try:
         from pytracer_amd import dist as ptdist
 
-        ptdist._use_p2p = use_p2p
-        H, W = 27, 5  # ragged: 8 + 8 + 8 + 3 rows over `world` ranks
+        if transport is not None:
+            ptdist.choose_transport(force=transport)  # (else: the collective probe inside the first gather decides)
+        W = 5
         full = torch.arange(H * W * 3, dtype=torch.float64).reshape(H, W, 3)
         rows = ptdist.shard_rows(H, 8, world, rank)
         shard = full[rows].contiguous() if rows else torch.zeros((1, W, 3), dtype=torch.float64)
         out = ptdist.gather_image(shard, H, 8)
         if rank == 0:
             ret["ok"] = bool(torch.equal(out, full))
+            ret["transport"] = ptdist.choose_transport()
         else:
             assert out is None
+        # a second frame through the same (now settled) transport
+        out = ptdist.gather_image(shard + 1.0, H, 8)
+        if rank == 0:
+            ret["ok2"] = bool(torch.equal(out, full + 1.0))
         dist.barrier()
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,use_p2p", [(2, True), (3, True), (2, False), (3, False)])
-def test_gather_straight_into_row_blocks_and_the_padded_fallback(world, use_p2p):
-    """Both collectives behind gather_image: the batched point-to-point transfers whose destinations are the row
-    blocks of the final frame, and the padded `gather` the code switches to if the backend refuses those."""
+@pytest.mark.parametrize("world,transport,H", [
+    (2, "p2p", 27), (3, "p2p", 27),        # ragged: 8 + 8 + 8 + 3 rows over `world` ranks
+    (2, "padded", 27), (3, "padded", 27),
+    (3, None, 27),                          # nobody forces anything: the collective probe decides (gloo: p2p)
+    (3, None, 10), (3, "padded", 10),      # rank 2 owns no rows and must still be in every collective
+    (3, None, 50),                          # 2 complete groups of 3 blocks + a ragged tail block of rank 0
+])
+def test_gather_one_transfer_per_rank_and_the_padded_transport(world, transport, H):
+    """Both transports behind gather_image: one batched point-to-point transfer per remote rank followed by the strided
+    placement into row-block order, and the padded `gather` for a backend that refuses those; which one is used is
+    agreed on collectively (`choose_transport`), also by a rank without rows."""
     port = _free_port()
     ret = mp.Manager().dict()
-    mp.spawn(_gather_worker, args=(world, port, use_p2p, ret), nprocs=world, join=True)
-    assert ret["ok"] is True
+    mp.spawn(_gather_worker, args=(world, port, transport, H, ret), nprocs=world, join=True)
+    assert ret["ok"] is True and ret["ok2"] is True
+    assert ret["transport"] == (transport or "p2p")
+
+
+def test_gather_plan_counts_transfers():
+    from pytracer_amd import dist as ptdist
+
+    plan = ptdist.gather_plan(2160, 3840, 8, 8, itemsize=4)
+    assert plan["gather_ops_per_frame"] == 7  # VERDICT r2 item 4: <= 40 transfers per 4K frame at 8 ranks (was 236)
+    assert plan["gather_bytes_per_frame"] == sum(plan["rows_per_rank"][1:]) * 3840 * 3 * 4
+    assert sum(plan["rows_per_rank"]) == 2160
+    assert ptdist.gather_plan(10, 48, 8, 3)["gather_ops_per_frame"] == 1  # rank 2 owns nothing: no transfer for it
+
+
+def test_place_shard_is_the_inverse_of_the_partition():
+    from pytracer_amd import dist as ptdist
+
+    for H, rb, world in ((27, 8, 2), (50, 8, 3), (10, 8, 3), (2160, 8, 8), (721, 7, 3), (5, 8, 2), (64, 8, 8)):
+        full = torch.arange(H * 2 * 3, dtype=torch.float64).reshape(H, 2, 3)
+        out = torch.full_like(full, -1.0)
+        for r in range(world):
+            rows = ptdist.shard_rows(H, rb, world, r)
+            if rows:
+                ptdist.place_shard(out, full[rows].contiguous(), H, rb, world, r)
+        assert torch.equal(out, full), (H, rb, world)
 
 
 def test_partition_helpers():
