@@ -9,12 +9,17 @@ pixel-centre rays (S=0), synthetic scene of SURVEY.md §8(d).  One *step* = one 
 precision: 12 B/pixel).  Every timed launch carries its own hipEvent pair IN the dispatch (no barrier
 packets), so `roofline.avg_kernel_ms` is the mean over all K timed launches.
 
-N > 1 (torch.distributed.run, one rank per GPU, RCCL) — workload = configs[3] ("C4"): ONE 3840x2160 frame, 256
-spheres, PathTracer depth 5, 64 samples per pixel, STRONG-scaled: rows are cut in interleaved 8-row blocks,
-every rank renders its blocks, and the frame is assembled on rank 0 by one batched RCCL point-to-point gather
-per frame straight into row-block order (double-buffered: the gather of frame i overlaps the render of frame
-i+1).  The gather is INSIDE the timed region: `value` = rays of the whole frame x K / wall time.  The same loop
-without the gather, the other PCG mode and the same frame on rank 0 alone are side rows.
+N > 1 (one rank per GPU, RCCL; under `torch.distributed.run`, or by itself: `python bench.py --gpus N` starts its
+own N ranks before touching the GPU and relays rank 0's line) — workload = configs[3] ("C4"): ONE 3840x2160 frame,
+256 spheres, PathTracer depth 5, 64 samples per pixel, STRONG-scaled: rows are cut in interleaved 8-row blocks,
+every rank renders its blocks, and the frame is assembled on rank 0 by one batched RCCL point-to-point group per
+frame (one transfer per remote rank + a strided placement copy; double-buffered: the gather of frame i overlaps
+the render of frame i+1).  The gather is INSIDE the timed region: `value` = rays of the whole frame x K / wall
+time.  This is NOT the N = 1 line's workload, so the line carries its own one-GPU figure (`n1_same_workload`: the
+same frame loop on rank 0 alone, same clock) with `speedup` and `parallel_efficiency` against it, `ranks_seen`
+(all-reduced) and `backend`; the same loop without the gather, with the dome shortcut off and under the other PCG
+mode are side rows.  After every phase the ranks all-reduce an error flag, so a rank's exception ends the job with
+a line carrying `error` instead of a watchdog abort.
 
 Prints ONE JSON line (rank 0).
 """
@@ -397,91 +402,211 @@ def run_single(args, local_rank):
     print(json.dumps(result), flush=True)
 
 
-def run_multi(args, rank, local_rank, world_size, dist):
+class Agreement:
+    """Ranks agree after every phase on whether all of them got through it: a rank that raised still enters this
+    all-reduce, so the others learn of it here instead of waiting in the next collective until the watchdog ends
+    the job -- and rank 0 can still print its line (with `error`)."""
+
+    def __init__(self, dist):
+        self.dist = dist
+        self.error = None
+
+    def run(self, phase, fn):
+        """Run `fn()` on this rank; -> True iff EVERY rank completed it (collective)."""
+        if self.error is None:
+            try:
+                fn()
+            except Exception as e:  # noqa: BLE001  (RCCL / driver errors surface as RuntimeError subclasses)
+                self.error = f"{phase}: {type(e).__name__}: {e}"[:400]
+        try:
+            flag = torch.tensor([0 if self.error is None else 1], dtype=torch.int32, device="cuda")
+            self.dist.all_reduce(flag, op=self.dist.ReduceOp.MAX)
+            if int(flag.item()) and self.error is None:
+                self.error = f"{phase}: another rank failed"
+        except Exception as e:  # noqa: BLE001
+            self.error = self.error or f"{phase}: agreement failed: {type(e).__name__}: {e}"[:400]
+        return self.error is None
+
+
+def run_multi(args, rank, local_rank, world_size, dist, backend):
+    from pytracer_amd import dist as ptdist
+
     W, H = C4["W"], C4["H"]
     flat = flatten.flatten_world(scenes.synthetic_world(C4["n_spheres"], wide=C4["wide"]))
     cam = cam_for(W, H)
     ds = DeviceScene(flat, device=local_rank)
-    err = None
+    agree = Agreement(dist)
     rows = {}
-    rays_frame = {}
-    try:
-        for mode in (abi.PCG_PIXEL, abi.PCG_SAMPLE):
-            par = abi.make_params(W, H, out_format=abi.OUT_F32, pcg_mode=mode, **C4["kw"])
-            loop = ShardedFrameLoop(ds, cam, par, row_block=8)
+    rays_frame, resolved_frame = {}, {}
+    seen = [0]
+
+    def count_ranks():
+        t = torch.ones(1, dtype=torch.int64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        seen[0] = int(t.item())
+        if seen[0] != world_size:
+            raise RuntimeError(f"{seen[0]} ranks answered, {world_size} expected")
+
+    agree.run("rank count", count_ranks)
+    for mode in (abi.PCG_SAMPLE, abi.PCG_PIXEL):
+        if agree.error is not None:
+            break
+        par = abi.make_params(W, H, out_format=abi.OUT_F32, pcg_mode=mode, **C4["kw"])
+        loop = [None]
+
+        def warm():
+            loop[0] = ShardedFrameLoop(ds, cam, par, row_block=8)
             ds.set_count_rays(True)
             ds.set_timing(True)
             for i in range(max(2, args.warmup)):
-                loop.step(i, gather=True)
+                loop[0].step(i, gather=True)
             fence(dist)
             ds.sync()
-            r = torch.tensor([int(ds.stats().n_rays)], dtype=torch.int64, device="cuda")
+            st = ds.stats()
+            r = torch.tensor([int(st.n_rays), int(st.n_rays_resolved)], dtype=torch.int64, device="cuda")
             dist.all_reduce(r, op=dist.ReduceOp.SUM)
-            rays_frame[mode] = int(r.item())
-            for gather in (True, False):
-                elapsed, _, _ = timed_loop(ds, loop, args.steps, dist, gather, events=False)
-                _, kernel_ms, launches = timed_loop(ds, loop, max(2, args.steps // 2), dist, gather, events=True)
+            rays_frame[mode], resolved_frame[mode] = int(r[0].item()), int(r[1].item())
+
+        if not agree.run(f"warm-up {PCG_NAMES[mode]}", warm):
+            break
+        for gather in (True, False):
+            def timed():
+                elapsed, _, _ = timed_loop(ds, loop[0], args.steps, dist, gather, events=False)
+                _, kernel_ms, launches = timed_loop(ds, loop[0], max(2, args.steps // 2), dist, gather, events=True)
                 t = torch.tensor([elapsed, kernel_ms / max(1, launches)], dtype=torch.float64, device="cuda")
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 rows[(mode, gather)] = (float(t[0].item()), float(t[1].item()))
-            # the frame assembled on rank 0 must be bit-identical to the same frame rendered by one rank
-            loop.step(0, gather=True)
+
+            if not agree.run(f"timed loop {PCG_NAMES[mode]} gather={gather}", timed):
+                break
+        if agree.error is not None:
+            break
+
+        def dome_off():  # the same frames with every primary ray generated and traced (no gather: a side row)
+            ds.set_dome_shortcut(False)
+            try:
+                elapsed, _, _ = timed_loop(ds, loop[0], max(2, args.steps // 4), dist, False, events=False)
+            finally:
+                ds.set_dome_shortcut(True)
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            rows[(mode, "dome_off")] = (float(t[0].item()), max(2, args.steps // 4))
+
+        if not agree.run(f"dome-off loop {PCG_NAMES[mode]}", dome_off):
+            break
+
+        def check_and_solo():
+            # the frame assembled on rank 0 must be bit-identical to the same frame rendered by one rank ...
+            loop[0].step(0, gather=True)
             fence(dist)
             if rank == 0:
-                full = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")
-                one = abi.copy_params(par, n_ranks=1, rank=0)
-                ms1 = []
-                for _ in range(3):
-                    ds.render_into(cam, one, full.data_ptr(), full.numel() * 4, None)
-                    ms1.append(ds.stats().kernel_ms)
-                rows[(mode, "check")] = "ok" if torch.equal(full, loop.image()) else "MISMATCH"
-                rows[(mode, "one_gpu_kernel_ms")] = float(np.median(ms1))
+                # ... and the SAME workload on ONE GPU, by the same wall clock as `value` (rank 0 alone, the others wait)
+                solo = ShardedFrameLoop(ds, cam, par, row_block=8, solo=True)
+                el1, _, _ = timed_loop(ds, solo, args.steps, None, False, events=False)
+                _, k1, n1 = timed_loop(ds, solo, max(2, args.steps // 2), None, False, events=True)
+                rows[(mode, "check")] = "ok" if torch.equal(solo.image(), loop[0].image()) else "MISMATCH"
+                rows[(mode, "n1")] = (el1, k1 / max(1, n1))
             fence(dist)
-    except Exception as e:  # noqa: BLE001  (RCCL / driver errors surface as RuntimeError subclasses)
-        err = f"{type(e).__name__}: {e}"[:400]
-    # agree on failure: a rank that raised must not leave the others waiting in a collective for ever (the process
-    # group has a timeout; whoever gets here reports)
+
+        if not agree.run(f"gather check + one-GPU loop {PCG_NAMES[mode]}", check_and_solo):
+            break
+
     if rank == 0:
         def line(mode, gather):
             el, k = rows[(mode, gather)]
+            traced = rays_frame[mode] - resolved_frame[mode]
             return {"value": rays_frame[mode] * args.steps / el / 1e6, "unit": "Mray/s", "ms_per_step": el / args.steps * 1e3,
+                    "traced_Mray_s": traced * args.steps / el / 1e6,
                     "avg_render_kernels_ms_max_over_ranks": k}
+
+        def mode_rows(mode):
+            out = dict(line(mode, True), without_gather=line(mode, False), gather_check=rows.get((mode, "check")),
+                       rays_per_frame=rays_frame[mode],
+                       traced_ray_fraction=1.0 - resolved_frame[mode] / max(1, rays_frame[mode]))
+            if (mode, "dome_off") in rows:
+                el, k = rows[(mode, "dome_off")]
+                out["dome_off"] = {"value": rays_frame[mode] * k / el / 1e6, "unit": "Mray/s", "ms_per_step": el / k * 1e3, "steps": k,
+                                   "note": "same frames, no gather, pt_set_dome_shortcut(0): every primary ray generated and traced"}
+            if (mode, "n1") in rows:
+                el1, k1 = rows[(mode, "n1")]
+                n1 = {"value": rays_frame[mode] * args.steps / el1 / 1e6, "unit": "Mray/s", "ms_per_step": el1 / args.steps * 1e3,
+                      "avg_render_kernels_ms": k1,
+                      "note": "the same C4 frame loop on rank 0 alone (no partition, no gather), same wall clock as `value`"}
+                out["n1_same_workload"] = n1
+                out["speedup"] = out["value"] / n1["value"]
+                out["parallel_efficiency"] = out["speedup"] / world_size
+            return out
+
+        plan = ptdist.gather_plan(H, W, 8, world_size, itemsize=4, transport=ptdist.choose_transport() if agree.error is None else ptdist.P2P)
         result = {
             "metric": "Mray/s (primary+shadow), C4: ONE 3840x2160 frame, 256 spheres, PathTracer depth 5, 64 spp, strong-scaled "
-                      f"over {world_size} MI355X with the RCCL gather of the HdrImage inside the timed region",
+                      f"over {world_size} MI355X with the RCCL gather of the HdrImage inside the timed region "
+                      "(NOT the N=1 line's workload: `python bench.py` measures C2, 1280x720 Flat; the one-GPU figure for THIS "
+                      "workload is n1_same_workload, and speedup / parallel_efficiency are computed against it)",
             "value": None, "unit": "Mray/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": None, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
-            "data": "synthetic",
+            "data": "synthetic", "ranks_seen": seen[0], "backend": backend,
             "config": {"workload": "C4 path tracer 3840x2160, 256 spheres, N=1, D=5, rr=3, S=8 (64 spp), fp32 RGB assembled on rank 0",
                        "width": W, "height": H, "n_shapes": flat.n_shapes, "renderer": "PathTracer",
-                       "pcg_mode": "PT_PCG_SAMPLE (one generator per sample = per lane of the second pass: 'PCG random state per-thread' of the north star; the same frame with one generator per PIXEL is the row pcg_pixel)",
-                       "partition": f"interleaved 8-row blocks over {world_size} ranks, one batched RCCL send/recv group per frame "
-                                    "into row-block order on rank 0, double-buffered behind the next frame's render"},
+                       "pcg_mode": "PT_PCG_SAMPLE (one generator per sample = per lane of the second pass: 'PCG random state per-thread' of the north star; headline since round 2 -- round 1's headline was the PT_PCG_PIXEL frame, now the row pcg_pixel)",
+                       "partition": f"interleaved 8-row blocks over {world_size} ranks; one batched RCCL send/recv group per frame: ONE "
+                                    "transfer per remote rank into a staging buffer on rank 0 + a strided placement copy per rank, "
+                                    "double-buffered behind the next frame's render"},
+            "gather": plan,
+            "value_note": "`value` counts every primary ray of the frame, including those of sky tiles that are resolved without "
+                          "being generated (exact: DESIGN.md 4 items 6/8); traced_Mray_s counts only rays that went through a "
+                          "world query, dome_off is the same loop with the shortcut switched off",
         }
         HEAD, SIDE = abi.PCG_SAMPLE, abi.PCG_PIXEL
-        if err is None and (HEAD, True) in rows:
-            head = line(HEAD, True)
-            result["value"], result["ms_per_step"] = head["value"], head["ms_per_step"]
-            result["avg_render_kernels_ms_max_over_ranks"] = head["avg_render_kernels_ms_max_over_ranks"]
-            result["gather_check"] = rows.get((HEAD, "check"))
-            result["without_gather"] = line(HEAD, False)
-            result["one_gpu_same_frame_kernel_ms"] = rows.get((HEAD, "one_gpu_kernel_ms"))
-            result["rays_per_frame"] = rays_frame[HEAD]
-            if (SIDE, True) in rows:
-                result["pcg_pixel"] = dict(line(SIDE, True), without_gather=line(SIDE, False),
-                                           gather_check=rows.get((SIDE, "check")),
-                                           one_gpu_same_frame_kernel_ms=rows.get((SIDE, "one_gpu_kernel_ms")),
-                                           rays_per_frame=rays_frame[SIDE],
+        if (HEAD, True) in rows and (HEAD, False) in rows:
+            result.update(mode_rows(HEAD))
+            if (SIDE, True) in rows and (SIDE, False) in rows:
+                result["pcg_pixel"] = dict(mode_rows(SIDE),
                                            note="the same frame with one generator per PIXEL (SURVEY.md 8c Mode PIXEL): a pixel's 64 "
                                                 "samples consume ONE stream in order, so the lanes of a pixel speculate on where each "
                                                 "sample starts (DESIGN.md 4 item 10) and a rank's share of the frame is bounded by its "
                                                 "slowest pixel's rounds, not by its share of the work")
-            result["gather_bytes_per_frame"] = W * H * 3 * 4 * (world_size - 1) // world_size
-        else:
-            result["error"] = err or "incomplete"
+        if agree.error is not None:
+            result["error"] = agree.error
         print(json.dumps(result), flush=True)
     ds.close()
-    return 0 if err is None else 1
+    return 0 if agree.error is None else 1
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves
+    (`python -m torch.distributed.run`, one per GPU), relay rank 0's JSON line and exit with the job's status.
+    Runs BEFORE this process touches the GPU (no exec of a process that has initialised HIP)."""
+    import socket
+    import subprocess
+
+    n_dev = torch.cuda.device_count()  # (counting devices does not initialise the GPU)
+    env = dict(os.environ)
+    if n_dev < args.gpus and env.get("PT_DIST_BACKEND", "nccl") == "nccl":
+        print(json.dumps({"metric": "Mray/s", "value": None, "unit": "Mray/s", "n_gpus": args.gpus,
+                          "error": f"--gpus {args.gpus} but {n_dev} GPU(s) visible (PT_DIST_BACKEND=gloo rehearses the "
+                                   "N-rank path on fewer GPUs, ranks sharing a card)"}), flush=True)
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    got_line = False
+    for ln in proc.stdout:
+        if ln.startswith("{") and '"metric"' in ln:
+            got_line = True
+        sys.stdout.write(ln)
+        sys.stdout.flush()
+    rc = proc.wait()
+    if not got_line:
+        print(json.dumps({"metric": "Mray/s", "value": None, "unit": "Mray/s", "n_gpus": args.gpus,
+                          "error": f"the ranks exited with status {rc} without printing a result line"}), flush=True)
+    return rc if rc != 0 or got_line else 1
 
 
 def main():
@@ -493,7 +618,11 @@ def main():
     ap.add_argument("--no-extras", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args, sys.argv[1:])
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world_size and "WORLD_SIZE" in os.environ:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world_size} rank(s)")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.steps is None:
@@ -518,7 +647,7 @@ def main():
                                 device_id=torch.device("cuda", local_rank))
     else:
         dist.init_process_group(backend, rank=rank, world_size=world_size, timeout=timeout)
-    rc = run_multi(args, rank, local_rank, world_size, dist)
+    rc = run_multi(args, rank, local_rank, world_size, dist, backend)
     try:
         if rc == 0:
             dist.barrier()

@@ -212,11 +212,13 @@ class ShardedFrameLoop:
     (compute stream).  ``finish()`` drains both streams."""
 
     def __init__(self, scene, cam: abi.Camera, params: abi.Params, group=None, row_block: int = 8,
-                 device: Optional[torch.device] = None):
+                 device: Optional[torch.device] = None, solo: bool = False):
+        """``solo``: this process renders the WHOLE frame by itself, whatever process group exists (the one-GPU
+        reference loop of the sharded bench)."""
         self.scene, self.cam = scene, cam
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() and not solo else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() and not solo else 0
         self.row_block = row_block
         self.params = abi.copy_params(params, row_block=row_block, n_ranks=self.world, rank=self.rank)
         self.height, self.width = params.height, params.width

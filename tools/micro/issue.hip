@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <map>
 #include <string>
 #include <vector>
@@ -196,6 +197,10 @@ int main(int argc, char **argv) {
   double h[64]; h[0] = 1.0; h[1] = 0.0; for (int i = 2; i < 64; ++i) h[i] = 1.0 + 0.01 * i;
   CHK(hipMemcpy(in, h, sizeof h, hipMemcpyHostToDevice));
   std::vector<int> Ws = {1, 2, 3, 4, 5, 8};
+  if (const char *e = getenv("ISSUE_WS")) {  // e.g. ISSUE_WS=4: one residency only (PMC passes over the same streams)
+    Ws.clear();
+    for (const char *q = e; *q; ++q) if (*q >= '1' && *q <= '8') Ws.push_back(*q - '0');
+  }
   bool first = true;
 #define RUN(OP) if (run_all<OP>(Ws, n_cu, stamps, ids, sink, in, js, first)) return 1;
   RUN(MUL_F64) RUN(ADD_F64) RUN(FMA_F64) RUN(ADD_F32) RUN(MUL_F32) RUN(FMA_F32) RUN(PK_MUL_F32) RUN(PK_FMA_F32) RUN(PK_ADD_F32)
