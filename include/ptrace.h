@@ -139,7 +139,17 @@ typedef struct pt_stats {
                                             (of its last launch when a frame takes several)   */
   uint64_t n_rays_resolved; /* of n_rays: primary rays whose hit was known without tracing them (tiles and
                                pixels that can only see a sphere around the camera) */
+  int32_t kernel;           /* PT_KERNEL_*: which render kernel produced the frame (its last launch)          */
+  int32_t _reserved;
 } pt_stats;
+
+/* pt_stats.kernel */
+#define PT_KERNEL_NONE 0
+#define PT_KERNEL_SIMPLE 1       /* one lane per pixel, every shape (tiny worlds, PTRACE_CULL=0)                  */
+#define PT_KERNEL_TILE 2         /* 8x8 tiles with culled shape lists                                             */
+#define PT_KERNEL_TILE4 3        /* 16x16 tiles, four pixels per lane (OnOff / Flat, pixel-centre rays)           */
+#define PT_KERNEL_PATH 4         /* path tracer, one queue over all pixels                                        */
+#define PT_KERNEL_PATH_REGIONS 5 /* path tracer in two passes: tile classification, then work units over regions */
 
 typedef struct pt_scene pt_scene; /* opaque: device-resident scene + workspace */
 

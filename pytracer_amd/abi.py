@@ -21,6 +21,7 @@ PCG_SEQ, PCG_PIXEL, PCG_SAMPLE = 0, 1, 2
 OUT_F64, OUT_F32 = 0, 1
 
 PT_OK = 0
+KERNEL_NONE, KERNEL_SIMPLE, KERNEL_TILE, KERNEL_TILE4, KERNEL_PATH, KERNEL_PATH_REGIONS = range(6)
 ERROR_NAMES = {
     -1: "PT_ERR_INVALID",
     -2: "PT_ERR_HIP",
@@ -118,6 +119,8 @@ class Stats(C.Structure):
         ("grid", C.c_int32),
         ("block", C.c_int32),
         ("n_rays_resolved", C.c_uint64),
+        ("kernel", C.c_int32),
+        ("_reserved", C.c_int32),
     ]
 
 

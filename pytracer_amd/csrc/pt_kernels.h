@@ -1079,7 +1079,8 @@ PT_DEV void note_flagged(unsigned long long *queue, int k) {
   atomicAdd(queue + 11, (unsigned long long)k);
   atomicAdd(queue + 16 + k, 1ULL);
 }
-PT_DEV void add_ray_count(const PtKArgs &a, unsigned long long n, int base = 0, unsigned long long resolved = 0) {
+PT_DEV void add_ray_count(const PtKArgs &a, unsigned long long n, int base = 0, unsigned long long resolved = 0, int block = -1) {
+  if (block < 0) block = blockIdx.x;  // (a 2-D grid passes its linear workgroup index)
   unsigned long long *counter = cold_args(a)->ray_counter;
   if (counter) {
     __shared__ unsigned long long partial[2 * (PT_BLOCK / 64)];
@@ -1098,8 +1099,8 @@ PT_DEV void add_ray_count(const PtKArgs &a, unsigned long long n, int base = 0, 
         t += partial[w];
         r += partial[PT_BLOCK / 64 + w];
       }
-      counter[2 * (base + blockIdx.x)] = t;
-      counter[2 * (base + blockIdx.x) + 1] = r;
+      counter[2 * (base + block)] = t;
+      counter[2 * (base + block) + 1] = r;
     }
   }
 }
@@ -2242,6 +2243,251 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
   pt_dbg_flush();
 #endif
   add_ray_count(a, nrays, count_base, nres);
+}
+
+// ---- OnOff / Flat, pixel-centre rays (S = 0), perspective camera: 16x16 tiles, FOUR pixels per lane ------------
+// pt_tile_kernel spends more than half of a tile's instructions and most of its dependent latency on what is
+// per TILE, not per pixel (profiles/r03_tile_sections.txt: cone 14 %, cull 21 %, loop bookkeeping and prologue
+// 23 % of a wave's cycles on C2).  Here a wave owns a 16 x 16-pixel tile = four 8 x 8 quadrants, lane l holding
+// pixel (l & 7, l >> 3) of EACH quadrant: one cone, one cull (the survivors stay in SGPR masks: with one sample
+// per pixel nothing is replayed, so no LDS), one walk over the survivors whose scalar-loaded record serves four
+// independent rays per lane (four dependency chains for the fp64 pipe to overlap), no tile loop (a 2 x 2 block of
+// tiles per workgroup, taken from a 2-D grid).  The rays share arithmetic bit for bit: u depends on the column
+// only, v on the row only (imagetracer.py:56-58), and in M*(d, (1-2u)a, 2v-1) the partial sum of the first two
+// terms is the same for the two pixels of a column pair (transformations.py:58-86 adds left to right).
+// Every ray still goes through exactly the reference arithmetic of world_query_tile / hit_details; a larger
+// tile only means a wider cone, i.e. more survivors.  Used when the rows of a tile are consecutive image rows
+// (one rank, or row blocks that are multiples of 16).
+struct Hit4 {
+  double best_t[4];
+  int best[4];
+};
+
+// shapes.py:103-121 for one ray given the object-space ray (PT_SPHERE_ROOTS as a function)
+template <bool ANYHIT>
+PT_DEV void sphere_roots1(const PtKArgs &a, int slot, bool active, double tmin, double ox, double oy, double oz, double dx,
+                          double dy, double dz, double aa, double cc, double &best_t, int &best) {
+  const double tmax = INFINITY;
+  PT_SPHERE_ROOTS(slot);
+}
+
+template <int RENDERER>
+__global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))) void pt_tile4_kernel(const PtKArgs a) {
+  constexpr bool ANYHIT = RENDERER == PT_RENDERER_ONOFF;
+  int W, rows_local, npass;
+  bool dome_on;
+  {
+    pt_kargs c = cold_args(a);
+    W = c->W;
+    rows_local = c->rows_local;
+    npass = c->npass;
+    dome_on = c->dome_shortcut != 0;
+  }
+  const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+  const int tx = blockIdx.x * 2 + (wib & 1), ty = blockIdx.y * 2 + (wib >> 1);
+  unsigned long long nrays = 0, nres = 0;
+  const bool valid = tx * 16 < W && ty * 16 < rows_local;  // (wave-uniform; the ray count below needs every wave)
+  if (valid) {
+    // ---- cone + cull of the 16 x 16 tile ----
+    const int lr0 = ty * 16, lr1 = (lr0 + 15 < rows_local) ? lr0 + 15 : rows_local - 1;
+    const int gr0 = global_row(a, lr0);  // the tile's rows are consecutive image rows (host: n_ranks == 1 or row_block % 16 == 0)
+    const float4 b_first = a.bounds[lane < a.n_shapes ? lane : 0];
+    const TileCone tc = tile_cone(a, tx * 16, (tx * 16 + 16 < W) ? tx * 16 + 16 : W, gr0, gr0 + (lr1 - lr0));
+    unsigned long long masks[4] = {0ULL, 0ULL, 0ULL, 0ULL};  // (npass <= 4: the host sends larger worlds elsewhere)
+    int nsurv = 0, only = 0;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      if (p < npass) {
+        const int slot = p * 64 + lane;
+        bool keep = false;
+        float4 b = {0.0f, 0.0f, 0.0f, -1.0f};
+        if (slot < a.n_shapes) b = p == 0 ? b_first : a.bounds[slot];
+        const bool isplane = slot >= a.n_spheres && slot < a.n_shapes;
+        if (slot < a.n_spheres) keep = cone_keeps(tc, b);
+        if (__any(isplane)) {
+          const bool pk = plane_keeps(tc, b, isplane);
+          if (isplane) keep = pk;
+        }
+        const unsigned long long m = __ballot(keep);
+        masks[p] = m;
+        nsurv += __popcll(m);
+        if (m) only = p * 64 + (__ffsll((long long)m) - 1);
+      }
+    }
+    // pixel k of this lane: quadrant (k & 1, k >> 1)
+    const int colA = tx * 16 + (lane & 7), colB = colA + 8;
+    const int lrowA = lr0 + (lane >> 3), lrowB = lrowA + 8;
+    const bool okcA = colA < W, okcB = colB < W, okrA = lrowA < rows_local, okrB = lrowB < rows_local;
+    const bool act[4] = {okcA && okrA, okcB && okrA, okcA && okrB, okcB && okrB};
+    const int ccA = okcA ? colA : W - 1, ccB = okcB ? colB : W - 1;  // idle lanes stand on a real pixel
+    const int crA = okrA ? lrowA : rows_local - 1, crB = okrB ? lrowB : rows_local - 1;
+    const long long pix[4] = {(long long)crA * W + ccA, (long long)crA * W + ccB, (long long)crB * W + ccA, (long long)crB * W + ccB};
+    bool done = false;
+    // ---- the dome shortcut (see pt_tile_kernel): one survivor, the camera well inside it, uniform pigments ----
+    if (dome_on && nsurv == 1 && only < a.n_spheres) {
+      only = __builtin_amdgcn_readfirstlane(only);
+      pt_kargs ca = cold_args(a);
+      const PtShapeAux *ax = ca->aux + only;
+      const float fro2 = (float)PT_KD(&a.recs[only])[13];  // PtShapeRec::fro2
+      const double hc = (only < a.n_diag) ? PT_KD(&a.hoist_diag[only])[6] : PT_KD(&a.hoist[only])[3];
+      if (ax->needs_uv == 0 && hc < -0.5 && fro2 * tc.dmax2 < 1e6f && tc.dmin > 1e-6f && !tc.all) {
+        V3 c;
+        if (RENDERER == PT_RENDERER_ONOFF) {
+          c.x = ca->onoff[0];
+          c.y = ca->onoff[1];
+          c.z = ca->onoff[2];
+        } else {
+          const V3 p1 = brdf_pigment(a, ax, 0.0, 0.0), p2 = emitted_pigment(a, ax, 0.0, 0.0);
+          c.x = p1.x + p2.x;
+          c.y = p1.y + p2.y;
+          c.z = p1.z + p2.z;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (act[k]) {
+            store_pixel(a, pix[k], c);
+            nrays += 1ULL;
+            nres += 1ULL;
+          }
+        done = true;
+      }
+    }
+    if (!done) {
+      // ---- the four primary rays (imagetracer.py:48-58, camera.py:103-124) ----
+      V3 org, dir[4];
+      double bgx, bgy, bgz;
+      {
+        pt_kargs c = cold_args(a);
+        const double dist = c->cam_dist, aspect = c->cam_aspect;
+        const double Wd = (double)c->W, Hd = (double)c->H;
+        const int growA = gr0 + (crA - lr0), growB = gr0 + (crB - lr0);
+        const double uA = ((double)ccA + 0.5) / Wd, uB = ((double)ccB + 0.5) / Wd;
+        const double vA = 1.0 - ((double)growA + 0.5) / Hd, vB = 1.0 - ((double)growB + 0.5) / Hd;
+        const double dyA = (1.0 - 2.0 * uA) * aspect, dyB = (1.0 - 2.0 * uB) * aspect;
+        const double dzA = 2.0 * vA - 1.0, dzB = 2.0 * vB - 1.0;
+        const double m0 = c->cam_m[0], m1 = c->cam_m[1], m2 = c->cam_m[2], m3 = c->cam_m[3];
+        const double m4 = c->cam_m[4], m5 = c->cam_m[5], m6 = c->cam_m[6], m7 = c->cam_m[7];
+        const double m8 = c->cam_m[8], m9 = c->cam_m[9], m10 = c->cam_m[10], m11 = c->cam_m[11];
+        // xf_vec: (d.x*m[0] + d.y*m[1]) + d.z*m[2] -- the bracket depends on the column only
+        const double xA = dist * m0 + dyA * m1, xB = dist * m0 + dyB * m1;
+        const double yA = dist * m4 + dyA * m5, yB = dist * m4 + dyB * m5;
+        const double zA = dist * m8 + dyA * m9, zB = dist * m8 + dyB * m9;
+        dir[0] = {xA + dzA * m2, yA + dzA * m6, zA + dzA * m10};
+        dir[1] = {xB + dzA * m2, yB + dzA * m6, zB + dzA * m10};
+        dir[2] = {xA + dzB * m2, yA + dzB * m6, zA + dzB * m10};
+        dir[3] = {xB + dzB * m2, yB + dzB * m6, zB + dzB * m10};
+        // xf_point of (-dist, 0, 0): ((o.x*m[0] + 0*m[1]) + 0*m[2]) + m[3], exactly as primary_ray evaluates it
+        const double ox_ = -dist, oy_ = 0.0, oz_ = 0.0;
+        org.x = ox_ * m0 + oy_ * m1 + oz_ * m2 + m3;
+        org.y = ox_ * m4 + oy_ * m5 + oz_ * m6 + m7;
+        org.z = ox_ * m8 + oy_ * m9 + oz_ * m10 + m11;
+        bgx = c->bg[0];
+        bgy = c->bg[1];
+        bgz = c->bg[2];
+      }
+      // ---- World.ray_intersection over the survivors, four rays per visit ----
+      const double tmin = 1.0e-5;
+      Hit4 h4;
+      bool fast = true;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        h4.best_t[k] = INFINITY;
+        h4.best[k] = -1;
+        Ray rk;
+        rk.o = org;
+        rk.d = dir[k];
+        rk.tmin = tmin;
+        fast = fast && wave_guard<true>(rk, act[k]).fast;
+      }
+      const int nd = a.n_diag, ns = a.n_spheres;
+      bool all_hit = false;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        unsigned long long mask = masks[p];
+        while (mask && !all_hit) {
+          const int slot = p * 64 + (__ffsll((long long)mask) - 1);
+          mask &= mask - 1;
+          if (slot < ns) {
+            if (slot < nd && fast) {
+              pt_kdouble h = PT_KD(&a.hoist_diag[slot]);
+              const double s0 = h[0], s1 = h[1], s2 = h[2], ox = h[3], oy = h[4], oz = h[5], cc = h[6];
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                const double dx = dir[k].x * s0, dy = dir[k].y * s1, dz = dir[k].z * s2;
+                const double aa = dx * dx + dy * dy + dz * dz;
+                sphere_roots1<ANYHIT>(a, slot, act[k], tmin, ox, oy, oz, dx, dy, dz, aa, cc, h4.best_t[k], h4.best[k]);
+              }
+            } else {
+              pt_kdouble m = PT_KD(a.recs[slot].invm);
+              pt_kdouble h = PT_KD(&a.hoist[slot]);
+              const double ox = h[0], oy = h[1], oz = h[2], cc = h[3];
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                const double dx = dir[k].x * m[0] + dir[k].y * m[1] + dir[k].z * m[2];
+                const double dy = dir[k].x * m[4] + dir[k].y * m[5] + dir[k].z * m[6];
+                const double dz = dir[k].x * m[8] + dir[k].y * m[9] + dir[k].z * m[10];
+                const double aa = dx * dx + dy * dy + dz * dz;
+                sphere_roots1<ANYHIT>(a, slot, act[k], tmin, ox, oy, oz, dx, dy, dz, aa, cc, h4.best_t[k], h4.best[k]);
+              }
+            }
+          } else {
+            pt_kdouble m = PT_KD(a.recs[slot].invm);
+            const double oz = PT_KD(&a.hoist[slot])[2];
+            const double tmax = INFINITY;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const double dz = dir[k].x * m[8] + dir[k].y * m[9] + dir[k].z * m[10];
+              const bool active = act[k];
+              double &best_t = h4.best_t[k];
+              int &best = h4.best[k];
+              PT_PLANE_HIT(slot);
+            }
+          }
+          if (ANYHIT) {  // OnOff: leave as soon as every active pixel has some hit (render.py:52-53 asks no more)
+            const bool open = (act[0] && h4.best[0] < 0) || (act[1] && h4.best[1] < 0) || (act[2] && h4.best[2] < 0) ||
+                              (act[3] && h4.best[3] < 0);
+            all_hit = __ballot(open) == 0ULL;
+          }
+        }
+      }
+      // ---- shade + store ----
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        V3 c = {bgx, bgy, bgz};
+        const int hit = h4.best[k];
+        if (RENDERER == PT_RENDERER_ONOFF) {  // render.py:52-53
+          if (hit >= 0) {
+            pt_kargs ca = cold_args(a);
+            c.x = ca->onoff[0];
+            c.y = ca->onoff[1];
+            c.z = ca->onoff[2];
+          }
+        } else if (hit >= 0) {  // render.py:65-74
+          const PtShapeAux *ax = cold_args(a)->aux + hit;
+          Hit h;
+          h.u = 0.0;
+          h.v = 0.0;
+          if (ax->needs_uv) {
+            Ray rk;
+            rk.o = org;
+            rk.d = dir[k];
+            rk.tmin = tmin;
+            hit_details(a.recs + hit, ax, rk, h4.best_t[k], h, true);
+          }
+          const V3 p1 = brdf_pigment(a, ax, h.u, h.v);
+          const V3 p2 = emitted_pigment(a, ax, h.u, h.v);
+          c.x = p1.x + p2.x;
+          c.y = p1.y + p2.y;
+          c.z = p1.z + p2.z;
+        }
+        if (act[k]) {
+          store_pixel(a, pix[k], c);
+          nrays += 1ULL;
+        }
+      }
+    }
+  }
+  add_ray_count(a, nrays, 0, nres, blockIdx.y * gridDim.x + blockIdx.x);
 }
 
 // ---- work units for the path tracer's second pass ---------------------------------------------------------

@@ -942,6 +942,17 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
     const long long wave_tiles = (long long)((p->width + 7) / 8) * ((rows + 7) / 8);
     grid = (int)std::max<long long>(1, std::min<long long>((wave_tiles + 3) / 4, tcap));
   }
+  // OnOff / Flat with pixel-centre rays of a perspective camera in worlds of at most 256 shapes: 16x16 tiles, four
+  // pixels per lane (pt_tile4_kernel), a 2x2 block of tiles per workgroup of a 2-D grid
+  static const int env_tile4 = getenv("PTRACE_TILE4") ? atoi(getenv("PTRACE_TILE4")) : 1;
+  const bool tile4 = tile && env_tile4 != 0 && !ortho && p->samples_per_side == 0 && s->n_shapes <= 256 &&
+                     (p->renderer == PT_RENDERER_ONOFF || p->renderer == PT_RENDERER_FLAT) &&
+                     (a.n_ranks == 1 || a.row_block % 16 == 0);
+  dim3 grid4(1, 1, 1);
+  if (tile4) {
+    grid4 = dim3((unsigned)(((p->width + 15) / 16 + 1) / 2), (unsigned)(((rows + 15) / 16 + 1) / 2), 1);
+    grid = (int)(grid4.x * grid4.y);
+  }
   int grid_first = 0;  // path tracer, first pass (pt_tile_kernel<PATHTRACER>): one wave per 8x8 region
   if (path_tiled) {
     const long long regions = (long long)((p->width + PT_REGION - 1) / PT_REGION) * ((rows + PT_REGION - 1) / PT_REGION);
@@ -952,6 +963,7 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
   s->stats.grid = grid;
   s->stats.block = PT_BLOCK;
   s->stats.lds_bytes = 0;
+  s->stats.kernel = PT_KERNEL_NONE;
 
   if (s->count_rays) {
     if (grid + grid_first > s->ray_partials_n) {
@@ -1132,7 +1144,14 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
   const hipEvent_t ev_a = s->timing ? (prof ? s->prof[2 * s->prof_used] : s->ev0) : nullptr;
   const hipEvent_t ev_b = s->timing ? (prof ? s->prof[2 * s->prof_used + 1] : s->ev1) : nullptr;
   bool ev_started = false;
-  if (tile || path_tiled) {
+  if (tile4) {
+    s->stats.kernel = PT_KERNEL_TILE4;
+    main_fn = p->renderer == PT_RENDERER_ONOFF ? (const void *)pt_tile4_kernel<PT_RENDERER_ONOFF> : (const void *)pt_tile4_kernel<PT_RENDERER_FLAT>;
+    if (p->renderer == PT_RENDERER_ONOFF)
+      hipExtLaunchKernelGGL((pt_tile4_kernel<PT_RENDERER_ONOFF>), grid4, dim3(PT_BLOCK), 0, st, ev_a, ev_b, 0, a);
+    else
+      hipExtLaunchKernelGGL((pt_tile4_kernel<PT_RENDERER_FLAT>), grid4, dim3(PT_BLOCK), 0, st, ev_a, ev_b, 0, a);
+  } else if (tile || path_tiled) {
 #ifdef PT_DEBUG_TIME
     if (p->renderer != PT_RENDERER_PATHTRACER) {
       s->queue_last = s->queue;  // (a.qpar = 0)
@@ -1142,6 +1161,7 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
 #endif
     const size_t lds = (size_t)4 * a.npass * sizeof(unsigned long long);
     s->stats.lds_bytes = (int)lds;
+    s->stats.kernel = path_tiled ? PT_KERNEL_PATH_REGIONS : PT_KERNEL_TILE;
     const int tgrid = path_tiled ? grid_first : grid;
     if (hier) {
       // enough (cell group, shape chunk) pairs to fill the chip; a chunk is a multiple of the block
@@ -1200,7 +1220,8 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
         PT_LAUNCH((pt_path_regions_kernel<false>), grid, lds + diag_lds_bytes, true, a);
       }
     }
-  } else
+  } else {
+  s->stats.kernel = p->renderer == PT_RENDERER_PATHTRACER ? PT_KERNEL_PATH : PT_KERNEL_SIMPLE;
   switch (p->renderer) {
     case PT_RENDERER_ONOFF:
       if (hoist)
@@ -1228,6 +1249,7 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
         PT_LAUNCH((pt_path_kernel<false>), grid, 0, true, a);
       }
       break;
+  }
   }
   HIP_TRY(hipGetLastError());
   if (p->renderer == PT_RENDERER_PATHTRACER) {  // its path kernel is enqueued: the other queue block will be zero

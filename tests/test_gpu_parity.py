@@ -229,16 +229,19 @@ def test_tile_culling_is_invisible(dev, oracle, n, spread, rotated, W, H, S, ren
     oracle.set_sqr_mode(oracle.SQR_POW)
     with dev.DeviceScene(scene) as ds:
         out = ds.render(cam, par)
-        assert ds.stats().lds_bytes > 0, "expected the tile kernel"
+        assert ds.stats().kernel in (abi.KERNEL_TILE, abi.KERNEL_TILE4), "expected a tile kernel"
         assert util.bits_equal(out, ora), f"max rel {util.rel_err(out, ora).max()}"
         assert ds.stats().n_rays == n_rays
-        # and under an awkward row partition (blocks of 7 rows over 3 ranks), and the usual one
-        for rb in (7, 8):
+        # and under an awkward row partition (blocks of 7 rows over 3 ranks), the usual one, and 16- / 32-row blocks
+        # (where pixel-centre OnOff / Flat frames keep the 16x16-tile kernel: a tile's rows are consecutive image rows)
+        for rb in (7, 8, 16, 32):
             got = np.zeros_like(out)
             for rank in range(3):
                 p = abi.copy_params(par, n_ranks=3, rank=rank, row_block=rb)
                 got[abi.rows_for_rank(H, rb, 3, rank)] = ds.render(cam, p)
-            assert util.bits_equal(got, ora)
+                if S == 0 and n <= 254 and renderer in (abi.RENDERER_FLAT, abi.RENDERER_ONOFF):
+                    assert ds.stats().kernel == (abi.KERNEL_TILE4 if rb % 16 == 0 else abi.KERNEL_TILE), (rb, ds.stats().kernel)
+            assert util.bits_equal(got, ora), rb
 
 
 @pytest.mark.parametrize("n,renderer,S", [(120, abi.RENDERER_FLAT, 0), (300, abi.RENDERER_ONOFF, 2),
@@ -263,7 +266,7 @@ def test_orthogonal_camera_beam_culling_is_invisible(dev, oracle, n, renderer, S
     oracle.set_sqr_mode(oracle.SQR_POW)
     with dev.DeviceScene(scene) as ds:
         out = ds.render(cam, par)
-        assert ds.stats().lds_bytes > 0, "expected the tile kernel"
+        assert ds.stats().kernel in (abi.KERNEL_TILE, abi.KERNEL_TILE4), "expected a tile kernel"
         assert util.bits_equal(out, ora), f"max rel {util.rel_err(out, ora).max()}"
         assert ds.stats().n_rays == n_rays
         got = np.zeros_like(out)
@@ -296,7 +299,7 @@ for camera in (hm.PerspectiveCamera(1.0, W / H, hm.translation(hm.Vec(-1.0, 0.0,
             par = abi.make_params(W, H, renderer, samples_per_side=S)
             ora, n_rays = oracle.render(scene, cam, par, sqr_mode=oracle.SQR_MUL)
             out = ds.render(cam, par)
-            assert ds.stats().lds_bytes == 0, "culling should be off"
+            assert ds.stats().kernel == abi.KERNEL_SIMPLE, "culling should be off"
             assert util.bits_equal(out, ora), (renderer, S)
             assert ds.stats().n_rays == n_rays
         par = abi.make_params(W, H, abi.RENDERER_PATHTRACER, samples_per_side=2, num_of_rays=2, max_depth=3, rr_limit=2,
@@ -371,7 +374,7 @@ def test_dome_shortcut_and_plane_culling_are_invisible(dev, oracle, case):
             for c in (cam, cam_o):  # (the orthogonal view: the dome test looks at the four corner origins)
                 ora, n_rays = oracle.render(scene, c, par, sqr_mode=oracle.SQR_MUL)
                 out = ds.render(c, par)
-                assert ds.stats().lds_bytes > 0, "expected the tile kernel"
+                assert ds.stats().kernel in (abi.KERNEL_TILE, abi.KERNEL_TILE4), "expected a tile kernel"
                 assert util.bits_equal(out, ora), f"{case} renderer {renderer} S={S}: max rel {util.rel_err(out, ora).max()}"
                 assert ds.stats().n_rays == n_rays
         if case != "checkered":  # (sin/cos/atan2 of the device differ from libm in the last bit: not bit-exact)

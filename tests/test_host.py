@@ -124,7 +124,7 @@ def test_struct_sizes_match_header():
     # catches ctypes/ABI drift: sizes computed from the C declarations
     assert C.sizeof(abi.Camera) == 4 + 4 + 12 * 8 + 16
     assert C.sizeof(abi.Params) == 4 * 4 + 9 * 8 + 4 * 4 + 4 * 8 + 4 * 4
-    assert C.sizeof(abi.Stats) == 2 * 8 + 2 * 8 + 4 * 4 + 8
+    assert C.sizeof(abi.Stats) == 2 * 8 + 2 * 8 + 4 * 4 + 8 + 2 * 4
     assert C.sizeof(abi.SceneDesc) == 25 * 8
 
 
