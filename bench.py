@@ -45,7 +45,39 @@ PEAK_FP64_VECTOR_TFLOPS = 78.6  # MI355X vector fp64, vendor figure: an FMA coun
 PEAK_HBM_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FLOP_PER_SPHERE_TEST = 54       # 33 transform + 5 a + 6 b + 6 c + 4 delta
 FLOP_PER_PLANE_TEST = 36
-VALU_CYCLES_PER_WAVE_INSTR = 4  # one wave64 fp64-rate VALU instruction holds its SIMD for 4 cycles
+# SIMD-cycles one wave64 instruction costs its SIMD, MEASURED on this part with every CU busy and 2-8 waves per SIMD
+# (tools/micro/issue.hip -> profiles/r03_issue_rates.{txt,json}; the loop overhead of the benchmark, ~5 %, removed):
+# fp64 add/mul/fma 4; fp32 and 32-bit integer add/mul/fma/logic/move 2 (4 for ONE wave alone on a SIMD); packed fp32,
+# 64-bit integer, 32-bit integer multiply, conversions to/from fp64, compares into an SGPR pair, selects on an SGPR
+# mask, lane reads 4; fp32 transcendentals 8; fp64 rcp/rsq/sqrt 16.  SALU: 4 per SIMD, issued beside the VALU.
+# rocprofv3 counts VALU instructions by class (SQ_INSTS_VALU_*); what no class counter covers ("other": moves,
+# compares, selects, lane reads, bit operations) is priced at 3, between the 2 of a move and the 4 of a compare,
+# and the fractions under 2 and under 4 are printed beside it.
+VALU_ISSUE_CYCLES = {"SQ_INSTS_VALU_ADD_F64": 4, "SQ_INSTS_VALU_MUL_F64": 4, "SQ_INSTS_VALU_FMA_F64": 4, "SQ_INSTS_VALU_TRANS_F64": 16,
+                     "SQ_INSTS_VALU_ADD_F32": 2, "SQ_INSTS_VALU_MUL_F32": 2, "SQ_INSTS_VALU_FMA_F32": 2, "SQ_INSTS_VALU_TRANS_F32": 8,
+                     "SQ_INSTS_VALU_CVT": 4, "SQ_INSTS_VALU_INT32": 2, "SQ_INSTS_VALU_INT64": 4}
+VALU_OTHER_CYCLES = (2, 3, 4)   # (low, priced, high) for instructions outside the class counters
+SALU_ISSUE_CYCLES = 4
+FP64_CLASSES = ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64")
+
+
+def priced_issue(counters, simd_cycles):
+    """VALU / fp64-pipe / SALU issue utilisation of a launch from its per-class instruction counts.
+    -> dict, or None when the class counters are missing."""
+    valu = counters.get("SQ_INSTS_VALU")
+    if not valu or any(k not in counters for k in VALU_ISSUE_CYCLES):
+        return None
+    classed = sum(counters[k] for k in VALU_ISSUE_CYCLES)
+    other = max(0.0, valu - classed)
+    base = sum(counters[k] * c for k, c in VALU_ISSUE_CYCLES.items())
+    lo, mid, hi = (base + other * c for c in VALU_OTHER_CYCLES)
+    f64 = sum(counters[k] * VALU_ISSUE_CYCLES[k] for k in FP64_CLASSES)
+    return {"valu_issue_cycles": mid, "frac": mid / simd_cycles, "frac_other_at_2": lo / simd_cycles, "frac_other_at_4": hi / simd_cycles,
+            "fp64_pipe_frac": f64 / simd_cycles,
+            "salu_issue_frac": counters.get("SQ_INSTS_SALU", 0.0) * SALU_ISSUE_CYCLES / simd_cycles,
+            "mean_cycles_per_valu_instruction": mid / valu,
+            "instructions_by_class": {**{k.replace("SQ_INSTS_VALU_", "").lower(): counters[k] for k in VALU_ISSUE_CYCLES}, "other": other},
+            "fp64_instruction_share": sum(counters[k] for k in FP64_CLASSES) / valu}
 
 C4 = dict(n_spheres=256, wide=True, W=3840, H=2160,
           kw=dict(renderer=abi.RENDERER_PATHTRACER, samples_per_side=8, num_of_rays=1, max_depth=5, rr_limit=3,
@@ -180,9 +212,13 @@ def extra_rows(device: int):
         pmc = load_profile(fname)
         if pmc is not None and tag in rows:
             valu, dur = pmc["counters"]["SQ_INSTS_VALU"], pmc["dur_us"] * 1e-6
+            simd_cycles = n_cu * 4 * dur * clock_khz * 1e3
+            pr = priced_issue(pmc["counters"], simd_cycles)
             rows[tag]["second_pass_executed"] = {
                 "kernel": "pt_path_regions_kernel", "valu_wave_instructions_per_launch": valu, "kernel_us_under_pmc_collection": pmc["dur_us"],
-                "valu_issue_utilisation": valu * VALU_CYCLES_PER_WAVE_INSTR / (n_cu * 4 * dur * clock_khz * 1e3), "source": pmc.get("source")}
+                "valu_issue_utilisation_if_every_instruction_took_4_cycles": valu * 4 / simd_cycles,
+                "valu_issue_utilisation": pr["frac"] if pr else None, "fp64_pipe_frac": pr["fp64_pipe_frac"] if pr else None,
+                "source": pmc.get("source")}
     # C5: HBM bytes per frame of its two kernels (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 passes, medians
     # committed under profiles/) over the kernel time measured here
     c5 = rows.get("C5_flat_1280x720_10k_spheres")
@@ -269,7 +305,7 @@ def fence(dist):
 def timed_loop(ds, loop, steps, dist, gather, events=True):
     """K frames between two fences; -> (wall s, summed kernel ms, launches).  With `events` every launch is timed by
     an event pair carried in its own dispatch (they cost a few microseconds of pipelining per launch, so the
-    headline loop runs without them and a second, identical loop supplies the kernel's average duration)."""
+    headline loop runs without them and a second, identical loop supplies the per-launch figure)."""
     ds.set_count_rays(False)
     ds.set_timing(events)
     loop.step(0, gather=gather)  # one uncounted frame so the timed region starts from the steady state
@@ -284,6 +320,24 @@ def timed_loop(ds, loop, steps, dist, gather, events=True):
     kernel_total_ms, launches = ds.profile_end() if events else (0.0, 0)
     ds.set_timing(True)
     return elapsed, kernel_total_ms, launches
+
+
+def bracketed_loop(ds, loop, steps):
+    """The K launches of the timed region between ONE pair of HIP events recorded on the stream the kernels are
+    launched on (no host synchronisation, no per-launch events in between): -> average duration of a launch in
+    seconds = what rocprofv3's kernel trace shows for the same kernel run back to back."""
+    ds.set_count_rays(False)
+    ds.set_timing(False)
+    loop.step(0, gather=False)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(loop.stream)
+    for i in range(steps):
+        loop.step(i, gather=False)
+    e1.record(loop.stream)
+    e1.synchronize()
+    ds.set_timing(True)
+    return e0.elapsed_time(e1) * 1e-3 / steps
 
 
 def run_single(args, local_rank):
@@ -306,8 +360,9 @@ def run_single(args, local_rank):
     rays_per_step, resolved = int(st.n_rays), int(st.n_rays_resolved)
     n_wg = st.grid
     elapsed, _, _ = timed_loop(ds, loop, args.steps, None, False, events=False)  # the headline: K frames back to back
-    elapsed_ev, kernel_total_ms, launches = timed_loop(ds, loop, args.steps, None, False, events=True)  # the same, all K timed
-    avg_kernel_s = kernel_total_ms / max(launches, 1) * 1e-3
+    elapsed_ev, kernel_total_ms, launches = timed_loop(ds, loop, args.steps, None, False, events=True)  # the same, every launch with its own event pair
+    per_launch_pair_s = kernel_total_ms / max(launches, 1) * 1e-3
+    avg_kernel_s = bracketed_loop(ds, loop, args.steps)  # the same K launches between one event pair on their stream
     ms_per_step = elapsed / args.steps * 1e3
 
     # the same frames with the dome shortcut off: every primary ray generated and traced
@@ -327,38 +382,49 @@ def run_single(args, local_rank):
     n_pl = int((flat.kind == abi.SHAPE_PLANE).sum())
     flops = rays_per_step * (n_sph * FLOP_PER_SPHERE_TEST + n_pl * FLOP_PER_PLANE_TEST)
     alg_bytes = rays_per_step * 12 + n_wg * flat.n_shapes * 104
-    peak_lane_ops = n_simd * 16 * clock_hz / 1e12  # fp64-rate VALU: 16 lanes per SIMD per cycle, no FMA on the parity path
     pmc = load_profile("pmc_c2.json")
     roofline = {
-        "bound": "valu_fp64_issue",
-        "achieved": None, "peak": peak_lane_ops, "unit": "TFLOP/s", "frac": None, "traffic": None,
-        "kernel": "pt_tile_kernel<FLAT> (8x8 tiles, culled shape lists, hoisted scale+translate tests)",
-        "avg_kernel_ms": avg_kernel_s * 1e3, "launches_timed": launches,
-        "ms_per_step_of_the_timed_launch_loop": elapsed_ev / args.steps * 1e3,
-        "note": "no dense contraction: MFMA unused; the path is bound by fp64 VALU issue/latency, not HBM (SURVEY.md 8d). "
-                "`achieved` = EXECUTED VALU lane-operations per second: wave-level VALU instructions per launch (rocprofv3 PMC "
-                "SQ_INSTS_VALU, profiles/pmc_c2.json) x 64 lanes / the kernel's average duration measured here over every "
-                "timed launch; `peak` = SIMDs x 16 lanes x clock (one fp64-rate VALU instruction holds a SIMD 4 cycles; "
-                "the parity kernels may not fuse a*b+c, so this, half the vendor's FMA figure, is their ceiling); "
-                "`frac` = achieved/peak = VALU issue utilisation.",
+        "bound": "valu_issue",
+        "achieved": None, "peak": None, "unit": "TFLOP/s", "frac": None, "traffic": None,
+        "kernel": "pt_tile4_kernel<FLAT> (16x16 tiles, four pixels per lane, culled shape lists, hoisted scale+translate tests)",
+        "avg_kernel_ms": avg_kernel_s * 1e3, "launches_timed": args.steps,
+        "avg_kernel_ms_method": "K launches back to back between one HIP event pair recorded on their stream / K (rocprofv3's "
+                                "kernel trace of the same command shows the same average for launches run back to back)",
+        "per_launch_event_pair_ms": per_launch_pair_s * 1e3,
+        "per_launch_event_pair_note": "every launch with its own event pair in the dispatch: includes the events' own pipeline "
+                                      "bubble (a few us per launch; rocprofv3 sees the kernels of this loop no longer than the others)",
+        "ms_per_step_of_the_per_launch_event_loop": elapsed_ev / args.steps * 1e3,
+        "note": "no dense contraction: MFMA unused; the path is bound by vector issue and dependent latency, not HBM (SURVEY.md 8d). "
+                "`frac` = VALU issue utilisation = sum over instruction classes of (wave-instructions per launch, rocprofv3 PMC "
+                "SQ_INSTS_VALU_*, profiles/pmc_c2.json) x (SIMD-cycles per instruction of that class, MEASURED by "
+                "tools/micro/issue.hip, profiles/r03_issue_rates.txt: fp64 4, fp32/int32 2, fp64 transcendental 16, ...; "
+                "instructions no class counter covers priced at 3, see frac_other_at_2 / _at_4) / (SIMDs x clock x the kernel's "
+                "average duration measured here over every timed launch).  `achieved` = executed VALU lane-operations per "
+                "second; `peak` = achieved / frac = the rate at which this instruction mix would issue with no SIMD ever idle.  "
+                "fp64_pipe_frac counts the fp64 instructions alone (x 4, transcendentals x 16); salu_issue_frac the scalar "
+                "instructions (x 4 per SIMD, issued beside the VALU).",
     }
-    if avg_kernel_s * 1e3 > ms_per_step * 1.02:
+    if avg_kernel_s * 1e3 > ms_per_step * 1.05:
         roofline["avg_kernel_ms"] = None
         roofline["note"] += " (kernel time discarded: it exceeded the step time)"
     elif pmc is not None:
         valu = pmc["counters"]["SQ_INSTS_VALU"]
+        simd_cycles = n_simd * avg_kernel_s * clock_hz
         ach = valu * 64 / avg_kernel_s / 1e12
-        f64 = sum(pmc["counters"].get(k, 0.0) for k in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64",
-                                                         "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64"))
-        roofline.update({
-            "achieved": ach, "frac": valu * VALU_CYCLES_PER_WAVE_INSTR / (n_simd * avg_kernel_s * clock_hz),
-            "traffic": pmc.get("hbm_bytes_per_launch"),
-            "executed": {"valu_wave_instructions_per_launch": valu,
-                         "salu_wave_instructions_per_launch": pmc["counters"].get("SQ_INSTS_SALU"),
-                         "fp64_instruction_share": (f64 / valu) if f64 else None,
-                         "kernel_us_under_pmc_collection": pmc.get("dur_us"), "simds": n_simd, "clock_GHz": clock_hz / 1e9,
-                         "source": pmc.get("source")},
-        })
+        pr = priced_issue(pmc["counters"], simd_cycles)
+        roofline["traffic"] = pmc.get("hbm_bytes_per_launch")
+        roofline["achieved"] = ach
+        roofline["executed"] = {"valu_wave_instructions_per_launch": valu,
+                                "salu_wave_instructions_per_launch": pmc["counters"].get("SQ_INSTS_SALU"),
+                                "kernel_us_under_pmc_collection": pmc.get("dur_us"), "simds": n_simd, "clock_GHz": clock_hz / 1e9,
+                                "kernel_profiled": pmc.get("kernel"), "source": pmc.get("source")}
+        if pr is not None:
+            roofline["frac"] = pr["frac"]
+            roofline["peak"] = ach / pr["frac"]
+            roofline.update({k: pr[k] for k in ("frac_other_at_2", "frac_other_at_4", "fp64_pipe_frac", "salu_issue_frac")})
+            roofline["executed"].update({k: pr[k] for k in ("mean_cycles_per_valu_instruction", "instructions_by_class", "fp64_instruction_share")})
+        else:
+            roofline["note"] += " (profiles/pmc_c2.json lacks the per-class counters: frac not priced)"
     roofline["algorithmic_equivalent"] = {
         "flop_per_launch": flops, "TFLOP_s": flops / avg_kernel_s / 1e12,
         "note": "SURVEY.md 8(d) recipe: 54 flop per ray-sphere and 36 per ray-plane test, every ray x every shape, / kernel "
@@ -389,7 +455,7 @@ def run_single(args, local_rank):
         "traced_ray_note": "rays of tiles whose only possible hit is the sphere around the camera are resolved without being "
                            "generated (exact, DESIGN.md 4 item 8) and counted in `value`; this is the share that was traced",
         "dome_off": {"value": rays_per_step * n_dome_off / el_off / 1e6, "unit": "Mray/s",
-                     "ms_per_step": el_off / n_dome_off * 1e3, "avg_kernel_ms": k_off / max(1, n_off), "steps": n_dome_off,
+                     "ms_per_step": el_off / n_dome_off * 1e3, "per_launch_event_pair_ms": k_off / max(1, n_off), "steps": n_dome_off,
                      "note": "same frames with the shortcut switched off (pt_set_dome_shortcut(0)): every primary ray traced"},
         "roofline": roofline,
     }

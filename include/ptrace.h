@@ -150,6 +150,7 @@ typedef struct pt_stats {
 #define PT_KERNEL_TILE4 3        /* 16x16 tiles, four pixels per lane (OnOff / Flat, pixel-centre rays)           */
 #define PT_KERNEL_PATH 4         /* path tracer, one queue over all pixels                                        */
 #define PT_KERNEL_PATH_REGIONS 5 /* path tracer in two passes: tile classification, then work units over regions */
+#define PT_KERNEL_PATH_TREE 6    /* ... num_of_rays > 1: second pass with one pixel per wave, a node's children on lanes */
 
 typedef struct pt_scene pt_scene; /* opaque: device-resident scene + workspace */
 

@@ -21,7 +21,7 @@ PCG_SEQ, PCG_PIXEL, PCG_SAMPLE = 0, 1, 2
 OUT_F64, OUT_F32 = 0, 1
 
 PT_OK = 0
-KERNEL_NONE, KERNEL_SIMPLE, KERNEL_TILE, KERNEL_TILE4, KERNEL_PATH, KERNEL_PATH_REGIONS = range(6)
+KERNEL_NONE, KERNEL_SIMPLE, KERNEL_TILE, KERNEL_TILE4, KERNEL_PATH, KERNEL_PATH_REGIONS, KERNEL_PATH_TREE = range(7)
 ERROR_NAMES = {
     -1: "PT_ERR_INVALID",
     -2: "PT_ERR_HIP",

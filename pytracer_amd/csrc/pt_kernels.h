@@ -3371,6 +3371,394 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAV
   path_trace<true, LDSF, true, SLDS>(a);
 }
 
+// ---- PathTracer with num_of_rays > 1 (perspective camera, second pass): ONE pixel per wave, a node's children on lanes --
+// render.py:126-139 runs the N children of a hit one after the other, each with its whole subtree, all drawing from one
+// generator: where child k starts in the stream is known only when child k-1 has returned.  path_trace gives such a
+// pixel one lane, which walks the tree ray by ray: up to sum N^d dependent steps (1 111 for the CLI's N = 10, D = 3)
+// while a frame's worst pixel sets the launch time (profiles/r03_units_n10_before.log: 8.3 ms, 1 111 iterations).
+// Here a wave owns a pixel and works on one NODE at a time (explicit stack of nodes, depth first, so the order of
+// draws is the reference's): the node's next children are scattered and traced AT THE SAME TIME on different lanes, each
+// from a SPECULATED generator state, and then committed in child order by comparing states -- child k counts iff the
+// state it started from is the state child k-1 ended with, in which case everything it computed is what the sequential
+// program computes; the first child that started elsewhere (and everything behind it) is simply done again in the next
+// round from the right state.  Child 0 always starts right, so a round commits at least one child.
+//   * A child that needs children of its own (hit, lum > 0, survived roulette, depth < D) is committed by pushing its
+//     node; its later siblings wait for the state its subtree leaves behind.
+//   * Ordinary families speculate a chain: child r starts r * cpred draws ahead, cpred = what the last committed child
+//     without a subtree drew (initially: its scatter draws, plus the roulette draw where depth >= rr).
+//   * LEAF families (children at depth D: traced, but THEIR children are beyond max_depth and only consume draws,
+//     render.py:100-101) have few outcomes: c0 draws (hit and killed, black or specular surface) or c0 + 2N (a diffuse hit
+//     that survives).  So child r is traced for EVERY start state it can have, r * c0 + b * 2N for b = 0..r: 55 lanes
+//     settle ten leaves in one round whatever mix of outcomes they have.  (A miss draws c0 - 1: the chain then breaks
+//     there and resumes next round -- slower, never wrong.)
+// The sum a node keeps (cum_radiance += hit_color * child, render.py:137) is formed in child order, so the frame is
+// the sequential one bit for bit; rays are counted for committed children only.
+// LDS: per wave max(D, 1) node records of PT_TREE_FRAME doubles (parents of the node in registers).
+#define PT_TREE_FRAME 20  // hc 0..2, em 3..5, cum 6..8, wp 9..11, n 12..14, in 15..17, brdf 18, next child 19
+struct TreeNode {        // wave-uniform: the node whose children are being traced
+  V3 hc, em, cum, wp, n, in;
+  int brdf, next;
+};
+
+PT_DEV double rl_f64(double v, int lane) {  // v_readlane of a double (lane wave-uniform)
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, lane);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), lane);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | (unsigned long long)lo);
+}
+PT_DEV unsigned long long rl_u64(unsigned long long u, int lane) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, lane);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), lane);
+  return ((unsigned long long)hi << 32) | (unsigned long long)lo;
+}
+PT_DEV V3 rl_v3(V3 v, int lane) {
+  V3 r = {rl_f64(v.x, lane), rl_f64(v.y, lane), rl_f64(v.z, lane)};
+  return r;
+}
+
+PT_DEV void path_tree(const PtKArgs &a) {
+  int S, nsamp, N, W, rows_local, npass, D, rr, diag_lds, pcg_mode, frames_lds;
+  {
+    pt_kargs c = cold_args(a);
+    diag_lds = c->diag_lds;
+    pcg_mode = c->pcg_mode;
+    S = c->S;
+    N = c->N;
+    W = c->W;
+    rows_local = c->rows_local;
+    npass = c->npass;
+    D = c->D;
+    rr = c->rr;
+    frames_lds = 4 * c->npass + (int)(threadIdx.x >> 6) * (c->D > 1 ? c->D : 1) * PT_TREE_FRAME;  // (doubles)
+  }
+  if (blockIdx.x == gridDim.x - 1) {  // the next frame's queue block (nothing of this frame reads it)
+    unsigned long long *qn = pt_queue_next(a);
+    for (int k = threadIdx.x; k < PT_QUEUE_WORDS; k += PT_BLOCK) qn[k] = 0ULL;
+  }
+  if (diag_lds >= 0) {  // scale+translate records into LDS: world_query_lanes fetches them by lane-private index
+    const unsigned long long *src = (const unsigned long long *)a.diag;
+    for (int k = threadIdx.x; k < a.n_diag * 8; k += PT_BLOCK) pt_lds_masks[diag_lds + k] = src[k];
+    __syncthreads();
+  }
+  {  // the grid's occupancy bits into LDS: the cell walk of world_query_lanes reads one per step
+    pt_kargs c = cold_args(a);
+    const int occ_lds = c->grid_occ_lds;
+    if (occ_lds >= 0) {
+      const int nwords = (c->grid_res[0] * c->grid_res[1] * c->grid_res[2] + 31) / 32;
+      unsigned *dst = (unsigned *)pt_lds_masks;
+      for (int k = threadIdx.x; k < nwords; k += PT_BLOCK) dst[occ_lds + k] = c->grid_occ[k];
+      __syncthreads();
+    }
+  }
+  nsamp = S > 0 ? S * S : 1;
+  const double invN = 1.0 / (double)N;
+  const int lane = threadIdx.x & 63;
+  const int mbase = (threadIdx.x >> 6) * npass;
+  const int regions_x = (W + PT_REGION - 1) / PT_REGION;
+  const int n_units = (int)pt_queue(a)[9];
+  bool first_unit = true;
+  unsigned long long nrays = 0;  // (wave-uniform: committed rays of this wave's pixels)
+  // lane r of a leaf round: row = child offset in the round, col = hypothesis b (0..row); rows with row(row+1)/2 + row < 64
+  int tri_row = 0;
+  while ((tri_row + 1) * (tri_row + 2) / 2 <= lane) ++tri_row;
+  const int tri_col = lane - tri_row * (tri_row + 1) / 2;
+  int tri_rows = 0;  // rows that fit the wave: 10
+  while ((tri_rows + 1) * (tri_rows + 2) / 2 <= 64) ++tri_rows;
+
+  auto frame_put = [&](int d, const TreeNode &t) {  // (lane 0 writes; the values are wave-uniform)
+    if (lane == 0) {
+      double *f = pt_lds_f64 + frames_lds + d * PT_TREE_FRAME;
+      f[0] = t.hc.x; f[1] = t.hc.y; f[2] = t.hc.z; f[3] = t.em.x; f[4] = t.em.y; f[5] = t.em.z;
+      f[6] = t.cum.x; f[7] = t.cum.y; f[8] = t.cum.z; f[9] = t.wp.x; f[10] = t.wp.y; f[11] = t.wp.z;
+      f[12] = t.n.x; f[13] = t.n.y; f[14] = t.n.z; f[15] = t.in.x; f[16] = t.in.y; f[17] = t.in.z;
+      f[18] = (double)t.brdf; f[19] = (double)t.next;
+    }
+  };
+  auto frame_get = [&](int d, TreeNode &t) {
+    const double *f = pt_lds_f64 + frames_lds + d * PT_TREE_FRAME;
+    t.hc = {f[0], f[1], f[2]};
+    t.em = {f[3], f[4], f[5]};
+    t.cum = {f[6], f[7], f[8]};
+    t.wp = {f[9], f[10], f[11]};
+    t.n = {f[12], f[13], f[14]};
+    t.in = {f[15], f[16], f[17]};
+    t.brdf = (int)f[18];
+    t.next = (int)f[19];
+  };
+
+  // what a lane found out about the ray it traced (render.py:103-139 up to the recursion)
+  bool o_term = true;            // the call returns without children of its own
+  V3 o_ret = {0.0, 0.0, 0.0};    // ... this value
+  V3 o_hc = {0.0, 0.0, 0.0}, o_em = {0.0, 0.0, 0.0}, o_wp = {0.0, 0.0, 0.0}, o_n = {0.0, 0.0, 1.0};  // else: its node
+  int o_brdf = 0;
+  Pcg pcg;
+  pcg.state = 0;
+  pcg.inc = 1;
+  pcg.n = 0;
+  Ray ray;
+  ray.o = {0.0, 0.0, 0.0};
+  ray.d = {1.0, 0.0, 0.0};
+  ray.tmin = 1e-5;
+  auto shade_ray = [&](int hit, double best_t, int depth) {
+    o_term = true;
+    if (hit < 0) {  // render.py:103-105
+      pt_kargs c = cold_args(a);
+      o_ret = {c->bg[0], c->bg[1], c->bg[2]};
+      return;
+    }
+    const PtShapeRec *rec = a.recs + hit;
+    const PtShapeAux *ax = cold_args(a)->aux + hit;
+    Hit h;
+    h.u = 0.0;
+    h.v = 0.0;
+    bool details = false;
+    if (ax->needs_uv != 0) {
+      hit_details<true>(rec, ax, ray, best_t, h, true);
+      details = true;
+    }
+    V3 hc = brdf_pigment(a, ax, h.u, h.v);
+    const V3 em = emitted_pigment(a, ax, h.u, h.v);
+    const double lum = max2(max2(hc.x, hc.y), hc.z);
+    if (depth >= rr) {  // render.py:116-123
+      const double q = max2(0.05, 1.0 - lum);
+      if (pcg_float(pcg) > q) {
+        const double k = 1.0 / (1.0 - q);
+        hc.x = hc.x * k;
+        hc.y = hc.y * k;
+        hc.z = hc.z * k;
+      } else {
+        o_ret = em;
+        return;
+      }
+    }
+    if (!(lum > 0.0)) {  // render.py:139 with cum_radiance = 0
+      o_ret = {em.x + 0.0 * invN, em.y + 0.0 * invN, em.z + 0.0 * invN};
+      return;
+    }
+    if (depth + 1 > D) {  // every child is beyond max_depth: its scatter draws are consumed, it returns black (render.py:100-101)
+      const bool diffuse = ax->brdf_kind == PT_BRDF_DIFFUSE;
+      V3 fc = {0.0, 0.0, 0.0};
+      for (int i = 0; i < N; ++i) {
+        if (diffuse) {
+          pcg_next(pcg);
+          pcg_next(pcg);
+        }
+        fc.x = fc.x + hc.x * 0.0;
+        fc.y = fc.y + hc.y * 0.0;
+        fc.z = fc.z + hc.z * 0.0;
+      }
+      o_ret = {em.x + fc.x * invN, em.y + fc.y * invN, em.z + fc.z * invN};
+      return;
+    }
+    if (!details) hit_details<true>(rec, ax, ray, best_t, h, false);
+    o_term = false;
+    o_hc = hc;
+    o_em = em;
+    o_wp = h.wp;
+    o_n = h.n;
+    o_brdf = ax->brdf_kind;
+  };
+
+  for (;;) {
+    // ---- next pixel: the unit list, one pixel per unit (see path_trace for the sharded heads) ----
+    unsigned uid = 0;
+    const unsigned nsh = gridDim.x < PT_UNIT_SHARDS ? gridDim.x : PT_UNIT_SHARDS;
+    const unsigned shard = blockIdx.x % nsh;
+    if (first_unit) {
+      uid = (blockIdx.x / nsh) * (PT_BLOCK / 64) + (threadIdx.x >> 6);
+      first_unit = false;
+    } else {
+      const unsigned pullers = (gridDim.x - shard + nsh - 1) / nsh * (PT_BLOCK / 64);
+      if (lane == 0) uid = pullers + (unsigned)atomicAdd(pt_queue(a) + PT_QUEUE_HEADS + 32 * shard, 1ULL);
+    }
+    uid = uid * nsh + shard;
+    const int seq = (int)__builtin_amdgcn_readfirstlane((int)uid);
+    if (seq >= n_units) break;
+    pt_kargs ca = cold_args(a);
+    const int4 unit = ca->units[seq];
+    const int region = __builtin_amdgcn_readfirstlane(unit.x), first = __builtin_amdgcn_readfirstlane(unit.y) & 0xff;
+    const unsigned long long todo = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(unit.z) |
+                                    ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(unit.w) << 32);
+    const int ry = region / regions_x, rx = region - ry * regions_x;
+    {  // the region's cone and survivor masks, for the primary rays
+      const int gr0 = global_row(a, ry * PT_REGION);
+      const int gr1 = global_row(a, (ry * PT_REGION + PT_REGION - 1 < rows_local) ? ry * PT_REGION + PT_REGION - 1 : rows_local - 1);
+      const TileCone tc = tile_cone(a, rx * PT_REGION, (rx * PT_REGION + PT_REGION < W) ? rx * PT_REGION + PT_REGION : W, gr0, gr1);
+      __builtin_amdgcn_wave_barrier();
+      for (int p = 0; p < npass; ++p) {
+        const int slot = p * 64 + lane;
+        bool keep = false;
+        if (slot < a.n_shapes) keep = slot >= a.n_spheres || cone_keeps(tc, a.bounds[slot]);  // planes: always
+        const unsigned long long m = __ballot(keep);
+        if (lane == 0) pt_lds_masks[mbase + p] = m;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    const int bit = nth_set_bit(todo, first);
+    const long long pix = (long long)(ry * PT_REGION + (bit >> 3)) * W + (rx * PT_REGION + (bit & 7));
+    int col, grow;
+    pixel_coords(a, pix, col, grow);
+    const unsigned long long gpix = (unsigned long long)grow * ca->W + col;
+    // the pixel's generator (PT_PCG_PIXEL) -- wave-uniform: `gstate` is the state the sequential program is in
+    unsigned long long gstate = 0, ginc = 1;
+    if (pcg_mode != PT_PCG_SAMPLE) {
+      Pcg g;
+      pcg_seed(g, ca->s0, ca->q0 + gpix);
+      gstate = g.state;
+      ginc = g.inc;
+    }
+    V3 cum_pix = {0.0, 0.0, 0.0};
+    unsigned long long prays = 0;
+    for (int samp = 0; samp < nsamp; ++samp) {
+      if (pcg_mode == PT_PCG_SAMPLE) {
+        Pcg g;
+        pcg_seed(g, ca->s0, ca->q0 + gpix * (unsigned)nsamp + (unsigned)samp);
+        gstate = g.state;
+        ginc = g.inc;
+      }
+      // ---- the sample's primary ray (imagetracer.py:86-97): lane 0 ----
+      pcg.state = gstate;
+      pcg.inc = ginc;
+      pcg.n = 0;
+      double up = 0.5, vp = 0.5;
+      if (S > 0) {
+        const int sr = samp / S, sc = samp - sr * S;
+        up = ((double)sc + pcg_float(pcg)) / (double)S;
+        vp = ((double)sr + pcg_float(pcg)) / (double)S;
+      }
+      ray = primary_ray(a, col, grow, up, vp);
+      {
+        double tp = INFINITY;
+        const int hp = world_query_tile<false, false, true>(a, ray, mbase, npass, tp, lane == 0);
+        shade_ray(hp, tp, 0);
+      }
+      prays += 1ULL;
+      V3 sample_ret = rl_v3(o_ret, 0);
+      gstate = rl_u64(pcg.state, 0);
+      int sp = 0;  // nodes on the stack (the node in `top` included)
+      TreeNode top;
+      top.hc = top.em = top.cum = top.wp = top.n = top.in = {0.0, 0.0, 0.0};
+      top.brdf = 0;
+      top.next = 0;
+      unsigned cpred = 0;
+      if (!__builtin_amdgcn_readfirstlane((int)o_term)) {
+        top.hc = rl_v3(o_hc, 0);
+        top.em = rl_v3(o_em, 0);
+        top.wp = rl_v3(o_wp, 0);
+        top.n = rl_v3(o_n, 0);
+        top.in = rl_v3(ray.d, 0);
+        top.brdf = __builtin_amdgcn_readlane(o_brdf, 0);
+        sp = 1;
+      }
+      auto base_draws = [&]() -> unsigned {  // what a child of `top` draws when it needs no children: its scatter draws + roulette
+        return (top.brdf == PT_BRDF_DIFFUSE ? 2u : 0u) + (sp >= rr ? 1u : 0u);
+      };
+      if (sp) cpred = base_draws();
+      // ---- the tree under the primary hit ----
+      while (sp > 0) {
+        const int remaining = N - top.next;
+        if (remaining <= 0) {
+          // render.py:139: the node returns; its parent adds hit_color * value (render.py:137) and goes on
+          const V3 val = {top.em.x + top.cum.x * invN, top.em.y + top.cum.y * invN, top.em.z + top.cum.z * invN};
+          sp--;
+          if (sp == 0) {
+            sample_ret = val;
+            break;
+          }
+          frame_get(sp - 1, top);
+          top.cum.x = top.cum.x + top.hc.x * val.x;
+          top.cum.y = top.cum.y + top.hc.y * val.y;
+          top.cum.z = top.cum.z + top.hc.z * val.z;
+          cpred = base_draws();
+          continue;
+        }
+        // ---- a round: children top.next .. of this node, depth sp, each from a speculated state ----
+        const unsigned c0 = base_draws();
+        const bool leaf = sp == D;  // (children of the children are beyond max_depth)
+        int row, nrows;
+        unsigned ahead;
+        if (leaf) {
+          nrows = remaining < tri_rows ? remaining : tri_rows;
+          row = tri_row;
+          ahead = (unsigned)tri_row * c0 + (unsigned)tri_col * 2u * (unsigned)N;
+        } else {
+          nrows = remaining < 64 ? remaining : 64;
+          row = lane;
+          ahead = (unsigned)lane * cpred;
+        }
+        const bool act = row < nrows;
+        pcg.state = act ? pcg_advance(gstate, ginc, ahead) : gstate;
+        pcg.inc = ginc;
+        pcg.n = 0;
+        const unsigned long long st_start = pcg.state;
+        ray = scatter_ray<true>(top.brdf, pcg, top.in, top.wp, top.n);  // materials.py:132-152, 175-196
+        double ts = INFINITY;
+        const int hs = world_query_lanes<false>(a, ray, INFINITY, ts, act, diag_lds);
+        if (act) shade_ray(hs, ts, sp);
+        // ---- commit in child order ----
+        unsigned long long expect = gstate;
+        bool pushed = false;
+        for (int r = 0; r < nrows; ++r) {
+          const unsigned long long m = __ballot(act && row == r && st_start == expect);
+          if (!m) break;  // nobody traced child r from the right state: next round
+          const int src = __ffsll((long long)m) - 1;
+          prays += 1ULL;
+          top.next++;
+          expect = rl_u64(pcg.state, src);
+          if (__builtin_amdgcn_readlane((int)o_term, src)) {
+            const V3 val = rl_v3(o_ret, src);
+            top.cum.x = top.cum.x + top.hc.x * val.x;  // render.py:137
+            top.cum.y = top.cum.y + top.hc.y * val.y;
+            top.cum.z = top.cum.z + top.hc.z * val.z;
+            cpred = (unsigned)__builtin_amdgcn_readlane((int)pcg.n, src);
+          } else {  // the child has children of its own: its node goes on the stack, the siblings wait
+            frame_put(sp - 1, top);
+            TreeNode t;
+            t.hc = rl_v3(o_hc, src);
+            t.em = rl_v3(o_em, src);
+            t.cum = {0.0, 0.0, 0.0};
+            t.wp = rl_v3(o_wp, src);
+            t.n = rl_v3(o_n, src);
+            t.in = rl_v3(ray.d, src);
+            t.brdf = __builtin_amdgcn_readlane(o_brdf, src);
+            t.next = 0;
+            top = t;
+            sp++;
+            pushed = true;
+            break;
+          }
+        }
+        gstate = expect;
+        if (pushed) cpred = base_draws();
+        __builtin_amdgcn_wave_barrier();  // (frame_put by lane 0 before any lane's frame_get)
+      }
+      // imagetracer.py:94-97
+      if (S > 0) {
+        cum_pix.x = cum_pix.x + sample_ret.x;
+        cum_pix.y = cum_pix.y + sample_ret.y;
+        cum_pix.z = cum_pix.z + sample_ret.z;
+      } else {
+        cum_pix = sample_ret;
+      }
+    }
+    if (S > 0) {  // imagetracer.py:99-101
+      const double k = 1.0 / (double)(S * S);
+      cum_pix.x = cum_pix.x * k;
+      cum_pix.y = cum_pix.y * k;
+      cum_pix.z = cum_pix.z * k;
+    }
+    if (lane == 0) store_pixel(a, pix, cum_pix);
+    nrays += prays;
+  }
+  add_ray_count(a, lane == 0 ? nrays : 0ULL);
+}
+
+__global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 8))) void pt_path_tree_kernel(const PtKArgs a) {
+  path_tree(a);
+}
+
 // ---- culling probe: cone_keeps / pixel_cone exactly as the render kernels evaluate them, one wave ---------------
 __global__ void pt_cull_probe_kernel(const PtKArgs a, int x0, int x1, int row0, int row1, int pixel_x, int pixel_row,
                                      int *keep) {

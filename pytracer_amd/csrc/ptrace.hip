@@ -882,6 +882,7 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
   static const int env_cull = getenv("PTRACE_CULL") ? atoi(getenv("PTRACE_CULL")) : 1;
   size_t frame_lds = 0, diag_lds_bytes = 0;
   bool lds_frames = false;  // path tracer: the frame stack fits in LDS
+  bool tree = false;        // path tracer, num_of_rays > 1: pt_path_tree_kernel
   if (p->renderer == PT_RENDERER_PATHTRACER) {
     // The path tracer hands pixels out dynamically; fewer resident lanes than pixels lets a lane
     // that drew a cheap pixel take several more while its neighbours finish an expensive one.
@@ -894,6 +895,16 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
     a.frame_doubles = p->num_of_rays > 1 ? 20 : 6;
     frame_lds = (size_t)std::max(p->max_depth, 1) * a.frame_doubles * PT_BLOCK * sizeof(double);
     const size_t mask_lds = regions ? (size_t)4 * a.npass * sizeof(unsigned long long) : 0;
+    // num_of_rays > 1 behind a perspective camera: one pixel per wave, a node's children on lanes (pt_path_tree_kernel);
+    // its stack holds one record per NODE and wave, not one per lane
+    static const int env_tree = getenv("PTRACE_TREE") ? atoi(getenv("PTRACE_TREE")) : 1;
+    const size_t tree_lds = (size_t)std::max(p->max_depth, 1) * PT_TREE_FRAME * (PT_BLOCK / 64) * sizeof(double);
+    tree = regions && cam->kind == PT_CAMERA_PERSPECTIVE && p->num_of_rays > 1 && env_tree != 0 && env_ldsf != 0 &&
+           tree_lds + mask_lds <= PT_LDS_BUDGET / 2;
+    if (tree) {
+      a.frame_doubles = PT_TREE_FRAME;
+      frame_lds = tree_lds;
+    }
     lds_frames = env_ldsf != 0 && frame_lds + mask_lds <= PT_LDS_BUDGET;
     // the scale+translate records ride along in LDS when they fit (world_query_lanes gathers them per lane)
     const size_t base_lds = mask_lds + (lds_frames ? frame_lds : 0);
@@ -914,7 +925,7 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
     // ... and the shapes' own records (what shading gathers per lane), while two workgroups still fit a CU
     static const int env_slds = getenv("PTRACE_SCENE_LDS") ? atoi(getenv("PTRACE_SCENE_LDS")) : 1;
     a.scene_lds = -1;
-    if (regions && lds_frames && env_slds) {
+    if (regions && lds_frames && env_slds && !tree) {
       const size_t at = (base_lds + diag_lds_bytes + 255) / 256 * 256;
       const size_t scene_bytes = (size_t)s->n_shapes * (sizeof(PtShapeRec) + sizeof(PtShapeAux));
       if (at + scene_bytes <= PT_LDS_BUDGET / 2) {
@@ -1039,7 +1050,8 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
   static const int env_lanes_cap = getenv("PTRACE_UNIT_LANES_CAP") ? atoi(getenv("PTRACE_UNIT_LANES_CAP")) : -1;  // 0: a unit = a region
   const long long lanes_cap = env_lanes_cap >= 0 ? (long long)env_lanes_cap : (long long)grid * PT_BLOCK;
   if (path_tiled) {
-    const int units_need = nregions + (int)(4 * lanes_cap / 64) + 64;  // (pt_unit_scatter may cut up to four units per resident wave)
+    // (pt_unit_scatter may cut up to four units per resident wave; the tree kernel takes one PIXEL per unit)
+    const int units_need = tree ? (int)std::min<long long>(a.npix + 64, 0x7fffff00LL) : nregions + (int)(4 * lanes_cap / 64) + 64;
     if (nregions > s->region_cap || units_need > s->units_cap) {
       HIP_TRY(hipStreamSynchronize(st));
       if (s->region_keys) HIP_TRY(hipFree(s->region_keys));
@@ -1207,9 +1219,17 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
       const int nsamp = p->samples_per_side > 0 ? p->samples_per_side * p->samples_per_side : 1;
       static const int env_minr = getenv("PTRACE_UNIT_MIN_ROUNDS") ? atoi(getenv("PTRACE_UNIT_MIN_ROUNDS")) : 0;
       const int min_rounds = env_minr != 0 ? env_minr : (a.pcg_mode == PT_PCG_SAMPLE ? -2 : 16);  // (< 0: see unit_ppu)
+      if (tree)  // one pixel per unit: "64 lanes per pixel, whatever the number of flagged pixels"
+        hipLaunchKernelGGL(pt_unit_scatter, dim3((nregions + PT_SCATTER_BLOCK - 1) / PT_SCATTER_BLOCK), dim3(PT_SCATTER_BLOCK), 0, st, s->region_keys, s->region_mask, nregions, s->units, s->units_cap,
+                           s->queue_last, (long long)1 << 60, 64, 1);
+      else
       hipLaunchKernelGGL(pt_unit_scatter, dim3((nregions + PT_SCATTER_BLOCK - 1) / PT_SCATTER_BLOCK), dim3(PT_SCATTER_BLOCK), 0, st, s->region_keys, s->region_mask, nregions, s->units, s->units_cap,
                          s->queue_last, lanes_cap, nsamp, min_rounds);
-      if (lds_frames && a.scene_lds >= 0) {
+      if (tree) {
+        s->stats.kernel = PT_KERNEL_PATH_TREE;
+        HIP_TRY(path_lds_limit((const void *)pt_path_tree_kernel, lds + frame_lds + diag_lds_bytes));
+        PT_LAUNCH((pt_path_tree_kernel), grid, lds + frame_lds + diag_lds_bytes, true, a);
+      } else if (lds_frames && a.scene_lds >= 0) {
         HIP_TRY(path_lds_limit((const void *)pt_path_regions_kernel<true, true>, lds + frame_lds + diag_lds_bytes));
         PT_LAUNCH((pt_path_regions_kernel<true, true>), grid, lds + frame_lds + diag_lds_bytes, true, a);
       } else if (lds_frames) {

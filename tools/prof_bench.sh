@@ -15,6 +15,7 @@ BENCH="python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --no-cpu-baseline > $OUT/trace.json 2> $OUT/trace.err
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --output-format csv -d $OUT/pmc1 -- $BENCH > $OUT/pmc1.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY --output-format csv -d $OUT/pmc2 -- $BENCH > $OUT/pmc2.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_CVT SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_BRANCH --output-format csv -d $OUT/pmc2b -- $BENCH > $OUT/pmc2b.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc3 -- $BENCH > $OUT/pmc3.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc4 -- $BENCH > $OUT/pmc4.log 2>&1
 # the path tracer's second pass on C3 alone (both PCG modes): instruction counts and duration per launch
@@ -31,9 +32,9 @@ python3 tools/pmc_summary.py $OUT/pmc_c5f $OUT/pmc_c5w --kernel "pt_tile_kernel<
 python3 tools/pmc_summary.py $OUT/pmc_c5f $OUT/pmc_c5w --kernel "pt_cell_kernel" --json $OUT/pmc_c5_cell.json --source "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate runs) on 'python3 tools/kbench.py c5 --rounds 4'; medians over the launches; tools/prof_bench.sh $TAG" > /dev/null
 python3 tools/pmc_summary.py $OUT/pmc_c3 --kernel "pt_path_regions_kernel" --json $OUT/pmc_c3_second_pass.json --source "rocprofv3 --pmc on 'python3 tools/kbench.py c3 --rounds 4' (C3, PT_PCG_PIXEL); medians over the launches; tools/prof_bench.sh $TAG" > /dev/null
 python3 tools/pmc_summary.py $OUT/pmc_c3s --kernel "pt_path_regions_kernel" --json $OUT/pmc_c3_second_pass_sample.json --source "rocprofv3 --pmc on 'python3 tools/kbench.py c3:sample --rounds 4' (C3, PT_PCG_SAMPLE); medians over the launches; tools/prof_bench.sh $TAG" > /dev/null
-SRC="rocprofv3 --pmc (four separate passes: SQ issue counters, fp64 instruction classes, FETCH_SIZE, WRITE_SIZE) on 'python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline'; medians over the dispatches of the kernel; tools/prof_bench.sh $TAG"
-python3 tools/pmc_summary.py $OUT/pmc1 $OUT/pmc2 $OUT/pmc3 $OUT/pmc4 --kernel "pt_tile_kernel<1, 4, false, false" --grid 524288 --json $OUT/pmc_c2.json --source "$SRC" > /dev/null
-python3 tools/pmc_summary.py $OUT/pmc1 $OUT/pmc2 $OUT/pmc3 $OUT/pmc4 --kernel "pt_path_regions_kernel" --grid 131072 --json $OUT/pmc_path_second_pass.json --source "$SRC (all second-pass launches of the run: C3, C4, shares)" > /dev/null || true
+SRC="rocprofv3 --pmc (five separate passes: SQ issue counters, fp64 / integer instruction classes, fp32 / conversion classes, FETCH_SIZE, WRITE_SIZE) on 'python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline'; medians over the dispatches of the kernel; tools/prof_bench.sh $TAG"
+python3 tools/pmc_summary.py $OUT/pmc1 $OUT/pmc2 $OUT/pmc2b $OUT/pmc3 $OUT/pmc4 --kernel "pt_tile4_kernel<1>" --grid 235520 --json $OUT/pmc_c2.json --source "$SRC" > /dev/null
+python3 tools/pmc_summary.py $OUT/pmc1 $OUT/pmc2 $OUT/pmc2b $OUT/pmc3 $OUT/pmc4 --kernel "pt_path_regions_kernel" --grid 131072 --json $OUT/pmc_path_second_pass.json --source "$SRC (all second-pass launches of the run: C3, C4, shares)" > /dev/null || true
 f=$(find $OUT/trace -name "*kernel_stats.csv" | head -1)
 cp $f $OUT/kernel_stats.csv
 head -12 $OUT/kernel_stats.csv | cut -d, -f1-4
