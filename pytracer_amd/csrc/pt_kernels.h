@@ -3458,6 +3458,9 @@ PT_DEV void path_tree(const PtKArgs &a) {
   const int n_units = (int)pt_queue(a)[9];
   bool first_unit = true;
   unsigned long long nrays = 0;  // (wave-uniform: committed rays of this wave's pixels)
+  // small worlds: the wave-uniform loop over every shape (records through the scalar cache) has a shorter critical
+  // path than per-lane candidate lists -- and a round's latency, not its throughput, is what a pixel's tree waits for
+  const bool uniform_loop = a.n_shapes <= cold_args(a)->tree_uniform_max;
   // lane r of a leaf round: row = child offset in the round, col = hypothesis b (0..row); rows with row(row+1)/2 + row < 64
   int tri_row = 0;
   while ((tri_row + 1) * (tri_row + 2) / 2 <= lane) ++tri_row;
@@ -3559,6 +3562,15 @@ PT_DEV void path_tree(const PtKArgs &a) {
     o_brdf = ax->brdf_kind;
   };
 
+#ifdef PT_DEBUG_TIME
+  // cycles of this wave in: 0 fetch + cull, 1 primary ray, 2 state jump + scatter, 3 scattered-ray query, 4 shade,
+  // 5 commit, 6 node returns; 7: rounds
+  unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
+  unsigned long long dbg_leaf_rounds = 0, dbg_committed = 0, dbg_traced = 0, dbg_max_rounds = 0;
+#define PT_TT(k) do { const unsigned long long tn = __builtin_amdgcn_s_memtime(); tsum[k] += tn - tprev; tprev = tn; } while (0)
+#else
+#define PT_TT(k) do { } while (0)
+#endif
   for (;;) {
     // ---- next pixel: the unit list, one pixel per unit (see path_trace for the sharded heads) ----
     unsigned uid = 0;
@@ -3611,6 +3623,10 @@ PT_DEV void path_tree(const PtKArgs &a) {
     }
     V3 cum_pix = {0.0, 0.0, 0.0};
     unsigned long long prays = 0;
+#ifdef PT_DEBUG_TIME
+    unsigned long long dbg_rounds_pix = 0;
+#endif
+    PT_TT(0);
     for (int samp = 0; samp < nsamp; ++samp) {
       if (pcg_mode == PT_PCG_SAMPLE) {
         Pcg g;
@@ -3635,6 +3651,7 @@ PT_DEV void path_tree(const PtKArgs &a) {
         shade_ray(hp, tp, 0);
       }
       prays += 1ULL;
+      PT_TT(1);
       V3 sample_ret = rl_v3(o_ret, 0);
       gstate = rl_u64(pcg.state, 0);
       int sp = 0;  // nodes on the stack (the node in `top` included)
@@ -3672,6 +3689,7 @@ PT_DEV void path_tree(const PtKArgs &a) {
           top.cum.y = top.cum.y + top.hc.y * val.y;
           top.cum.z = top.cum.z + top.hc.z * val.z;
           cpred = base_draws();
+          PT_TT(6);
           continue;
         }
         // ---- a round: children top.next .. of this node, depth sp, each from a speculated state ----
@@ -3694,9 +3712,22 @@ PT_DEV void path_tree(const PtKArgs &a) {
         pcg.n = 0;
         const unsigned long long st_start = pcg.state;
         ray = scatter_ray<true>(top.brdf, pcg, top.in, top.wp, top.n);  // materials.py:132-152, 175-196
+        PT_TT(2);
         double ts = INFINITY;
-        const int hs = world_query_lanes<false>(a, ray, INFINITY, ts, act, diag_lds);
+        int hs;
+        if (uniform_loop)
+          hs = world_query<false, false>(a, ray, INFINITY, ts, act);
+        else
+          hs = world_query_lanes<false>(a, ray, INFINITY, ts, act, diag_lds);
+        PT_TT(3);
         if (act) shade_ray(hs, ts, sp);
+        PT_TT(4);
+#ifdef PT_DEBUG_TIME
+        tsum[7] += 1;
+        dbg_rounds_pix += 1;
+        if (leaf) dbg_leaf_rounds += 1;
+        dbg_traced += (unsigned long long)__popcll(__ballot(act));
+#endif
         // ---- commit in child order ----
         unsigned long long expect = gstate;
         bool pushed = false;
@@ -3733,6 +3764,7 @@ PT_DEV void path_tree(const PtKArgs &a) {
         gstate = expect;
         if (pushed) cpred = base_draws();
         __builtin_amdgcn_wave_barrier();  // (frame_put by lane 0 before any lane's frame_get)
+        PT_TT(5);
       }
       // imagetracer.py:94-97
       if (S > 0) {
@@ -3751,7 +3783,20 @@ PT_DEV void path_tree(const PtKArgs &a) {
     }
     if (lane == 0) store_pixel(a, pix, cum_pix);
     nrays += prays;
+#ifdef PT_DEBUG_TIME
+    dbg_committed += prays;
+    if (dbg_rounds_pix > dbg_max_rounds) dbg_max_rounds = dbg_rounds_pix;
+#endif
   }
+#ifdef PT_DEBUG_TIME
+  if (lane == 0) {
+    for (int q = 0; q < 8; ++q) atomicAdd(pt_queue(a) + 1 + q, tsum[q]);
+    atomicAdd(pt_queue(a) + 12, dbg_leaf_rounds);
+    atomicAdd(pt_queue(a) + 13, dbg_committed);
+    atomicAdd(pt_queue(a) + 14, dbg_traced);
+    atomicMax(pt_queue(a) + 15, dbg_max_rounds);
+  }
+#endif
   add_ray_count(a, lane == 0 ? nrays : 0ULL);
 }
 

@@ -117,6 +117,7 @@ struct PtKArgs {
   const int4 *units;               // path tracer, second pass: (region, first flagged pixel | pixels << 8, region mask) per work unit
   int dome_slot;                   // path tracer, first pass: the sphere the camera is deepest inside (uniform pigments), or -1
   int dome_shortcut;               // 0: every tile goes through rays (pt_set_dome_shortcut; a measurement switch)
+  int tree_uniform_max;            // pt_path_tree_kernel: worlds up to this many shapes are queried by the wave-uniform loop
   int dbg_trace_unit;              // -DPT_DEBUG_TIME builds: the unit whose steps are traced (PTRACE_TRACE_UNIT)
   int spec_draws;                  // ... PT_PCG_PIXEL: draws per sample assumed for a pixel nothing is known about yet
   unsigned long long *region_mask; // path tracer: [region] pixels the first pass left to pt_path_kernel

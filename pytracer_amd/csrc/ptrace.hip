@@ -1079,6 +1079,8 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
     // first pass settles, per pixel, what can only hit that sphere (pt_tile_kernel re-checks every condition
     // from the exact hoisted constants; this only names the candidate).
     a.dome_slot = -1;
+    static const int env_tumax = getenv("PTRACE_TREE_UNIFORM_MAX") ? atoi(getenv("PTRACE_TREE_UNIFORM_MAX")) : 0;  // (measured on C3, N = 10: the uniform loop 2.48 ms, candidate lists 1.92)
+    a.tree_uniform_max = env_tumax;
     static const int env_trace = getenv("PTRACE_TRACE_UNIT") ? atoi(getenv("PTRACE_TRACE_UNIT")) : 0;
     a.dbg_trace_unit = env_trace;
     static const int env_dome = getenv("PTRACE_PIXEL_DOME") ? atoi(getenv("PTRACE_PIXEL_DOME")) : 1;

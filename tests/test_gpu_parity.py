@@ -179,6 +179,41 @@ def test_c5_many_spheres_flat_vs_oracle(dev, oracle):
     assert util.bits_equal(out, ora)
 
 
+@pytest.mark.parametrize("n_rays,depth,rr", [(3, 3, 2), (10, 2, 0), (5, 4, 3)])
+def test_tree_kernel_in_a_world_without_a_dome(dev, oracle, n_rays, depth, rr):
+    """num_of_rays > 1 where scattered rays can MISS (no sphere around the scene), over mirrors (no scatter draws) and a
+    checkered plane: the draw counts the children's start states are speculated from take every value the reference
+    can produce, and whatever the speculation gets wrong is only done again -- the frame must equal the oracle's."""
+    from pytracer_amd import flatten, hostmodel as hm
+
+    g = hm.PCG(77, 5)
+    r = g.random_float
+    w = hm.World()
+    for i in range(14):
+        rad = 0.25 + 0.35 * r()
+        brdf = hm.SpecularBRDF(hm.UniformPigment(hm.Color(0.3 + 0.6 * r(), 0.3 + 0.6 * r(), 0.3 + 0.6 * r()))) if i % 3 == 0 else \
+            hm.DiffuseBRDF(hm.UniformPigment(hm.Color(0.2 + 0.7 * r(), 0.2 + 0.7 * r(), 0.2 + 0.7 * r())))
+        emit = hm.UniformPigment(hm.Color(2.0 * r(), 2.0 * r(), 2.0 * r())) if i % 4 == 1 else hm.UniformPigment(hm.BLACK)
+        w.add_shape(hm.Sphere(hm.translation(hm.Vec(1.5 + 3.5 * r(), 3.0 * (r() - 0.5), rad + 0.8 * r())) * hm.scaling(hm.Vec(rad, rad, rad)),
+                              hm.Material(brdf, emit)))
+    w.add_shape(hm.Plane(hm.Transformation(), hm.Material(hm.DiffuseBRDF(hm.CheckeredPigment(hm.Color(0.3, 0.5, 0.1), hm.Color(0.1, 0.2, 0.5), 4)))))
+    scene = flatten.flatten_world(w)
+    W, H = 96, 56
+    cam = flatten.flatten_camera(hm.PerspectiveCamera(1.0, W / H, hm.translation(hm.Vec(-1.0, 0.0, 1.0))))
+    for S, mode in ((1, abi.PCG_PIXEL), (2, abi.PCG_SAMPLE)):
+        par = abi.make_params(W, H, abi.RENDERER_PATHTRACER, samples_per_side=S, num_of_rays=n_rays, max_depth=depth, rr_limit=rr,
+                              pcg_mode=mode, path_state=45, path_seq=54, background=(0.05, 0.1, 0.3))
+        with dev.DeviceScene(scene) as ds:
+            out = ds.render(cam, par)
+            st = ds.stats()
+        assert st.kernel == abi.KERNEL_PATH_TREE
+        ora, n = oracle.render(scene, cam, par, sqr_mode=oracle.SQR_MUL)
+        oracle.set_sqr_mode(oracle.SQR_POW)
+        bad = int((util.rel_err(out, ora) > TOL).any(axis=-1).sum())
+        assert bad <= 3, (S, mode, bad)
+        assert abs(int(st.n_rays) - n) <= 8 + n // 100000, (S, mode, int(st.n_rays), n)
+
+
 def _cluster_world(n, spread, seed, rotated=False):
     """n small spheres bunched around the view axis (many survivors per tile: exercises survivor-mask
     bits >= 31 and several culling passes), optionally with non-diagonal transforms, plus duplicates."""
@@ -387,7 +422,14 @@ def test_dome_shortcut_and_plane_culling_are_invisible(dev, oracle, case):
 
 
 @pytest.mark.parametrize("n_rays,depth,S,mode", [(1, 3, 4, abi.PCG_PIXEL), (2, 2, 2, abi.PCG_PIXEL),
-                                                 (1, 5, 2, abi.PCG_SAMPLE), (3, 3, 0, abi.PCG_PIXEL)])
+                                                 (1, 5, 2, abi.PCG_SAMPLE), (3, 3, 0, abi.PCG_PIXEL),
+                                                 # num_of_rays > 1: one pixel per wave, a node's children on lanes (pt_path_tree_kernel)
+                                                 (10, 3, 1, abi.PCG_PIXEL),    # the CLI's defaults (main.py:95-102)
+                                                 (10, 3, 2, abi.PCG_SAMPLE),
+                                                 (4, 5, 2, abi.PCG_PIXEL),     # roulette (depth >= 3) inside families that still branch
+                                                 (70, 1, 0, abi.PCG_PIXEL),    # more children than lanes: several rounds per node
+                                                 (12, 2, 1, abi.PCG_PIXEL),    # leaf families larger than the ten rows of hypotheses
+                                                 (2, 6, 3, abi.PCG_PIXEL)])
 def test_c3_pathtracer_vs_oracle(dev, oracle, n_rays, depth, S, mode):
     scene, cam = _synthetic(32, False, False, 160, 90)
     par = abi.make_params(160, 90, abi.RENDERER_PATHTRACER, samples_per_side=S, num_of_rays=n_rays,
@@ -395,6 +437,7 @@ def test_c3_pathtracer_vs_oracle(dev, oracle, n_rays, depth, S, mode):
     with dev.DeviceScene(scene) as ds:
         out = ds.render(cam, par)
         st = ds.stats()
+    assert st.kernel == (abi.KERNEL_PATH_TREE if n_rays > 1 else abi.KERNEL_PATH_REGIONS)
     ora, n = oracle.render(scene, cam, par, sqr_mode=oracle.SQR_MUL)
     oracle.set_sqr_mode(oracle.SQR_POW)
     err = util.rel_err(out, ora)
