@@ -1,0 +1,56 @@
+/* ptrace_debug.h — diagnostic entry points of libptrace.so.  NOT part of the drop-in boundary (include/ptrace.h is):
+ * nothing a renderer needs is declared here.  They exist so that the tests can look at pieces of the device path on
+ * their own -- the arithmetic primitives, the culling predicate, the hit record, camera rays, BRDF scattering -- and
+ * compare them with the reference's own fixtures (tests/golden/g3_shapes.npz, g4_camera.npz, g6_scatter_onb.npz:
+ * the values of /root/reference/tests/test_all.py:607-869 and of the reference run on random inputs).
+ * Same conventions as ptrace.h: extern "C", plain pointers, 0 or a negative PT_ERR_* code.
+ */
+#ifndef PTRACE_DEBUG_H
+#define PTRACE_DEBUG_H
+
+#include "ptrace.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Elementwise device primitives (op 0 sqrt, 1 x/y, 2 sin, 3 cos, 4 atan2(x, y), 5 acos, 6 floor, 7 x*y+x unfused,
+ * 8/9 PCG outputs / floats, 10 pcg_advance == n steps): IEEE exactness and ulp distance to libm. */
+int pt_debug_probe(int op, const double *x, const double *y, double *out, int n);
+
+/* keep[i] (World.shapes index): does the conservative cull of the primary rays through the image rectangle
+ * [x0, x1] x [row0, row1 + 1] keep shape i?  pixel_x >= 0: the cone of that one pixel instead.   */
+int pt_debug_cull_probe(pt_scene *scene, const pt_camera *cam, int width, int height, int x0, int x1, int row0, int row1,
+                        int pixel_x, int pixel_row, int *keep);
+
+/* Shape.ray_intersection / World.ray_intersection on the device (shapes.py:97-131, 163-189; world.py:51-69) through
+ * the kernels' own world_query + hit_details.  rays: n x 8 doubles (origin, dir, tmin, tmax).  shape_index >= 0: that
+ * shape of World.shapes alone; -1: the closest hit over the world.  out: n x 12 doubles
+ * (hit 0/1, t, world_point[3], normal[3] normalised as world.py:66-68 does for the winner, u, v, World.shapes index, 0). */
+int pt_debug_hit_probe(pt_scene *scene, int shape_index, const double *rays, int n, double *out);
+
+/* ImageTracer.fire_ray + Camera.fire_ray on the device (imagetracer.py:48-58, camera.py:59-78, 103-124) through the
+ * kernels' own primary_ray.  pix: n x 4 doubles (col, row, u_pixel, v_pixel); out: n x 7 doubles (origin, dir, tmin). */
+int pt_debug_camera_probe(const pt_camera *cam, int width, int height, const double *pix, int n, double *out);
+
+/* BRDF.scatter_ray on the device (materials.py:132-152, 175-196 with geometry.py:247-262).  in: n x 12 doubles
+ * (brdf kind, PCG init_state, PCG init_seq, normal[3], incoming dir[3], point[3]); out: n x 7 doubles (origin, dir,
+ * tmin); state_after: n generator states after the call. */
+int pt_debug_scatter_probe(const double *in, int n, double *out, unsigned long long *state_after);
+
+/* The 16 leading words of the path tracer's queue block of the last frame (unit counts; section sums of a
+ * -DPT_DEBUG_TIME build). */
+int pt_debug_read_queue(pt_scene *scene, unsigned long long *out16);
+
+#ifdef PT_DEBUG_TIME /* instrumented builds only (tools/dbg*.py) */
+int pt_debug_read_dbg(unsigned long long *out8, int reset);
+int pt_debug_read_lat_hist(unsigned long long *out160, int clear);
+int pt_debug_read_lat_events(unsigned long long *out, int clear);
+int pt_debug_read_unitlog(unsigned long long *out, int n_units);
+int pt_debug_read_trace(unsigned long long *out, int n);
+#endif
+
+#ifdef __cplusplus
+}
+#endif
+#endif

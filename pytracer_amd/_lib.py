@@ -17,6 +17,11 @@ EXPORTS = ("pt_device_count", "pt_scene_upload", "pt_scene_free", "pt_rows_for_r
            "pt_image_average_luminosity", "pt_image_tonemap", "pt_host_alloc", "pt_host_free", "pt_set_dome_shortcut", "pt_device_info")
 
 
+# every symbol include/ptrace_debug.h declares for ordinary builds (diagnostics: not part of the boundary)
+DEBUG_EXPORTS = ("pt_debug_probe", "pt_debug_cull_probe", "pt_debug_hit_probe", "pt_debug_camera_probe",
+                 "pt_debug_scatter_probe", "pt_debug_read_queue")
+
+
 class PtraceError(RuntimeError):
     def __init__(self, code: int, message: str):
         super().__init__(f"{abi.ERROR_NAMES.get(code, code)}: {message}")
@@ -110,10 +115,25 @@ def lib():
         L.pt_host_alloc.argtypes = [C.c_size_t, P(C.c_void_p)]
         L.pt_host_free.restype = C.c_int
         L.pt_host_free.argtypes = [C.c_void_p]
-        L.pt_debug_cull_probe.restype = C.c_int
-        L.pt_debug_cull_probe.argtypes = [C.c_void_p, P(abi.Camera)] + [C.c_int] * 8 + [C.c_void_p]
-        L.pt_debug_probe.restype = C.c_int
-        L.pt_debug_probe.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        # diagnostics (include/ptrace_debug.h): bound when the build carries them -- a renderer never needs one
+        if hasattr(L, "pt_debug_cull_probe"):
+            L.pt_debug_cull_probe.restype = C.c_int
+            L.pt_debug_cull_probe.argtypes = [C.c_void_p, P(abi.Camera)] + [C.c_int] * 8 + [C.c_void_p]
+        if hasattr(L, "pt_debug_probe"):
+            L.pt_debug_probe.restype = C.c_int
+            L.pt_debug_probe.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        if hasattr(L, "pt_debug_hit_probe"):
+            L.pt_debug_hit_probe.restype = C.c_int
+            L.pt_debug_hit_probe.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        if hasattr(L, "pt_debug_camera_probe"):
+            L.pt_debug_camera_probe.restype = C.c_int
+            L.pt_debug_camera_probe.argtypes = [P(abi.Camera), C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        if hasattr(L, "pt_debug_scatter_probe"):
+            L.pt_debug_scatter_probe.restype = C.c_int
+            L.pt_debug_scatter_probe.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        if hasattr(L, "pt_debug_read_queue"):
+            L.pt_debug_read_queue.restype = C.c_int
+            L.pt_debug_read_queue.argtypes = [C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 

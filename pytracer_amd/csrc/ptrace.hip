@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "../../include/ptrace.h"
+#include "../../include/ptrace_debug.h"
 #include "pt_kernels.h"
 #include "pt_layout.h"
 #include "pt_post.h"
@@ -1686,5 +1687,74 @@ extern "C" int pt_debug_probe(int op, const double *x, const double *y, double *
   (void)hipFree(dx);
   (void)hipFree(dy);
   (void)hipFree(dout);
+  return PT_OK;
+}
+
+// ---- diagnostics: the hit record, camera rays and BRDF scattering of the device path on their own ----------------
+extern "C" int pt_debug_hit_probe(pt_scene *s, int shape_index, const double *rays, int n, double *out) {
+  if (!s || !rays || !out || n <= 0 || shape_index >= s->n_shapes) return fail(PT_ERR_INVALID, "bad probe arguments");
+  HIP_TRY(hipSetDevice(s->device));
+  PtKArgs a;
+  memset(&a, 0, sizeof a);
+  a.recs = s->recs;
+  a.aux = s->aux;
+  a.diag = s->diag;
+  a.n_shapes = s->n_shapes;
+  a.n_spheres = s->n_spheres;
+  a.n_diag = s->n_diag;
+  double *rd = nullptr, *od = nullptr;
+  HIP_TRY(hipMalloc((void **)&rd, (size_t)n * 8 * sizeof(double)));
+  HIP_TRY(hipMalloc((void **)&od, (size_t)n * 12 * sizeof(double)));
+  HIP_TRY(hipMemcpy(rd, rays, (size_t)n * 8 * sizeof(double), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(pt_hit_probe_kernel, dim3((n + 63) / 64), dim3(64), 0, 0, a, shape_index, rd, n, od);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(out, od, (size_t)n * 12 * sizeof(double), hipMemcpyDeviceToHost));
+  (void)hipFree(rd);
+  (void)hipFree(od);
+  return PT_OK;
+}
+
+extern "C" int pt_debug_camera_probe(const pt_camera *cam, int width, int height, const double *pix, int n, double *out) {
+  if (!cam || !pix || !out || n <= 0 || width <= 0 || height <= 0) return fail(PT_ERR_INVALID, "bad probe arguments");
+  PtKArgs a;
+  memset(&a, 0, sizeof a);
+  a.cam_kind = cam->kind;
+  memcpy(a.cam_m, cam->m, sizeof a.cam_m);
+  a.cam_dist = cam->screen_distance;
+  a.cam_aspect = cam->aspect_ratio;
+  a.W = width;
+  a.H = height;
+  PtKArgs *a_dev = nullptr;
+  double *pd = nullptr, *od = nullptr;
+  HIP_TRY(hipMalloc((void **)&a_dev, sizeof a));
+  HIP_TRY(hipMalloc((void **)&pd, (size_t)n * 4 * sizeof(double)));
+  HIP_TRY(hipMalloc((void **)&od, (size_t)n * 7 * sizeof(double)));
+  a.cold = a_dev;
+  HIP_TRY(hipMemcpy(a_dev, &a, sizeof a, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(pd, pix, (size_t)n * 4 * sizeof(double), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(pt_camera_probe_kernel, dim3((n + 63) / 64), dim3(64), 0, 0, a, pd, n, od);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(out, od, (size_t)n * 7 * sizeof(double), hipMemcpyDeviceToHost));
+  (void)hipFree(a_dev);
+  (void)hipFree(pd);
+  (void)hipFree(od);
+  return PT_OK;
+}
+
+extern "C" int pt_debug_scatter_probe(const double *in, int n, double *out, unsigned long long *state_after) {
+  if (!in || !out || !state_after || n <= 0) return fail(PT_ERR_INVALID, "bad probe arguments");
+  double *id = nullptr, *od = nullptr;
+  unsigned long long *sd = nullptr;
+  HIP_TRY(hipMalloc((void **)&id, (size_t)n * 12 * sizeof(double)));
+  HIP_TRY(hipMalloc((void **)&od, (size_t)n * 7 * sizeof(double)));
+  HIP_TRY(hipMalloc((void **)&sd, (size_t)n * sizeof(unsigned long long)));
+  HIP_TRY(hipMemcpy(id, in, (size_t)n * 12 * sizeof(double), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(pt_scatter_probe_kernel, dim3((n + 63) / 64), dim3(64), 0, 0, id, n, od, sd);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(out, od, (size_t)n * 7 * sizeof(double), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(state_after, sd, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  (void)hipFree(id);
+  (void)hipFree(od);
+  (void)hipFree(sd);
   return PT_OK;
 }

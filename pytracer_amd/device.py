@@ -112,6 +112,16 @@ class DeviceScene:
                                                   int(row1), int(px), int(py), keep.ctypes.data_as(C.c_void_p)))
         return keep[: self.flat.n_shapes].astype(bool)
 
+    def hit_probe(self, rays, shape_index: int = -1) -> np.ndarray:
+        """Diagnostics (include/ptrace_debug.h): ``Shape.ray_intersection`` of shape ``shape_index`` of ``World.shapes``
+        (or, with -1, ``World.ray_intersection``) for ``[n, 8]`` rays (origin, dir, tmin, tmax), evaluated by the
+        kernels' own query and hit-record code.  -> ``[n, 12]``: hit, t, world point, normalised normal, u, v, index."""
+        rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 8)
+        out = np.zeros((rays.shape[0], 12), dtype=np.float64)
+        _lib.check(_lib.lib().pt_debug_hit_probe(self._h, int(shape_index), rays.ctypes.data_as(C.c_void_p), rays.shape[0],
+                                                 out.ctypes.data_as(C.c_void_p)))
+        return out
+
     def sync(self) -> None:
         _lib.check(_lib.lib().pt_sync(self._h))
 
@@ -151,6 +161,26 @@ def device_info(device: int = 0) -> Tuple[int, int]:
 
 def device_count() -> int:
     return int(_lib.lib().pt_device_count())
+
+
+def camera_probe(cam: abi.Camera, width: int, height: int, pix) -> np.ndarray:
+    """Diagnostics: ``ImageTracer.fire_ray`` for ``[n, 4]`` (col, row, u_pixel, v_pixel) -> ``[n, 7]`` (origin, dir, tmin)."""
+    pix = np.ascontiguousarray(pix, dtype=np.float64).reshape(-1, 4)
+    out = np.zeros((pix.shape[0], 7), dtype=np.float64)
+    _lib.check(_lib.lib().pt_debug_camera_probe(C.byref(cam), int(width), int(height), pix.ctypes.data_as(C.c_void_p),
+                                                pix.shape[0], out.ctypes.data_as(C.c_void_p)))
+    return out
+
+
+def scatter_probe(rows) -> Tuple[np.ndarray, np.ndarray]:
+    """Diagnostics: ``BRDF.scatter_ray`` for ``[n, 12]`` (brdf kind, PCG init_state, init_seq, normal, incoming, point)
+    -> (``[n, 7]`` origin, dir, tmin; ``[n]`` generator states after the call)."""
+    rows = np.ascontiguousarray(rows, dtype=np.float64).reshape(-1, 12)
+    out = np.zeros((rows.shape[0], 7), dtype=np.float64)
+    st = np.zeros(rows.shape[0], dtype=np.uint64)
+    _lib.check(_lib.lib().pt_debug_scatter_probe(rows.ctypes.data_as(C.c_void_p), rows.shape[0], out.ctypes.data_as(C.c_void_p),
+                                                 st.ctypes.data_as(C.c_void_p)))
+    return out, st
 
 
 def probe(op: int, x, y=None) -> np.ndarray:

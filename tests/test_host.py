@@ -112,6 +112,16 @@ def test_c_abi_library_exports_header_symbols():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in ptrace.h but not exported"
     assert set(_lib.EXPORTS) == declared
+    # ... and the diagnostics live in their own header: everything the library exports is declared in one of the two
+    dbg_header = open(os.path.join(ROOT, "include", "ptrace_debug.h")).read().split("#ifdef PT_DEBUG_TIME")[0]
+    dbg_declared = set(re.findall(r"\b(pt_debug_[a-z_]+)\s*\(", dbg_header))
+    assert set(_lib.DEBUG_EXPORTS) == dbg_declared
+    for name in dbg_declared:
+        assert hasattr(lib, name), f"{name} declared in ptrace_debug.h but not exported"
+    import subprocess
+    nm = subprocess.run(["nm", "-D", "--defined-only", _lib.lib_path()], capture_output=True, text=True).stdout
+    exported = set(re.findall(r"\bT (pt_[a-z_0-9]+)$", nm, flags=re.M))
+    assert exported == declared | dbg_declared, exported ^ (declared | dbg_declared)
     assert lib.pt_version() >> 16 == 1
     # pure host-side entry points work without a device
     p = abi.make_params(1280, 721, abi.RENDERER_FLAT, n_ranks=3, rank=1, row_block=8, out_format=abi.OUT_F32)

@@ -48,3 +48,11 @@ def bits_equal(a, b) -> bool:
     a = np.ascontiguousarray(a, dtype=np.float64)
     b = np.ascontiguousarray(b, dtype=np.float64)
     return a.shape == b.shape and a.tobytes() == b.tobytes()
+
+
+def bits_equal_rows(a, b) -> np.ndarray:
+    """Per row: are all values of the row bit-identical?"""
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    a2, b2 = a.reshape(a.shape[0], -1), b.reshape(b.shape[0], -1)
+    return (a2.view(np.uint64) == b2.view(np.uint64)).all(axis=1)
