@@ -131,9 +131,15 @@ def cli():
 @click.option("--samples-per-pixel", type=int, default=1, help="Samples per pixel (a perfect square, e.g. 16).")
 @click.option("--declare-float", "-d", type=str, multiple=True, help="Declare a variable: --declare-float=VAR:VALUE")
 @click.option("--device", type=int, default=0, help="GPU to render on")
+@click.option("--pcg-mode", type=click.Choice(["pixel", "sample"]), default="pixel",
+              help="Random streams: one generator per pixel (default: the alignment the reference's CLI frames are pinned "
+                   "in) or one per sample (equally pinned, samples of a pixel independent: several times faster with "
+                   "--samples-per-pixel > 1).")
+@click.option("--host-postprocess", is_flag=True, default=False,
+              help="Copy the fp64 frame to the host first and post-process there (the round-2 behaviour; same bytes).")
 @click.argument("input_scene_name", type=str)
 def render(width, height, algorithm, pfm_output, png_output, num_of_rays, max_depth, init_state, init_seq,
-           samples_per_pixel, declare_float, device, input_scene_name):
+           samples_per_pixel, declare_float, device, pcg_mode, host_postprocess, input_scene_name):
     try:
         job = plan_render(width, height, algorithm, num_of_rays, max_depth, init_state, init_seq, samples_per_pixel,
                           declare_float, input_scene_name)
@@ -143,19 +149,22 @@ def render(width, height, algorithm, pfm_output, png_output, num_of_rays, max_de
     click.echo(f"{width}x{height} px, {algorithm}, {job.samples_per_side ** 2} sample(s) per pixel, "
                f"{len(job.world.shapes)} shape(s), GPU {device}")
     image = hm.HdrImage(width, height)
-    tracer = GpuImageTracer(image=image, camera=job.camera, samples_per_side=job.samples_per_side, device=device)
+    tracer = GpuImageTracer(image=image, camera=job.camera, samples_per_side=job.samples_per_side, device=device,
+                            pcg_mode=pcg_mode, resident=not host_postprocess)
     started = perf_counter()
     tracer.fire_all_rays(job.renderer, callback=lambda col, row: click.echo(f"  row {row + 1} of {height}\r", nl=False))
     wall = perf_counter() - started
     st = tracer.last_stats
     click.echo(f"frame done: {wall:.3f} s wall, {st.kernel_ms:.3f} ms in kernels, {st.n_rays} rays")
-    # what main.py:203-213 leaves behind: the PFM of the raw frame, then a PNG of the tone-mapped one
+    # what main.py:203-213 leaves behind: the PFM of the raw frame, then a PNG of the tone-mapped one.  The frame stays
+    # in HBM (fp64, like the reference's HdrImage): the PFM floats and the tone-mapped bytes are all that crosses the link
+    frame = image if host_postprocess else tracer.device_image
     with open(pfm_output, "wb") as f:
-        image.write_pfm(f)
-    image.normalize_image(factor=1.0)
-    image.clamp_image()
+        frame.write_pfm(f)
+    frame.normalize_image(factor=1.0)
+    frame.clamp_image()
     with open(png_output, "wb") as f:
-        image.write_ldr_image(f, "PNG")
+        frame.write_ldr_image(f, "PNG")
     click.echo(f"wrote {pfm_output} and {png_output}")
     tracer.close()
 

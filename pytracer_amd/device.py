@@ -25,7 +25,7 @@ class _PinnedBuf:
 
 
 _free_pinned = {}  # nbytes -> [ptr, ...]; at most _POOL_KEEP idle buffers per size stay allocated
-_POOL_KEEP = 3
+_POOL_KEEP = 2
 
 
 def _release_pinned(ptr: int, nbytes: int) -> None:
@@ -34,6 +34,21 @@ def _release_pinned(ptr: int, nbytes: int) -> None:
         idle.append(ptr)
     else:
         _lib.lib().pt_host_free(C.c_void_p(ptr))
+
+
+def free_pinned_pool() -> None:
+    """Release every idle page-locked buffer of the pool (also registered to run at interpreter exit)."""
+    for idle in _free_pinned.values():
+        while idle:
+            try:
+                _lib.lib().pt_host_free(C.c_void_p(idle.pop()))
+            except Exception:
+                pass
+
+
+import atexit  # noqa: E402
+
+atexit.register(free_pinned_pool)
 
 
 def pinned_empty(shape, dtype) -> np.ndarray:
@@ -85,9 +100,10 @@ class DeviceScene:
     def output_shape(params: abi.Params) -> Tuple[int, int, int]:
         return int(_lib.lib().pt_rows_for_rank(C.byref(params))), int(params.width), 3
 
-    def render(self, cam: abi.Camera, params: abi.Params, pinned: bool = True) -> np.ndarray:
-        """Kernel + device->host copy; returns ``[rows_for_rank, W, 3]`` (fp64 or fp32), by default in
-        page-locked memory from a small pool (``pinned=False``: an ordinary numpy array)."""
+    def render(self, cam: abi.Camera, params: abi.Params, pinned: bool = False) -> np.ndarray:
+        """Kernel + device->host copy; returns ``[rows_for_rank, W, 3]`` (fp64 or fp32) as an ordinary numpy array, or
+        with ``pinned=True`` in page-locked memory from a small pool (for callers that consume the frame at once: the
+        array's memory goes back to the pool when it is collected; ``free_pinned_pool()`` releases the idle buffers)."""
         dt = np.float64 if params.out_format == abi.OUT_F64 else np.float32
         out = pinned_empty(self.output_shape(params), dt) if pinned else np.empty(self.output_shape(params), dtype=dt)
         _lib.check(_lib.lib().pt_render(self._h, C.byref(cam), C.byref(params),

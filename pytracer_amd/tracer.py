@@ -34,6 +34,18 @@ without a callback the frame is one launch.  The clock is wall time (the referen
 
 The scene is re-flattened on every call, as the reference re-reads ``World.shapes`` on every call;
 the device copy is reused only when the flattened arrays are bit-identical to the ones uploaded.
+
+``resident=True`` (what the ``render`` command uses): the frame is left in HBM as ``tracer.device_image`` (a
+:class:`pytracer_amd.postprocess.DeviceImage`, fp64 like the reference's ``HdrImage``) instead of being copied
+into ``image`` -- the PFM floats and the tone-mapped bytes are then the only device-to-host traffic of a render
+(main.py:203-213 on the device; 14 MB instead of the 22 MB fp64 frame at 1280x720).  ``image`` keeps its size and is
+filled on demand by ``tracer.download()``.
+
+``fallback="host"`` (opt-in, never the default): a reference renderer whose world the device cannot express (an
+unknown shape / BRDF / pigment class, a non-affine matrix) is itself a callable ``Ray -> Color``; with this option it
+runs through the host loop above -- the reference's own code computing every radiance, exactly as
+``ImageTracer.fire_all_rays`` would -- instead of raising ``UnsupportedSceneError``.  Without the option nothing
+ever leaves the device path silently.
 """
 from __future__ import annotations
 
@@ -71,7 +83,13 @@ class _RayView:
 
 class GpuImageTracer:
     def __init__(self, image, camera, samples_per_side: int = 0, pcg=None, device: int = 0,
-                 pcg_mode: str = "pixel"):
+                 pcg_mode: str = "pixel", resident: bool = False, fallback: Optional[str] = None):
+        if fallback not in (None, "host"):
+            raise ValueError('fallback must be None or "host"')
+        self.resident = bool(resident)
+        self.fallback = fallback
+        self.device_image = None   # resident=True: the last frame, in HBM
+        self.last_path = None      # "device" | "host": where the last frame was computed
         self.image = image
         self.camera = camera
         self.samples_per_side = samples_per_side
@@ -105,9 +123,19 @@ class GpuImageTracer:
     # -- imagetracer.py:60-110 ------------------------------------------------------------------------
     def fire_all_rays(self, func, callback=None, callback_time_s: float = 2.0, **callback_kwargs) -> None:
         if flatten.is_device_renderer(func):
-            self._device_frame(func, callback, callback_time_s, callback_kwargs)
+            try:
+                self._device_frame(func, callback, callback_time_s, callback_kwargs)
+                self.last_path = "device"
+            except flatten.UnsupportedSceneError:
+                # (raised while flattening: before anything was rendered or written)
+                if self.fallback != "host" or not callable(func):
+                    raise
+                self.device_image = None
+                self._host_loop(func, callback, callback_time_s, callback_kwargs)
+                self.last_path = "host"
         elif callable(func):
             self._host_loop(func, callback, callback_time_s, callback_kwargs)
+            self.last_path = "host"
         else:
             raise TypeError(f"func must be a renderer or a callable Ray -> Color, not {type(func).__name__}")
 
@@ -156,30 +184,52 @@ class GpuImageTracer:
                                          tracer_pcg=self.pcg, pcg_mode=_PCG_MODES[self.pcg_mode])
         cam = flatten.flatten_camera(self.camera)
         scene = self._device_scene(func.world)
+        dev_t = None
+        if self.resident:
+            import torch  # device memory for the resident frame (plumbing only)
+
+            dev_t = torch.empty((h, w, 3), dtype=torch.float64, device=torch.device("cuda", self.device))
+            params = abi.copy_params(params, out_format=abi.OUT_F64)
+        row_bytes = w * 3 * 8
+
+        def render_rows(p, row0):
+            """One launch for the partition written into `p`; -> its rows (host array, or None when resident)."""
+            if dev_t is None:
+                return scene.render(cam, p)
+            rows = DeviceScene.output_shape(p)[0]
+            scene.render_into(cam, p, dev_t.data_ptr() + row0 * row_bytes, rows * row_bytes, None)
+            return rows
+
         if not callback or h <= 8:
-            out = scene.render(cam, params)  # [H, W, 3] fp64, row 0 = top (hdrimages.py:78-80)
+            out = render_rows(params, 0)  # [H, W, 3] fp64, row 0 = top (hdrimages.py:78-80)
             self.last_stats = scene.stats()
             self.last_bands = 1
         else:
             # Bands of 2^k rows starting at multiples of their height (so a band is "block r0/L of L-row
             # blocks", which the partition fields of pt_params express); per-pixel seeds make the frame
-            # independent of how it is cut.  Four or fewer bands for a frame that renders quickly.
-            out = np.empty((h, w, 3), dtype=np.float64)
+            # independent of how it is cut.  A frame starts as TWO bands (the first one tells how long a band takes)
+            # and is cut finer only while a band takes more than half of callback_time_s.
+            out = np.empty((h, w, 3), dtype=np.float64) if dev_t is None else None
             band = 1
-            while band * 4 < h:
+            while band * 2 < h:
                 band *= 2
-            row0, n_rays, kernel_ms, total_ms, self.last_bands = 0, 0, 0.0, 0.0, 0
+            row0, n_rays, n_res, kernel_ms, total_ms, self.last_bands = 0, 0, 0, 0.0, 0.0, 0
+            st = None
             while row0 < h:
                 while row0 % band:
                     band //= 2
                 p = abi.copy_params(params, row_block=band, n_ranks=(h + band - 1) // band, rank=row0 // band)
                 t0 = perf_counter()
-                shard = scene.render(cam, p)
+                shard = render_rows(p, row0)
+                if dev_t is None:
+                    out[row0:row0 + shard.shape[0]] = shard
+                    row0 += shard.shape[0]
+                else:
+                    row0 += shard
+                st = scene.stats()  # (waits for the band)
                 dt = perf_counter() - t0
-                out[row0:row0 + shard.shape[0]] = shard
-                row0 += shard.shape[0]
-                st = scene.stats()
-                n_rays, kernel_ms, total_ms = n_rays + st.n_rays, kernel_ms + st.kernel_ms, total_ms + st.total_ms
+                n_rays, n_res = n_rays + st.n_rays, n_res + st.n_rays_resolved
+                kernel_ms, total_ms = kernel_ms + st.kernel_ms, total_ms + st.total_ms
                 self.last_bands += 1
                 now = perf_counter()
                 if row0 < h and now - last_call_time > callback_time_s:
@@ -187,9 +237,21 @@ class GpuImageTracer:
                     last_call_time = now
                 if dt > 0.5 * callback_time_s and band > 1:
                     band //= 2
-            st.n_rays, st.kernel_ms, st.total_ms, st.n_pixels = n_rays, kernel_ms, total_ms, w * h
+            st.n_rays, st.n_rays_resolved, st.kernel_ms, st.total_ms, st.n_pixels = n_rays, n_res, kernel_ms, total_ms, w * h
             self.last_stats = st
-        _fill_image(self.image, out)
+        if dev_t is not None:
+            from .postprocess import DeviceImage
+
+            self.device_image = DeviceImage(dev_t)
+        else:
+            self.device_image = None
+            _fill_image(self.image, out)
+
+    def download(self) -> None:
+        """resident=True: copy the frame left in HBM into ``image`` (what ``fire_all_rays`` does by itself otherwise)."""
+        if self.device_image is None:
+            raise RuntimeError("no resident frame: fire_all_rays(renderer) with resident=True leaves one")
+        _fill_image(self.image, self.device_image.numpy())
 
     def close(self):
         if self._scene is not None:

@@ -3,7 +3,12 @@
 
 Run in the build container only (the reference lives at /root/reference and never travels):
 
-    PYTHONDONTWRITEBYTECODE=1 python3 tests/golden/make_golden.py
+    PYTHONDONTWRITEBYTECODE=1 python3 tests/golden/make_golden.py [--out DIR] [g1 g2 ... g5cli]
+
+Without generator names every generator runs IN ITS OWN PROCESS: the reference's scene parser keeps one default
+``World()`` for all parses of a process (scene_file.py:363), so a second ``parse_scene`` in the same
+process would see the first one's shapes again -- one parse per process is the recipe that produced the committed
+files.  ``--out DIR`` writes somewhere else (tests/test_golden_regen.py regenerates a fixture and compares arrays).
 
 Each fixture is pure data: flattened inputs (through pytracer_amd.flatten's duck-typed reader,
 applied to the reference's own objects) and the outputs the reference computed for them, stored
@@ -43,8 +48,11 @@ from pytracer_amd import abi, flatten  # noqa: E402
 INF = float("inf")
 
 
+OUT_DIR = HERE  # (--out)
+
+
 def save(name, **arrays):
-    path = os.path.join(HERE, name + ".npz")
+    path = os.path.join(OUT_DIR, name + ".npz")
     np.savez_compressed(path, **arrays)
     print(f"{name}.npz  {os.path.getsize(path) / 1024:.1f} KiB")
 
@@ -488,7 +496,8 @@ def g10_postprocess():
     from pytracer.hdrimages import Endianness
     out = {}
     for tag, name in (("a", "g5_c2_flat_160x90"), ("b", "g5_demo_path_40x30_n2d2_pixel")):
-        px = np.load(os.path.join(HERE, name + ".npz"))["pixels"]
+        src = os.path.join(OUT_DIR, name + ".npz")
+        px = np.load(src if os.path.exists(src) else os.path.join(HERE, name + ".npz"))["pixels"]
         h, w = px.shape[:2]
         img = HdrImage(w, h)
         img.pixels = [Color(*map(float, px[y, x])) for y in range(h) for x in range(w)]
@@ -512,10 +521,24 @@ def g10_postprocess():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g6", "g8", "g9", "g5", "g10", "g5cli", "g5c4"]
+    argv = sys.argv[1:]
+    if "--out" in argv:
+        at = argv.index("--out")
+        OUT_DIR = os.path.abspath(argv[at + 1])
+        os.makedirs(OUT_DIR, exist_ok=True)
+        del argv[at:at + 2]
     table = {"g1": g1_pcg, "g2": g2_xform, "g3": g3_shapes, "g4": g4_camera, "g6": g6_g7_scatter_onb,
              "g8": g8_pigments, "g9": g9_furnace, "g5": g5_frames, "g10": g10_postprocess, "g5c4": g5_c4,
              "g5cli": g5_cli}
-    for k in which:
-        table[k]()
+    if argv:
+        parses = sum(1 for k in argv if k in ("g5", "g5cli"))
+        if parses > 1:
+            raise SystemExit("g5 and g5cli both parse examples/demo.txt: run them in separate processes (SURVEY.md H5)")
+        for k in argv:
+            table[k]()
+    else:
+        import subprocess
 
+        for k in ["g1", "g2", "g3", "g4", "g6", "g8", "g9", "g5", "g10", "g5cli", "g5c4"]:  # (g10 reads g5's frames)
+            subprocess.run([sys.executable, os.path.abspath(__file__), "--out", OUT_DIR, k], check=True,
+                           env=dict(os.environ, PYTHONDONTWRITEBYTECODE="1"))

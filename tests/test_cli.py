@@ -137,6 +137,49 @@ def test_cli_frame_equals_reference_cli_frame(tmp_path, algo, fixture, w, h):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("algo,w,h,extra", [("flat", 64, 48, []), ("pathtracing", 32, 24, []),
+                                            ("pathtracing", 40, 30, ["--samples-per-pixel", "4", "--num-of-rays", "2", "--pcg-mode", "sample"]),
+                                            ("pointlight", 64, 48, []), ("onoff", 33, 17, [])])
+def test_cli_post_processing_on_the_resident_frame_writes_the_same_bytes(tmp_path, algo, w, h, extra):
+    """main.py:203-213 on the frame left in HBM (the PFM floats and the tone-mapped bytes are the only device-to-host
+    traffic) == the same steps after copying the fp64 frame to the host first (--host-postprocess): PFM and PNG files
+    byte for byte."""
+    from pytracer_amd.cli import cli
+
+    files = {}
+    for tag, flag in (("dev", []), ("host", ["--host-postprocess"])):
+        pfm, png = str(tmp_path / f"{tag}.pfm"), str(tmp_path / f"{tag}.png")
+        r = CliRunner().invoke(cli, ["render", "--width", str(w), "--height", str(h), "--algorithm", algo, "--pfm-output", pfm,
+                                     "--png-output", png, "-d", "clock:150"] + extra + flag + ["builtin:demo"])
+        assert r.exit_code == 0, r.output
+        files[tag] = (open(pfm, "rb").read(), open(png, "rb").read())
+    assert files["dev"][0] == files["host"][0], "PFM differs"
+    assert files["dev"][1] == files["host"][1], "PNG differs"
+    assert len(files["dev"][0]) == len(f"PF\n{w} {h}\n-1.0\n") + w * h * 12
+
+
+@pytest.mark.gpu
+def test_cli_pcg_mode_sample_is_the_sample_aligned_frame(tmp_path):
+    """--pcg-mode sample: sample k of pixel i owns PCG(init_state, init_seq + i * S^2 + k) (SURVEY.md 8c Mode SAMPLE)."""
+    from pytracer_amd import abi, flatten, scenes
+    from pytracer_amd.cli import cli
+    from pytracer_amd.device import DeviceScene
+
+    w, h = 48, 36
+    pfm, png = str(tmp_path / "o.pfm"), str(tmp_path / "o.png")
+    r = CliRunner().invoke(cli, ["render", "--width", str(w), "--height", str(h), "--algorithm", "pathtracing", "--samples-per-pixel", "4",
+                                 "--num-of-rays", "1", "--max-depth", "3", "--pcg-mode", "sample", "--pfm-output", pfm,
+                                 "--png-output", png, "-d", "clock:150", "builtin:demo"])
+    assert r.exit_code == 0, r.output
+    world, camera = scenes.demo_world(clock=150.0)
+    par = abi.make_params(w, h, abi.RENDERER_PATHTRACER, samples_per_side=2, num_of_rays=1, max_depth=3, pcg_mode=abi.PCG_SAMPLE,
+                          path_state=45, path_seq=54, out_format=abi.OUT_F32)
+    with DeviceScene(flatten.flatten_world(world)) as ds:
+        direct = ds.render(flatten.flatten_camera(camera), par)
+    assert np.array_equal(_read_pfm(pfm, w, h), direct)
+
+
+@pytest.mark.gpu
 def test_cli_scene_file_on_the_gpu(tmp_path, reference_importable):
     """Where both the reference and a GPU exist: the scene-file branch end to end."""
     from pytracer_amd.cli import cli

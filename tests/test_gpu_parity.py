@@ -786,10 +786,23 @@ def test_gpu_image_tracer_bands_callback_and_world_mutation(dev, oracle):
     assert calls[0] == (0, 0) and len(calls) == t2.last_bands
     assert all(c == 159 for c, _ in calls[1:]) and [r for _, r in calls[1:]] == sorted(r for _, r in calls[1:])
     assert calls[-1][1] < 89
-    # default callback_time_s: the frame is far quicker, so only the initial call is made
+    # the statistics of a banded frame are sums over its bands, the resolved rays included (a subset count of n_rays)
+    assert t2.last_stats.n_rays_resolved == t1.last_stats.n_rays_resolved <= t2.last_stats.n_rays
+    # default callback_time_s: the frame is far quicker, so only the initial call is made -- in two launches, not four
     calls.clear()
     t2.fire_all_rays(pt(), callback=lambda col, row: calls.append((col, row)))
-    assert calls == [(0, 0)]
+    assert calls == [(0, 0)] and t2.last_bands == 2
+    # resident=True: the same frame, left in HBM (banded or not), nothing written into `image` until download()
+    held = hm.HdrImage(160, 90)
+    t4 = GpuImageTracer(held, camera, samples_per_side=2, resident=True)
+    t4.fire_all_rays(pt(), callback=lambda col, row: None, callback_time_s=0.0)
+    assert t4.last_bands >= 2 and not held.array.any()
+    assert util.bits_equal(t4.device_image.numpy(), one.array)
+    t4.fire_all_rays(pt())
+    assert t4.last_bands == 1 and util.bits_equal(t4.device_image.numpy(), one.array)
+    t4.download()
+    assert util.bits_equal(held.array, one.array)
+    t4.close()
     # mutate the SAME World object between two calls (a cache keyed on identity rendered the old scene)
     flat_before = hm.HdrImage(160, 90)
     t3 = GpuImageTracer(flat_before, camera)

@@ -164,3 +164,44 @@ def test_host_loop_equals_reference_imagetracer(ref, S):
         assert calls == [(0, 0)]
         assert all(type(c) is Color for c in b.pixels)
         assert [(c.r, c.g, c.b) for c in a.pixels] == [(c.r, c.g, c.b) for c in b.pixels]
+
+
+def test_renderer_with_an_inexpressible_world_raises_unless_the_host_fallback_is_asked_for(ref):
+    """the reference runs any renderer on any world (imagetracer.py:60-110, render.py:26-39).  A world
+    with a shape class the device cannot express raises ``UnsupportedSceneError`` by default -- nothing leaves the device
+    path silently -- and with ``fallback="host"`` the renderer, itself a callable Ray -> Color, goes through the host loop:
+    the reference's own code computes every radiance, and the frame equals the reference ImageTracer's."""
+    from pytracer.camera import PerspectiveCamera
+    from pytracer.colors import Color
+    from pytracer.geometry import Vec
+    from pytracer.hdrimages import HdrImage
+    from pytracer.imagetracer import ImageTracer
+    from pytracer.materials import DiffuseBRDF, Material, UniformPigment
+    from pytracer.pcg import PCG
+    from pytracer.render import FlatRenderer, PathTracer
+    from pytracer.shapes import Sphere
+    from pytracer.transformations import scaling, translation
+    from pytracer.world import World
+
+    from pytracer_amd import flatten
+
+    class Blob(Sphere):  # a shape class of the user's own: the flattener knows shapes by class name
+        pass
+
+    world = World()
+    world.add_shape(Blob(transformation=translation(Vec(2.0, 0.0, 0.0)) * scaling(Vec(0.7, 0.7, 0.7)),
+                         material=Material(brdf=DiffuseBRDF(UniformPigment(Color(0.3, 0.6, 0.9))),
+                                           emitted_radiance=UniformPigment(Color(0.1, 0.2, 0.3)))))
+    camera = PerspectiveCamera(aspect_ratio=1.5)
+    for make, S in ((lambda: FlatRenderer(world, background_color=Color(0.0, 0.1, 0.0)), 0),
+                    (lambda: PathTracer(world, pcg=PCG(45, 54), num_of_rays=2, max_depth=2), 2)):
+        with pytest.raises(flatten.UnsupportedSceneError):
+            GpuImageTracer(HdrImage(6, 4), camera, samples_per_side=S, pcg=PCG(11, 3)).fire_all_rays(make())
+        a, b = HdrImage(6, 4), HdrImage(6, 4)
+        ImageTracer(a, camera, samples_per_side=S, pcg=PCG(11, 3)).fire_all_rays(make())
+        t = GpuImageTracer(b, camera, samples_per_side=S, pcg=PCG(11, 3), fallback="host")
+        t.fire_all_rays(make())
+        assert t.last_path == "host"
+        assert [(c.r, c.g, c.b) for c in a.pixels] == [(c.r, c.g, c.b) for c in b.pixels]
+    with pytest.raises(ValueError):
+        GpuImageTracer(HdrImage(2, 2), camera, fallback="oracle")
