@@ -268,6 +268,41 @@ def boundary_rows(flat, device: int, rays_per_frame: int):
                 "pt_render call per frame: the copy runs at the host link's rate and is >90 % of the time",
     }
 
+    # the `render` command's path since round 3 (main.py:197-213 on the device): the fp64 frame stays in HBM, the PFM
+    # floats (12 B/pixel) and the tone-mapped bytes (3 B/pixel) are the only device-to-host traffic -- against the round-2
+    # path: copy the fp64 frame (24 B/pixel) to the host, then upload it again for every post-processing step
+    from pytracer_amd.postprocess import DeviceImage
+
+    par64 = abi.make_params(W, H, abi.RENDERER_FLAT, out_format=abi.OUT_F64)
+    dev_frame = torch.empty((H, W, 3), dtype=torch.float64, device="cuda")
+
+    def cli_resident():
+        ds.render_into(cam, par64, dev_frame.data_ptr(), dev_frame.numel() * 8, None)
+        img = DeviceImage(dev_frame)
+        pfm = img.pfm_payload()
+        img.normalize_image(factor=1.0)
+        img.clamp_image()
+        return pfm, img.ldr_bytes()
+
+    def cli_host_frame():
+        img = DeviceImage.from_numpy(ds.render(cam, par64))
+        pfm = img.pfm_payload()
+        img.normalize_image(factor=1.0)
+        img.clamp_image()
+        return pfm, img.ldr_bytes()
+
+    for fn, key in ((cli_resident, "cli_render_to_pfm_and_rgb8_resident_ms"), (cli_host_frame, "cli_render_to_pfm_and_rgb8_via_host_frame_ms")):
+        fn()
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            fn()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        rows[key] = float(np.median(ts))
+    rows["cli_note"] = ("render + write_pfm payload + normalize_image + clamp_image + LDR bytes (main.py:197-213) for the C2 frame: "
+                        "`resident` leaves the fp64 frame in HBM (device-to-host: 11.06 MB of PFM floats + 2.76 MB of rgb8), "
+                        "`via_host_frame` is the round-2 path (22.1 MB fp64 frame to the host, uploaded again per step)")
+
     class RefColor:  # the reference's Color: three attributes
         __slots__ = ("r", "g", "b")
 
