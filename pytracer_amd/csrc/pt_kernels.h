@@ -14,13 +14,21 @@
 // involved the result is bit-identical to the reference arithmetic with x*x for x**2
 // (SURVEY.md H1/H2).  sqrt and '/' are IEEE-correct on gfx950.
 //
-// Execution model (MI355X): 1 lane = 1 pixel (grid-stride), wave64, 256-thread workgroups.  The
-// shape loop index is wave-uniform, so shape records are fetched through the scalar cache into
-// SGPRs (one s_load per record per wave) and every v_mul_f64 takes its matrix element as an SGPR
-// operand: VGPRs hold only the ray.  The path tracer is a per-lane state machine whose ONLY
-// convergent hot loop is the shape loop: a lane that finishes a path immediately starts its next
-// sample, so lanes stay busy until their pixel's S*S samples are done (no per-bounce tail).
-// MFMA is not used (no dense contraction on this path); the bound is fp64 VALU issue.
+// Execution model (MI355X, wave64, 256-thread workgroups; DESIGN.md section 4 has the measurements):
+//   pt_tile4_kernel       OnOff / Flat, pixel-centre rays, perspective camera, <= 256 shapes: a wave owns a 16x16 tile,
+//                         FOUR pixels per lane; one cone + one cull per tile, survivors in SGPR masks, every survivor's
+//                         hoisted record (scalar loads) serves four independent rays per lane.
+//   pt_tile_kernel        the other OnOff / Flat / PointLight frames and the path tracer's FIRST pass: a wave owns an
+//                         8x8 tile, one pixel per lane, survivor masks in LDS replayed per jitter sample; strips and
+//                         blocks of tiles share a cull; cell lists (pt_cell_kernel) for worlds of > 256 shapes.
+//   pt_path_regions_kernel  the path tracer's second pass for num_of_rays = 1: work units of flagged pixels, a
+//                         pixel's samples spread over lanes, speculated generator states committed in order;
+//                         scattered rays walk per-lane candidate lists (world_query_lanes) or a uniform grid.
+//   pt_path_tree_kernel   ... for num_of_rays > 1: one pixel per wave, a node's children on lanes.
+//   pt_simple_kernel / pt_path_kernel   one lane per pixel (tiny worlds, orthogonal path tracing, PTRACE_CULL=0): the
+//                         shape loop index is wave-uniform, records come through the scalar cache into SGPRs.
+// MFMA is not used (no dense contraction on this path); what binds is vector issue and dependent latency
+// (profiles/r03_issue_rates.txt: fp64 4, fp32 / int32 2, SALU 4 SIMD-cycles per wave-instruction).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -651,7 +659,12 @@ PT_DEV int world_query_lanes(const PtKArgs &a, const Ray &r, double tmax, double
     const unsigned *occ_shared = (const unsigned *)pt_lds_masks;
     // the part of the ray inside the grid's box: [t0, t1] (slabs; a zero component: inside the slab or never)
     float t0 = 0.0f, t1 = ANYHIT ? (float)tmax * (1.0f + 1e-5f) : INFINITY;
-    bool walking = active && !(ANYHIT && best >= 0);
+    // A ray that starts very far from the grid (a far point of an unbounded plane, a distant mirror): the fp32 copy of
+    // its origin is off by ~6e-8 |o|, which the margin the spheres were entered with (sized from the GRID's coordinates,
+    // pt_scene_upload) no longer covers.  Such a lane does not walk; it runs every sphere's ball through the
+    // conservative filter below, whose slack does scale with |o| (eo).
+    const bool far = active && !(eo <= ga->grid_far_eo);  // (NaN origin: far)
+    bool walking = active && !far && !(ANYHIT && best >= 0);
     {
       const float lo_[3] = {bx0, by0, bz0}, hi_[3] = {ga->grid_max[0], ga->grid_max[1], ga->grid_max[2]};
       const float o_[3] = {ofx, ofy, ofz}, d_[3] = {dfx, dfy, dfz};
@@ -758,6 +771,12 @@ PT_DEV int world_query_lanes(const PtKArgs &a, const Ray &r, double tmax, double
       }
       flush();
       if (ANYHIT && best >= 0) walking = false;
+    }
+    if (__ballot(far) != 0ULL) {  // (rare: see above) every sphere for the far lanes, one ball per turn
+      for (int slot = 0; slot < ns; ++slot) {
+        const bool cand = far && !(ANYHIT && best >= 0) && !reject1(bsx[slot], bsy[slot], bsz[slot], bsr[slot], ofx, ofy, ofz, dfx, dfy, dfz, dd, eo, dd8);
+        if (__ballot(cand) != 0ULL) visit2(slot, cand, 0, false);
+      }
     }
     // planes, then done
     for (int k = ns; k < n; ++k) {
@@ -3461,6 +3480,8 @@ PT_DEV void path_tree(const PtKArgs &a) {
   // small worlds: the wave-uniform loop over every shape (records through the scalar cache) has a shorter critical
   // path than per-lane candidate lists -- and a round's latency, not its throughput, is what a pixel's tree waits for
   const bool uniform_loop = a.n_shapes <= cold_args(a)->tree_uniform_max;
+  const bool fuse_on = cold_args(a)->tree_fuse != 0;
+  int b_last = N / 2;  // survivors of the last complete leaf family (wave-uniform): where the next one's guesses are centred
   // lane r of a leaf round: row = child offset in the round, col = hypothesis b (0..row); rows with row(row+1)/2 + row < 64
   int tri_row = 0;
   while ((tri_row + 1) * (tri_row + 2) / 2 <= lane) ++tri_row;
@@ -3566,7 +3587,7 @@ PT_DEV void path_tree(const PtKArgs &a) {
   // cycles of this wave in: 0 fetch + cull, 1 primary ray, 2 state jump + scatter, 3 scattered-ray query, 4 shade,
   // 5 commit, 6 node returns; 7: rounds
   unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
-  unsigned long long dbg_leaf_rounds = 0, dbg_committed = 0, dbg_traced = 0, dbg_max_rounds = 0;
+  unsigned long long dbg_leaf_rounds = 0, dbg_committed = 0, dbg_traced = 0, dbg_max_rounds = 0, dbg_fused = 0, dbg_fused_hit = 0;
 #define PT_TT(k) do { const unsigned long long tn = __builtin_amdgcn_s_memtime(); tsum[k] += tn - tprev; tprev = tn; } while (0)
 #else
 #define PT_TT(k) do { } while (0)
@@ -3706,12 +3727,37 @@ PT_DEV void path_tree(const PtKArgs &a) {
           row = lane;
           ahead = (unsigned)lane * cpred;
         }
-        const bool act = row < nrows;
+        bool act = row < nrows;
+        // A WHOLE leaf family leaves lanes over (ten leaves: 55 of 64).  Where the family ends is known up to the number
+        // b of its members that survive roulette on a diffuse surface -- N * c0 + 2N * b draws -- so the spare lanes
+        // trace the NEXT sibling of this node (a child of its parent, one level up) from those states in the same round:
+        // when the family commits in full and b is among the guesses, the sibling's ray is already traced when the node
+        // returns, and a parent whose children all branch costs one round per child instead of two.
+        const int leaf_lanes = nrows * (nrows + 1) / 2;
+        TreeNode par = top;
+        bool fused = leaf && sp >= 2 && top.next == 0 && nrows == N && leaf_lanes < 64 && fuse_on;
+        if (fused) {
+          frame_get(sp - 2, par);
+          fused = par.next < N;
+        }
+        // (the spare lanes cover nh consecutive values of b around what the last complete family had)
+        const int nh = (64 - leaf_lanes) < (N + 1) ? (64 - leaf_lanes) : (N + 1);
+        int bmin = b_last - nh / 2;
+        bmin = bmin < 0 ? 0 : (bmin > N + 1 - nh ? N + 1 - nh : bmin);
+        const bool sib = fused && lane >= leaf_lanes && lane - leaf_lanes < nh;  // hypothesis b = bmin + lane - leaf_lanes
+        if (sib) {
+          act = true;
+          row = -1;
+          ahead = (unsigned)N * c0 + 2u * (unsigned)N * (unsigned)(bmin + lane - leaf_lanes);
+        }
         pcg.state = act ? pcg_advance(gstate, ginc, ahead) : gstate;
         pcg.inc = ginc;
         pcg.n = 0;
         const unsigned long long st_start = pcg.state;
-        ray = scatter_ray<true>(top.brdf, pcg, top.in, top.wp, top.n);  // materials.py:132-152, 175-196
+        {
+          const V3 n_in = sib ? par.in : top.in, n_wp = sib ? par.wp : top.wp, n_n = sib ? par.n : top.n;
+          ray = scatter_ray<true>(sib ? par.brdf : top.brdf, pcg, n_in, n_wp, n_n);  // materials.py:132-152, 175-196
+        }
         PT_TT(2);
         double ts = INFINITY;
         int hs;
@@ -3720,7 +3766,7 @@ PT_DEV void path_tree(const PtKArgs &a) {
         else
           hs = world_query_lanes<false>(a, ray, INFINITY, ts, act, diag_lds);
         PT_TT(3);
-        if (act) shade_ray(hs, ts, sp);
+        if (act) shade_ray(hs, ts, sib ? sp - 1 : sp);
         PT_TT(4);
 #ifdef PT_DEBUG_TIME
         tsum[7] += 1;
@@ -3731,10 +3777,9 @@ PT_DEV void path_tree(const PtKArgs &a) {
         // ---- commit in child order ----
         unsigned long long expect = gstate;
         bool pushed = false;
-        for (int r = 0; r < nrows; ++r) {
-          const unsigned long long m = __ballot(act && row == r && st_start == expect);
-          if (!m) break;  // nobody traced child r from the right state: next round
-          const int src = __ffsll((long long)m) - 1;
+        // child `src` of the node in `top` counts: add its value up, or put its node on the stack
+        unsigned fam_draws = 0;
+        auto commit_child = [&](int src) {
           prays += 1ULL;
           top.next++;
           expect = rl_u64(pcg.state, src);
@@ -3744,6 +3789,7 @@ PT_DEV void path_tree(const PtKArgs &a) {
             top.cum.y = top.cum.y + top.hc.y * val.y;
             top.cum.z = top.cum.z + top.hc.z * val.z;
             cpred = (unsigned)__builtin_amdgcn_readlane((int)pcg.n, src);
+            fam_draws += cpred;
           } else {  // the child has children of its own: its node goes on the stack, the siblings wait
             frame_put(sp - 1, top);
             TreeNode t;
@@ -3758,8 +3804,32 @@ PT_DEV void path_tree(const PtKArgs &a) {
             top = t;
             sp++;
             pushed = true;
-            break;
           }
+        };
+        for (int r = 0; r < nrows && !pushed; ++r) {
+          const unsigned long long m = __ballot(act && row == r && st_start == expect);
+          if (!m) break;  // nobody traced child r from the right state: next round
+          commit_child(__ffsll((long long)m) - 1);
+        }
+        if (leaf && top.next == N && nrows == N && fam_draws >= (unsigned)N * c0)
+          b_last = (int)((fam_draws - (unsigned)N * c0) / (2u * (unsigned)N));
+#ifdef PT_DEBUG_TIME
+        if (fused) dbg_fused += 1;
+#endif
+        if (fused && top.next == N) {
+          // the leaf family is complete: its node returns now (render.py:139), and its parent's next child may be there
+          const V3 val = {top.em.x + top.cum.x * invN, top.em.y + top.cum.y * invN, top.em.z + top.cum.z * invN};
+          sp--;
+          top = par;
+          top.cum.x = top.cum.x + top.hc.x * val.x;
+          top.cum.y = top.cum.y + top.hc.y * val.y;
+          top.cum.z = top.cum.z + top.hc.z * val.z;
+          cpred = base_draws();
+          const unsigned long long m = __ballot(sib && st_start == expect);
+          if (m) commit_child(__ffsll((long long)m) - 1);
+#ifdef PT_DEBUG_TIME
+          if (m) dbg_fused_hit += 1;
+#endif
         }
         gstate = expect;
         if (pushed) cpred = base_draws();
@@ -3791,7 +3861,7 @@ PT_DEV void path_tree(const PtKArgs &a) {
 #ifdef PT_DEBUG_TIME
   if (lane == 0) {
     for (int q = 0; q < 8; ++q) atomicAdd(pt_queue(a) + 1 + q, tsum[q]);
-    atomicAdd(pt_queue(a) + 12, dbg_leaf_rounds);
+    atomicAdd(pt_queue(a) + 12, dbg_leaf_rounds | (dbg_fused << 24) | (dbg_fused_hit << 44));
     atomicAdd(pt_queue(a) + 13, dbg_committed);
     atomicAdd(pt_queue(a) + 14, dbg_traced);
     atomicMax(pt_queue(a) + 15, dbg_max_rounds);

@@ -100,6 +100,7 @@ struct PtKArgs {
   const float4 *grid_balls;
   const unsigned short *grid_slots;
   const int *grid_always;
+  float grid_far_eo;                // a ray whose 1e-6 * max|origin component| exceeds this is too far away for the walk's margins
   int grid_n_always, grid_occ_lds;  // grid_occ_lds: where the kernel staged grid_occ in LDS (4-byte words), -1: read it from memory
   int grid_res[3];
   float grid_min[3], grid_max[3], grid_cell[3], grid_inv[3];
@@ -117,6 +118,7 @@ struct PtKArgs {
   const int4 *units;               // path tracer, second pass: (region, first flagged pixel | pixels << 8, region mask) per work unit
   int dome_slot;                   // path tracer, first pass: the sphere the camera is deepest inside (uniform pigments), or -1
   int dome_shortcut;               // 0: every tile goes through rays (pt_set_dome_shortcut; a measurement switch)
+  int tree_fuse;                   // pt_path_tree_kernel: spare lanes of a leaf round trace the parent's next child (1) or idle (0)
   int tree_uniform_max;            // pt_path_tree_kernel: worlds up to this many shapes are queried by the wave-uniform loop
   int dbg_trace_unit;              // -DPT_DEBUG_TIME builds: the unit whose steps are traced (PTRACE_TRACE_UNIT)
   int spec_draws;                  // ... PT_PCG_PIXEL: draws per sample assumed for a pixel nothing is known about yet

@@ -55,6 +55,7 @@ struct pt_scene {
   unsigned short *grid_slots = nullptr;
   int *grid_always = nullptr;
   int grid_n_always = 0, grid_n_cells = 0, grid_res[3] = {0, 0, 0};
+  float grid_far_eo = INFINITY;  // rays with 1e-6 * max|origin component| above this do not walk the grid (see world_query_lanes)
   float grid_min[3] = {0, 0, 0}, grid_max[3] = {0, 0, 0}, grid_cell[3] = {0, 0, 0}, grid_inv[3] = {0, 0, 0};
   float *bsoa = nullptr;  // bounds as x[], y[], z[], r'[] (bs_stride floats each), then group and chunk balls
   int bs_stride = 0, gs_stride = 0, cs_stride = 0, bs_levels = 0;
@@ -678,6 +679,10 @@ extern "C" int pt_scene_upload(const pt_scene_desc *d, int device, pt_scene **ou
         UP(upload(&s->grid_balls, balls));
         UP(upload(&s->grid_always, always));
         s->grid_n_always = (int)always.size();
+        // the margin a sphere is entered with, >= 1e-4 * cmax, covers the fp32 copy of a ray whose origin lies within
+        // ~100 x the grid's coordinates (1.2e-7 |o| <= a quarter of the margin); a ray from farther away takes the
+        // exhaustive filter instead of the walk
+        s->grid_far_eo = (float)(1e-4 * cmax);
         s->grid_n_cells = (int)ncell;
       }
     }
@@ -820,6 +825,7 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
   a.grid_slots = s->grid_slots;
   a.grid_always = s->grid_always;
   a.grid_n_always = s->grid_n_always;
+  a.grid_far_eo = s->grid_far_eo;
   a.grid_occ_lds = -1;
   a.scene_lds = -1;
   for (int q = 0; q < 3; ++q) {
@@ -1082,6 +1088,8 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
     a.dome_slot = -1;
     static const int env_tumax = getenv("PTRACE_TREE_UNIFORM_MAX") ? atoi(getenv("PTRACE_TREE_UNIFORM_MAX")) : 0;  // (measured on C3, N = 10: the uniform loop 2.48 ms, candidate lists 1.92)
     a.tree_uniform_max = env_tumax;
+    static const int env_tfuse = getenv("PTRACE_TREE_FUSE") ? atoi(getenv("PTRACE_TREE_FUSE")) : 1;
+    a.tree_fuse = env_tfuse;
     static const int env_trace = getenv("PTRACE_TRACE_UNIT") ? atoi(getenv("PTRACE_TRACE_UNIT")) : 0;
     a.dbg_trace_unit = env_trace;
     static const int env_dome = getenv("PTRACE_PIXEL_DOME") ? atoi(getenv("PTRACE_PIXEL_DOME")) : 1;

@@ -214,6 +214,46 @@ def test_tree_kernel_in_a_world_without_a_dome(dev, oracle, n_rays, depth, rr):
         assert abs(int(st.n_rays) - n) <= 8 + n // 100000, (S, mode, int(st.n_rays), n)
 
 
+def test_rays_from_far_away_do_not_lose_spheres_to_the_grid(dev, oracle):
+    """the grid's insertion margin is sized from the grid's own coordinates, the walk uses an fp32 copy of the
+    ray -- a scattered ray starting ~1e4 grid extents away (here: reflected by a distant mirror back through a cluster
+    of > 1024 spheres, where the grid is on) deviates by more than that margin.  Such lanes take the exhaustive filter
+    (its slack scales with |o|); the frame must equal the oracle's bit for bit wherever no libm function is involved."""
+    from pytracer_amd import flatten, hostmodel as hm
+
+    g = hm.PCG(2024, 9)
+    r = g.random_float
+    w = hm.World()
+    for i in range(1100):
+        rad = 0.05 + 0.08 * r()
+        col = hm.Color(0.2 + 0.7 * r(), 0.2 + 0.7 * r(), 0.2 + 0.7 * r())
+        w.add_shape(hm.Sphere(hm.translation(hm.Vec(3.0 + 4.0 * r(), 4.0 * (r() - 0.5), 4.0 * (r() - 0.5))) * hm.scaling(hm.Vec(rad, rad, rad)),
+                              hm.Material(hm.DiffuseBRDF(hm.UniformPigment(hm.BLACK)), hm.UniformPigment(col))))
+    # a concave spherical mirror of radius 1e5 around the cluster: primary rays that pass between the spheres are
+    # reflected 1e5 away, converge behind the cluster and run back through it -- scattered rays with |o| ~ 1e5
+    w.add_shape(hm.Sphere(hm.translation(hm.Vec(5.0, 0.0, 0.0)) * hm.scaling(hm.Vec(1.0e5, 1.0e5, 1.0e5)),
+                          hm.Material(hm.SpecularBRDF(hm.UniformPigment(hm.Color(0.9, 0.9, 0.9))))))
+    scene = flatten.flatten_world(w)
+    W, H = 192, 128
+    cam = flatten.flatten_camera(hm.PerspectiveCamera(2.0, W / H, hm.translation(hm.Vec(-1.0, 0.0, 0.0))))
+    par = abi.make_params(W, H, abi.RENDERER_PATHTRACER, samples_per_side=0, num_of_rays=1, max_depth=2, rr_limit=5,
+                          path_state=45, path_seq=54, background=(0.0, 0.0, 0.0))
+    with dev.DeviceScene(scene) as ds:
+        out = ds.render(cam, par)
+        st = ds.stats()
+    ora, n = oracle.render(scene, cam, par, sqr_mode=oracle.SQR_MUL)
+    oracle.set_sqr_mode(oracle.SQR_POW)
+    reflected = int(st.n_rays) - W * H
+    assert reflected > 2000, f"only {reflected} rays came back from the mirror: the scene does not exercise far origins"
+    # pixels whose primary ray met the mirror (value = 0.9 x what came back) and whose reflected ray then met a sphere
+    _, n_primary_only = oracle.render(scene, cam, abi.copy_params(par, max_depth=0), sqr_mode=oracle.SQR_MUL)
+    assert n_primary_only == W * H
+    came_back_lit = int(((ora.sum(axis=-1) > 0) & (oracle.render(scene, cam, abi.copy_params(par, max_depth=0), sqr_mode=oracle.SQR_MUL)[0].sum(axis=-1) == 0)).sum())
+    assert came_back_lit > 300, f"only {came_back_lit} reflected rays meet a sphere of the cluster"
+    assert int(st.n_rays) == n
+    assert util.bits_equal(out, ora), f"{int((util.rel_err(out, ora) > 0).any(axis=-1).sum())} pixels differ"
+
+
 def _cluster_world(n, spread, seed, rotated=False):
     """n small spheres bunched around the view axis (many survivors per tile: exercises survivor-mask
     bits >= 31 and several culling passes), optionally with non-diagonal transforms, plus duplicates."""
