@@ -3489,26 +3489,10 @@ PT_DEV void path_tree(const PtKArgs &a) {
   int tri_rows = 0;  // rows that fit the wave: 10
   while ((tri_rows + 1) * (tri_rows + 2) / 2 <= 64) ++tri_rows;
 
-  auto frame_put = [&](int d, const TreeNode &t) {  // (lane 0 writes; the values are wave-uniform)
-    if (lane == 0) {
-      double *f = pt_lds_f64 + frames_lds + d * PT_TREE_FRAME;
-      f[0] = t.hc.x; f[1] = t.hc.y; f[2] = t.hc.z; f[3] = t.em.x; f[4] = t.em.y; f[5] = t.em.z;
-      f[6] = t.cum.x; f[7] = t.cum.y; f[8] = t.cum.z; f[9] = t.wp.x; f[10] = t.wp.y; f[11] = t.wp.z;
-      f[12] = t.n.x; f[13] = t.n.y; f[14] = t.n.z; f[15] = t.in.x; f[16] = t.in.y; f[17] = t.in.z;
-      f[18] = (double)t.brdf; f[19] = (double)t.next;
-    }
-  };
-  auto frame_get = [&](int d, TreeNode &t) {
-    const double *f = pt_lds_f64 + frames_lds + d * PT_TREE_FRAME;
-    t.hc = {f[0], f[1], f[2]};
-    t.em = {f[3], f[4], f[5]};
-    t.cum = {f[6], f[7], f[8]};
-    t.wp = {f[9], f[10], f[11]};
-    t.n = {f[12], f[13], f[14]};
-    t.in = {f[15], f[16], f[17]};
-    t.brdf = (int)f[18];
-    t.next = (int)f[19];
-  };
+  // node records live in LDS (frame d = the node at depth d of the current path through the tree); a wave's DS
+  // operations execute in order, so a record written by one lane is what every lane reads afterwards
+  auto frame = [&](int d) -> double * { return pt_lds_f64 + frames_lds + d * PT_TREE_FRAME; };
+  auto rfl_f64 = [&](double v) -> double { return rl_f64(v, 0); };  // (a broadcast LDS read, made scalar)
 
   // what a lane found out about the ray it traced (render.py:103-139 up to the recursion)
   bool o_term = true;            // the call returns without children of its own
@@ -3675,45 +3659,69 @@ PT_DEV void path_tree(const PtKArgs &a) {
       PT_TT(1);
       V3 sample_ret = rl_v3(o_ret, 0);
       gstate = rl_u64(pcg.state, 0);
-      int sp = 0;  // nodes on the stack (the node in `top` included)
-      TreeNode top;
-      top.hc = top.em = top.cum = top.wp = top.n = top.in = {0.0, 0.0, 0.0};
-      top.brdf = 0;
-      top.next = 0;
+      int sp = 0;  // nodes on the stack; the innermost one (frame sp - 1) is the node whose children are being traced
+      // of that node, in registers (wave-uniform): hit_color, the sum of its children so far, how many are done, its BRDF
+      V3 t_hc = {0.0, 0.0, 0.0}, t_cum = {0.0, 0.0, 0.0};
+      int t_next = 0, t_brdf = 0;
       unsigned cpred = 0;
-      if (!__builtin_amdgcn_readfirstlane((int)o_term)) {
-        top.hc = rl_v3(o_hc, 0);
-        top.em = rl_v3(o_em, 0);
-        top.wp = rl_v3(o_wp, 0);
-        top.n = rl_v3(o_n, 0);
-        top.in = rl_v3(ray.d, 0);
-        top.brdf = __builtin_amdgcn_readlane(o_brdf, 0);
-        sp = 1;
-      }
-      auto base_draws = [&]() -> unsigned {  // what a child of `top` draws when it needs no children: its scatter draws + roulette
-        return (top.brdf == PT_BRDF_DIFFUSE ? 2u : 0u) + (sp >= rr ? 1u : 0u);
+      // lane `src` traced a ray that needs children of its own: its node becomes frame sp (written by that lane itself)
+      auto push_node = [&](int src, V3 in_dir) {
+        if (sp > 0 && lane == 0) {  // the parent's running sum and child counter wait in its record
+          double *f = frame(sp - 1);
+          f[6] = t_cum.x; f[7] = t_cum.y; f[8] = t_cum.z;
+          f[19] = (double)t_next;
+        }
+        if (lane == src) {
+          double *f = frame(sp);
+          f[0] = o_hc.x; f[1] = o_hc.y; f[2] = o_hc.z; f[3] = o_em.x; f[4] = o_em.y; f[5] = o_em.z;
+          f[6] = 0.0; f[7] = 0.0; f[8] = 0.0; f[9] = o_wp.x; f[10] = o_wp.y; f[11] = o_wp.z;
+          f[12] = o_n.x; f[13] = o_n.y; f[14] = o_n.z; f[15] = in_dir.x; f[16] = in_dir.y; f[17] = in_dir.z;
+          f[18] = (double)o_brdf; f[19] = 0.0;
+        }
+        t_hc = rl_v3(o_hc, src);
+        t_cum = {0.0, 0.0, 0.0};
+        t_next = 0;
+        t_brdf = __builtin_amdgcn_readlane(o_brdf, src);
+        sp++;
       };
-      if (sp) cpred = base_draws();
+      // render.py:139 for the innermost node, then render.py:137 in its parent, which becomes the innermost one
+      auto pop_node = [&]() -> V3 {
+        const double *f = frame(sp - 1);
+        const V3 val = {rfl_f64(f[3]) + t_cum.x * invN, rfl_f64(f[4]) + t_cum.y * invN, rfl_f64(f[5]) + t_cum.z * invN};
+        sp--;
+        if (sp > 0) {
+          const double *g = frame(sp - 1);
+          t_hc = {rfl_f64(g[0]), rfl_f64(g[1]), rfl_f64(g[2])};
+          t_cum = {rfl_f64(g[6]), rfl_f64(g[7]), rfl_f64(g[8])};
+          t_brdf = (int)rfl_f64(g[18]);
+          t_next = (int)rfl_f64(g[19]);
+          t_cum.x = t_cum.x + t_hc.x * val.x;
+          t_cum.y = t_cum.y + t_hc.y * val.y;
+          t_cum.z = t_cum.z + t_hc.z * val.z;
+        }
+        return val;
+      };
+      auto base_draws = [&]() -> unsigned {  // what a child of the innermost node draws when it needs no children: scatter + roulette
+        return (t_brdf == PT_BRDF_DIFFUSE ? 2u : 0u) + (sp >= rr ? 1u : 0u);
+      };
+      if (!__builtin_amdgcn_readfirstlane((int)o_term)) {
+        push_node(0, ray.d);
+        cpred = base_draws();
+      }
       // ---- the tree under the primary hit ----
       while (sp > 0) {
-        const int remaining = N - top.next;
+        const int remaining = N - t_next;
         if (remaining <= 0) {
-          // render.py:139: the node returns; its parent adds hit_color * value (render.py:137) and goes on
-          const V3 val = {top.em.x + top.cum.x * invN, top.em.y + top.cum.y * invN, top.em.z + top.cum.z * invN};
-          sp--;
+          const V3 val = pop_node();
           if (sp == 0) {
             sample_ret = val;
             break;
           }
-          frame_get(sp - 1, top);
-          top.cum.x = top.cum.x + top.hc.x * val.x;
-          top.cum.y = top.cum.y + top.hc.y * val.y;
-          top.cum.z = top.cum.z + top.hc.z * val.z;
           cpred = base_draws();
           PT_TT(6);
           continue;
         }
-        // ---- a round: children top.next .. of this node, depth sp, each from a speculated state ----
+        // ---- a round: children t_next .. of this node, depth sp, each from a speculated state ----
         const unsigned c0 = base_draws();
         const bool leaf = sp == D;  // (children of the children are beyond max_depth)
         int row, nrows;
@@ -3734,12 +3742,8 @@ PT_DEV void path_tree(const PtKArgs &a) {
         // when the family commits in full and b is among the guesses, the sibling's ray is already traced when the node
         // returns, and a parent whose children all branch costs one round per child instead of two.
         const int leaf_lanes = nrows * (nrows + 1) / 2;
-        TreeNode par = top;
-        bool fused = leaf && sp >= 2 && top.next == 0 && nrows == N && leaf_lanes < 64 && fuse_on;
-        if (fused) {
-          frame_get(sp - 2, par);
-          fused = par.next < N;
-        }
+        bool fused = leaf && sp >= 2 && t_next == 0 && nrows == N && leaf_lanes < 64 && fuse_on;
+        if (fused) fused = (int)rfl_f64(frame(sp - 2)[19]) < N;
         // (the spare lanes cover nh consecutive values of b around what the last complete family had)
         const int nh = (64 - leaf_lanes) < (N + 1) ? (64 - leaf_lanes) : (N + 1);
         int bmin = b_last - nh / 2;
@@ -3750,13 +3754,19 @@ PT_DEV void path_tree(const PtKArgs &a) {
           row = -1;
           ahead = (unsigned)N * c0 + 2u * (unsigned)N * (unsigned)(bmin + lane - leaf_lanes);
         }
+        // (what the last round found out is dead: said explicitly, so that it holds no registers across the query)
+        o_term = true;
+        o_ret = o_hc = o_em = o_wp = {0.0, 0.0, 0.0};
+        o_n = {0.0, 0.0, 1.0};
+        o_brdf = 0;
         pcg.state = act ? pcg_advance(gstate, ginc, ahead) : gstate;
         pcg.inc = ginc;
         pcg.n = 0;
         const unsigned long long st_start = pcg.state;
         {
-          const V3 n_in = sib ? par.in : top.in, n_wp = sib ? par.wp : top.wp, n_n = sib ? par.n : top.n;
-          ray = scatter_ray<true>(sib ? par.brdf : top.brdf, pcg, n_in, n_wp, n_n);  // materials.py:132-152, 175-196
+          const double *f = frame(sib ? sp - 2 : sp - 1);  // the node the ray leaves from
+          const V3 n_wp = {f[9], f[10], f[11]}, n_n = {f[12], f[13], f[14]}, n_in = {f[15], f[16], f[17]};
+          ray = scatter_ray<true>((int)f[18], pcg, n_in, n_wp, n_n);  // materials.py:132-152, 175-196
         }
         PT_TT(2);
         double ts = INFINITY;
@@ -3777,32 +3787,21 @@ PT_DEV void path_tree(const PtKArgs &a) {
         // ---- commit in child order ----
         unsigned long long expect = gstate;
         bool pushed = false;
-        // child `src` of the node in `top` counts: add its value up, or put its node on the stack
         unsigned fam_draws = 0;
+        // child `src` of the innermost node counts: add its value up, or put its node on the stack
         auto commit_child = [&](int src) {
           prays += 1ULL;
-          top.next++;
+          t_next++;
           expect = rl_u64(pcg.state, src);
           if (__builtin_amdgcn_readlane((int)o_term, src)) {
             const V3 val = rl_v3(o_ret, src);
-            top.cum.x = top.cum.x + top.hc.x * val.x;  // render.py:137
-            top.cum.y = top.cum.y + top.hc.y * val.y;
-            top.cum.z = top.cum.z + top.hc.z * val.z;
+            t_cum.x = t_cum.x + t_hc.x * val.x;  // render.py:137
+            t_cum.y = t_cum.y + t_hc.y * val.y;
+            t_cum.z = t_cum.z + t_hc.z * val.z;
             cpred = (unsigned)__builtin_amdgcn_readlane((int)pcg.n, src);
             fam_draws += cpred;
           } else {  // the child has children of its own: its node goes on the stack, the siblings wait
-            frame_put(sp - 1, top);
-            TreeNode t;
-            t.hc = rl_v3(o_hc, src);
-            t.em = rl_v3(o_em, src);
-            t.cum = {0.0, 0.0, 0.0};
-            t.wp = rl_v3(o_wp, src);
-            t.n = rl_v3(o_n, src);
-            t.in = rl_v3(ray.d, src);
-            t.brdf = __builtin_amdgcn_readlane(o_brdf, src);
-            t.next = 0;
-            top = t;
-            sp++;
+            push_node(src, ray.d);
             pushed = true;
           }
         };
@@ -3811,19 +3810,14 @@ PT_DEV void path_tree(const PtKArgs &a) {
           if (!m) break;  // nobody traced child r from the right state: next round
           commit_child(__ffsll((long long)m) - 1);
         }
-        if (leaf && top.next == N && nrows == N && fam_draws >= (unsigned)N * c0)
+        if (leaf && t_next == N && nrows == N && fam_draws >= (unsigned)N * c0)
           b_last = (int)((fam_draws - (unsigned)N * c0) / (2u * (unsigned)N));
 #ifdef PT_DEBUG_TIME
         if (fused) dbg_fused += 1;
 #endif
-        if (fused && top.next == N) {
-          // the leaf family is complete: its node returns now (render.py:139), and its parent's next child may be there
-          const V3 val = {top.em.x + top.cum.x * invN, top.em.y + top.cum.y * invN, top.em.z + top.cum.z * invN};
-          sp--;
-          top = par;
-          top.cum.x = top.cum.x + top.hc.x * val.x;
-          top.cum.y = top.cum.y + top.hc.y * val.y;
-          top.cum.z = top.cum.z + top.hc.z * val.z;
+        if (fused && t_next == N) {
+          // the leaf family is complete: its node returns now, and its parent's next child may be there already
+          (void)pop_node();
           cpred = base_draws();
           const unsigned long long m = __ballot(sib && st_start == expect);
           if (m) commit_child(__ffsll((long long)m) - 1);
@@ -3833,7 +3827,6 @@ PT_DEV void path_tree(const PtKArgs &a) {
         }
         gstate = expect;
         if (pushed) cpred = base_draws();
-        __builtin_amdgcn_wave_barrier();  // (frame_put by lane 0 before any lane's frame_get)
         PT_TT(5);
       }
       // imagetracer.py:94-97
@@ -3870,7 +3863,10 @@ PT_DEV void path_tree(const PtKArgs &a) {
   add_ray_count(a, lane == 0 ? nrays : 0ULL);
 }
 
-__global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 8))) void pt_path_tree_kernel(const PtKArgs a) {
+#ifndef PT_TREE_WAVES
+#define PT_TREE_WAVES 2
+#endif
+__global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_TREE_WAVES, 8))) void pt_path_tree_kernel(const PtKArgs a) {
   path_tree(a);
 }
 
