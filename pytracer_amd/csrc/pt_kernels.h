@@ -447,6 +447,8 @@ static __device__ void pt_dbg_flush() {
 // (the kernels' one dynamic LDS block, viewed as 64-bit words and as doubles; see pt_tile_kernel, path_trace)
 extern __shared__ unsigned long long pt_lds_masks[];
 extern __shared__ double pt_lds_f64[];
+typedef const __attribute__((address_space(3))) PtShapeRec *pt_lds_rec;  // the shapes' records when a kernel staged them in LDS
+typedef const __attribute__((address_space(3))) PtShapeAux *pt_lds_aux;
 
 // ---- closest hit, every lane on its own candidate list ---------------------------------------------------
 // The scattered rays of a wave point everywhere: for almost every sphere SOME lane's line meets it, so
@@ -2290,9 +2292,18 @@ PT_DEV void sphere_roots1(const PtKArgs &a, int slot, bool active, double tmin, 
   PT_SPHERE_ROOTS(slot);
 }
 
-template <int RENDERER>
+// SLDS (small worlds, Flat): the shapes' records (128 B + 256 B each) are staged in LDS by the workgroup and shading
+//   gathers from there instead of through the vector memory path (C2: 14.4 -> 13.9 us per frame).
+template <int RENDERER, bool SLDS = false>
 __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))) void pt_tile4_kernel(const PtKArgs a) {
   constexpr bool ANYHIT = RENDERER == PT_RENDERER_ONOFF;
+#ifdef PT_DEBUG_TIME
+  // cycles of this wave in: 0 prologue, 1 cone, 2 cull, 3 dome tile, 4 rays, 5 query, 6 shade, 7 store
+  unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
+#define PT_T4(k) do { const unsigned long long tn = __builtin_amdgcn_s_memtime(); tsum[k] += tn - tprev; tprev = tn; } while (0)
+#else
+#define PT_T4(k) do { } while (0)
+#endif
   int W, rows_local, npass;
   bool dome_on;
   {
@@ -2306,12 +2317,21 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))
   const int tx = blockIdx.x * 2 + (wib & 1), ty = blockIdx.y * 2 + (wib >> 1);
   unsigned long long nrays = 0, nres = 0;
   const bool valid = tx * 16 < W && ty * 16 < rows_local;  // (wave-uniform; the ray count below needs every wave)
+  if (SLDS) {  // recs[] then aux[] into LDS (8-byte words; every wave of the workgroup takes part)
+    const unsigned long long *src = (const unsigned long long *)a.recs;
+    for (int k = threadIdx.x; k < a.n_shapes * 16; k += PT_BLOCK) pt_lds_masks[k] = src[k];
+    src = (const unsigned long long *)a.aux;
+    for (int k = threadIdx.x; k < a.n_shapes * 32; k += PT_BLOCK) pt_lds_masks[a.n_shapes * 16 + k] = src[k];
+    __syncthreads();  // (measured: placing this barrier before the shading instead, behind cone / cull / query, gains nothing)
+  }
   if (valid) {
     // ---- cone + cull of the 16 x 16 tile ----
     const int lr0 = ty * 16, lr1 = (lr0 + 15 < rows_local) ? lr0 + 15 : rows_local - 1;
     const int gr0 = global_row(a, lr0);  // the tile's rows are consecutive image rows (host: n_ranks == 1 or row_block % 16 == 0)
     const float4 b_first = a.bounds[lane < a.n_shapes ? lane : 0];
+    PT_T4(0);
     const TileCone tc = tile_cone(a, tx * 16, (tx * 16 + 16 < W) ? tx * 16 + 16 : W, gr0, gr0 + (lr1 - lr0));
+    PT_T4(1);
     unsigned long long masks[4] = {0ULL, 0ULL, 0ULL, 0ULL};  // (npass <= 4: the host sends larger worlds elsewhere)
     int nsurv = 0, only = 0;
 #pragma unroll
@@ -2333,6 +2353,7 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))
         if (m) only = p * 64 + (__ffsll((long long)m) - 1);
       }
     }
+    PT_T4(2);
     // pixel k of this lane: quadrant (k & 1, k >> 1)
     const int colA = tx * 16 + (lane & 7), colB = colA + 8;
     const int lrowA = lr0 + (lane >> 3), lrowB = lrowA + 8;
@@ -2371,6 +2392,7 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))
         done = true;
       }
     }
+    PT_T4(3);
     if (!done) {
       // ---- the four primary rays (imagetracer.py:48-58, camera.py:103-124) ----
       V3 org, dir[4];
@@ -2404,6 +2426,7 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))
         bgy = c->bg[1];
         bgz = c->bg[2];
       }
+      PT_T4(4);
       // ---- World.ray_intersection over the survivors, four rays per visit ----
       const double tmin = 1.0e-5;
       Hit4 h4;
@@ -2469,6 +2492,7 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))
           }
         }
       }
+      PT_T4(5);
       // ---- shade + store ----
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -2482,30 +2506,43 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))
             c.z = ca->onoff[2];
           }
         } else if (hit >= 0) {  // render.py:65-74
-          const PtShapeAux *ax = cold_args(a)->aux + hit;
           Hit h;
           h.u = 0.0;
           h.v = 0.0;
-          if (ax->needs_uv) {
-            Ray rk;
-            rk.o = org;
-            rk.d = dir[k];
-            rk.tmin = tmin;
-            hit_details(a.recs + hit, ax, rk, h4.best_t[k], h, true);
+          Ray rk;
+          rk.o = org;
+          rk.d = dir[k];
+          rk.tmin = tmin;
+          V3 p1, p2;
+          if constexpr (SLDS) {
+            const pt_lds_rec rec = (pt_lds_rec)(const void *)pt_lds_f64 + hit;
+            const pt_lds_aux ax = (pt_lds_aux)(const void *)(pt_lds_f64 + a.n_shapes * 16) + hit;
+            if (ax->needs_uv) hit_details(rec, ax, rk, h4.best_t[k], h, true);
+            p1 = brdf_pigment(a, ax, h.u, h.v);
+            p2 = emitted_pigment(a, ax, h.u, h.v);
+          } else {
+            const PtShapeAux *ax = cold_args(a)->aux + hit;
+            if (ax->needs_uv) hit_details(a.recs + hit, ax, rk, h4.best_t[k], h, true);
+            p1 = brdf_pigment(a, ax, h.u, h.v);
+            p2 = emitted_pigment(a, ax, h.u, h.v);
           }
-          const V3 p1 = brdf_pigment(a, ax, h.u, h.v);
-          const V3 p2 = emitted_pigment(a, ax, h.u, h.v);
           c.x = p1.x + p2.x;
           c.y = p1.y + p2.y;
           c.z = p1.z + p2.z;
         }
+        PT_T4(6);
         if (act[k]) {
           store_pixel(a, pix[k], c);
           nrays += 1ULL;
         }
+        PT_T4(7);
       }
     }
   }
+#ifdef PT_DEBUG_TIME
+  if ((threadIdx.x & 63) == 0 && ((blockIdx.y * gridDim.x + blockIdx.x) & 15) == 0)
+    for (int q = 0; q < 8; ++q) atomicAdd(pt_queue(a) + 1 + q, tsum[q]);
+#endif
   add_ray_count(a, nrays, 0, nres, blockIdx.y * gridDim.x + blockIdx.x);
 }
 
@@ -2720,8 +2757,6 @@ PT_DEV long long next_pixel(const PtKArgs &a, bool need, long long npix) {
 #ifndef PT_REGIONS_INLINE
 #define PT_REGIONS_INLINE 1  // second pass: HitRecord / scatter / transcendental code inline (1) or behind calls (0)
 #endif
-typedef const __attribute__((address_space(3))) PtShapeRec *pt_lds_rec;
-typedef const __attribute__((address_space(3))) PtShapeAux *pt_lds_aux;
 template <bool TILED, bool LDSF, bool LAT, bool SLDS = false>
 PT_DEV void path_trace(const PtKArgs &a) {
   constexpr bool INL = LAT && PT_REGIONS_INLINE;

@@ -1169,11 +1169,26 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
   bool ev_started = false;
   if (tile4) {
     s->stats.kernel = PT_KERNEL_TILE4;
-    main_fn = p->renderer == PT_RENDERER_ONOFF ? (const void *)pt_tile4_kernel<PT_RENDERER_ONOFF> : (const void *)pt_tile4_kernel<PT_RENDERER_FLAT>;
-    if (p->renderer == PT_RENDERER_ONOFF)
+#ifdef PT_DEBUG_TIME
+    s->queue_last = s->queue;  // (a.qpar = 0: the section sums land in block 0)
+    HIP_TRY(hipMemsetAsync(s->queue, 0, 16 * sizeof(unsigned long long), st));
+    if (s->queue_parity == 0) s->queue_clean = false;
+#endif
+    // small worlds: the shapes' records ride in LDS for shading (Flat; OnOff reads none of them)
+    static const int env_t4lds = getenv("PTRACE_TILE4_LDS") ? atoi(getenv("PTRACE_TILE4_LDS")) : 1;
+    const size_t scene_bytes = (size_t)s->n_shapes * (sizeof(PtShapeRec) + sizeof(PtShapeAux));
+    const bool t4lds = env_t4lds != 0 && p->renderer == PT_RENDERER_FLAT && scene_bytes <= 24 * 1024;
+    s->stats.lds_bytes = t4lds ? (int)scene_bytes : 0;
+    if (p->renderer == PT_RENDERER_ONOFF) {
+      main_fn = (const void *)pt_tile4_kernel<PT_RENDERER_ONOFF>;
       hipExtLaunchKernelGGL((pt_tile4_kernel<PT_RENDERER_ONOFF>), grid4, dim3(PT_BLOCK), 0, st, ev_a, ev_b, 0, a);
-    else
+    } else if (t4lds) {
+      main_fn = (const void *)pt_tile4_kernel<PT_RENDERER_FLAT, true>;
+      hipExtLaunchKernelGGL((pt_tile4_kernel<PT_RENDERER_FLAT, true>), grid4, dim3(PT_BLOCK), scene_bytes, st, ev_a, ev_b, 0, a);
+    } else {
+      main_fn = (const void *)pt_tile4_kernel<PT_RENDERER_FLAT>;
       hipExtLaunchKernelGGL((pt_tile4_kernel<PT_RENDERER_FLAT>), grid4, dim3(PT_BLOCK), 0, st, ev_a, ev_b, 0, a);
+    }
   } else if (tile || path_tiled) {
 #ifdef PT_DEBUG_TIME
     if (p->renderer != PT_RENDERER_PATHTRACER) {

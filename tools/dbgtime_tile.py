@@ -16,6 +16,9 @@ _lib.lib().pt_debug_read_queue(ds._h, q)
 t = np.array([q[i] for i in range(1, 9)], dtype=np.float64)
 names = ["coords", "cone", "cull+LDS", "sample setup+primary ray", "tile query", "shade+accum", "store", "loop top"]
 nw = ((ds.stats().grid + 63) // 64) * 4  # sampled workgroups only
+if ds.stats().kernel == abi.KERNEL_TILE4:  # 16x16 tiles, one per wave; every 16th workgroup reports
+    names = ["prologue", "cone", "cull", "dome tile", "four rays", "query", "shade", "store"]
+    nw = ((ds.stats().grid + 15) // 16) * 4
 print("kernel ms", ds.stats().kernel_ms, "sampled waves", nw, "tiles/wave", 14400 / (ds.stats().grid * 4))
 for n, v in zip(names, t):
     print(f"{n:26s} {v / nw:10.0f} cycles/wave  {100 * v / t.sum():5.1f} %")
