@@ -214,6 +214,26 @@ def test_tree_kernel_in_a_world_without_a_dome(dev, oracle, n_rays, depth, rr):
         assert abs(int(st.n_rays) - n) <= 8 + n // 100000, (S, mode, int(st.n_rays), n)
 
 
+@pytest.mark.parametrize("W,H", [(17, 1), (1, 33), (16, 16), (15, 31), (33, 2), (2, 2)])
+def test_sixteen_by_sixteen_tiles_at_awkward_frame_sizes(dev, oracle, W, H):
+    """pt_tile4_kernel (OnOff / Flat, pixel-centre rays): frames narrower or lower than a tile, one pixel beyond a tile
+    edge, a 2x2-block grid with idle waves -- against the oracle, both renderers, with and without the dome shortcut."""
+    scene, cam = _synthetic(32, True, False, W, H)
+    for renderer in (abi.RENDERER_FLAT, abi.RENDERER_ONOFF):
+        par = abi.make_params(W, H, renderer)
+        ora, n_rays = oracle.render(scene, cam, par, sqr_mode=oracle.SQR_MUL)
+        oracle.set_sqr_mode(oracle.SQR_POW)
+        with dev.DeviceScene(scene) as ds:
+            for dome in (True, False):
+                ds.set_dome_shortcut(dome)
+                out = ds.render(cam, par)
+                st = ds.stats()
+                assert st.kernel == abi.KERNEL_TILE4
+                assert util.bits_equal(out, ora), (renderer, dome)
+                assert int(st.n_rays) == n_rays == W * H
+                assert (st.n_rays_resolved == 0) if not dome else (st.n_rays_resolved <= st.n_rays)
+
+
 def test_rays_from_far_away_do_not_lose_spheres_to_the_grid(dev, oracle):
     """the grid's insertion margin is sized from the grid's own coordinates, the walk uses an fp32 copy of the
     ray -- a scattered ray starting ~1e4 grid extents away (here: reflected by a distant mirror back through a cluster
