@@ -179,6 +179,24 @@ def test_c5_many_spheres_flat_vs_oracle(dev, oracle):
     assert util.bits_equal(out, ora)
 
 
+def test_tree_kernel_deep_and_wide(dev, oracle):
+    """The node stack of pt_path_tree_kernel at depth 14 (N = 2: up to 2^15 rays per pixel, roulette from depth 3 on) and a
+    family of 200 children (four rounds of 64 lanes per node) on a small frame, against the oracle."""
+    scene, cam = _synthetic(32, False, False, 24, 16)
+    for n_rays, depth, rr in ((2, 14, 3), (200, 1, 3), (3, 40, 2)):
+        par = abi.make_params(24, 16, abi.RENDERER_PATHTRACER, samples_per_side=1, num_of_rays=n_rays, max_depth=depth, rr_limit=rr,
+                              path_state=45, path_seq=54)
+        with dev.DeviceScene(scene) as ds:
+            out = ds.render(cam, par)
+            st = ds.stats()
+        assert st.kernel == abi.KERNEL_PATH_TREE
+        ora, n = oracle.render(scene, cam, par, sqr_mode=oracle.SQR_MUL)
+        oracle.set_sqr_mode(oracle.SQR_POW)
+        bad = int((util.rel_err(out, ora) > TOL).any(axis=-1).sum())
+        assert bad <= 1, (n_rays, depth, bad)
+        assert abs(int(st.n_rays) - n) <= 8 + n // 100000, (n_rays, depth, int(st.n_rays), n)
+
+
 @pytest.mark.parametrize("n_rays,depth,rr", [(3, 3, 2), (10, 2, 0), (5, 4, 3)])
 def test_tree_kernel_in_a_world_without_a_dome(dev, oracle, n_rays, depth, rr):
     """num_of_rays > 1 where scattered rays can MISS (no sphere around the scene), over mirrors (no scatter draws) and a
