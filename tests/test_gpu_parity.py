@@ -195,6 +195,19 @@ def test_tree_kernel_deep_and_wide(dev, oracle):
         bad = int((util.rel_err(out, ora) > TOL).any(axis=-1).sum())
         assert bad <= 1, (n_rays, depth, bad)
         assert abs(int(st.n_rays) - n) <= 8 + n // 100000, (n_rays, depth, int(st.n_rays), n)
+    # a rank's rows of a partitioned frame are the same bits (per-pixel seeds; the tree kernel takes one pixel per unit)
+    par = abi.make_params(24, 16, abi.RENDERER_PATHTRACER, samples_per_side=2, num_of_rays=4, max_depth=3, rr_limit=2,
+                          path_state=45, path_seq=54)
+    with dev.DeviceScene(scene) as ds:
+        full = ds.render(cam, par)
+        n_full = int(ds.stats().n_rays)
+        got, n_sum = np.zeros_like(full), 0
+        for rank in range(3):
+            p = abi.copy_params(par, n_ranks=3, rank=rank, row_block=5)
+            got[abi.rows_for_rank(16, 5, 3, rank)] = ds.render(cam, p)
+            assert ds.stats().kernel == abi.KERNEL_PATH_TREE
+            n_sum += int(ds.stats().n_rays)
+    assert util.bits_equal(got, full) and n_sum == n_full
 
 
 @pytest.mark.parametrize("n_rays,depth,rr", [(3, 3, 2), (10, 2, 0), (5, 4, 3)])

@@ -21,8 +21,12 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc4 -- $BENCH > $OUT/pmc
 # the path tracer's second pass on C3 alone (both PCG modes): instruction counts and duration per launch
 KB="python3 $ROOT/tools/kbench.py c3 --rounds 4"
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $OUT/pmc_c3 -- $KB > $OUT/pmc_c3.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_LDS SQ_INSTS_SMEM --output-format csv -d $OUT/pmc_c3_2 -- $KB > $OUT/pmc_c3_2.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_CVT SQ_INSTS_VMEM SQ_INSTS_BRANCH --output-format csv -d $OUT/pmc_c3_3 -- $KB > $OUT/pmc_c3_3.log 2>&1
 KB="python3 $ROOT/tools/kbench.py c3:sample --rounds 4"
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $OUT/pmc_c3s -- $KB > $OUT/pmc_c3s.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_LDS SQ_INSTS_SMEM --output-format csv -d $OUT/pmc_c3s_2 -- $KB > $OUT/pmc_c3s_2.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_CVT SQ_INSTS_VMEM SQ_INSTS_BRANCH --output-format csv -d $OUT/pmc_c3s_3 -- $KB > $OUT/pmc_c3s_3.log 2>&1
 # the CLI's default path tracer (N = 10, D = 3, one sample per pixel) on the C3 scene: pt_path_tree_kernel
 KB="python3 $ROOT/tools/kbench.py c3n10 --rounds 4"
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $OUT/pmc_tree -- $KB > $OUT/pmc_tree.log 2>&1
@@ -36,10 +40,10 @@ cd $ROOT
 python3 tools/pmc_summary.py $OUT/pmc_c5f $OUT/pmc_c5w --kernel "pt_tile_kernel<1, 4, true, false" --json $OUT/pmc_c5_tile.json --source "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate runs) on 'python3 tools/kbench.py c5 --rounds 4' (C5: 1280x720, 10 000 spheres, Flat); medians over the launches; tools/prof_bench.sh $TAG" > /dev/null
 python3 tools/pmc_summary.py $OUT/pmc_c5f $OUT/pmc_c5w --kernel "pt_cell_kernel" --json $OUT/pmc_c5_cell.json --source "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate runs) on 'python3 tools/kbench.py c5 --rounds 4'; medians over the launches; tools/prof_bench.sh $TAG" > /dev/null
 python3 tools/pmc_summary.py $OUT/pmc_tree $OUT/pmc_tree2 $OUT/pmc_tree3 --kernel "pt_path_tree_kernel" --json $OUT/pmc_c3n10_tree.json --source "rocprofv3 --pmc (three passes) on 'python3 tools/kbench.py c3n10 --rounds 4' (C3 scene, PathTracer N = 10, D = 3, S = 1: the CLI's defaults); medians over the launches; tools/prof_bench.sh $TAG" > /dev/null
-python3 tools/pmc_summary.py $OUT/pmc_c3 --kernel "pt_path_regions_kernel" --json $OUT/pmc_c3_second_pass.json --source "rocprofv3 --pmc on 'python3 tools/kbench.py c3 --rounds 4' (C3, PT_PCG_PIXEL); medians over the launches; tools/prof_bench.sh $TAG" > /dev/null
-python3 tools/pmc_summary.py $OUT/pmc_c3s --kernel "pt_path_regions_kernel" --json $OUT/pmc_c3_second_pass_sample.json --source "rocprofv3 --pmc on 'python3 tools/kbench.py c3:sample --rounds 4' (C3, PT_PCG_SAMPLE); medians over the launches; tools/prof_bench.sh $TAG" > /dev/null
+python3 tools/pmc_summary.py $OUT/pmc_c3 $OUT/pmc_c3_2 $OUT/pmc_c3_3 --kernel "pt_path_regions_kernel" --json $OUT/pmc_c3_second_pass.json --source "rocprofv3 --pmc on 'python3 tools/kbench.py c3 --rounds 4' (C3, PT_PCG_PIXEL); medians over the launches; tools/prof_bench.sh $TAG" > /dev/null
+python3 tools/pmc_summary.py $OUT/pmc_c3s $OUT/pmc_c3s_2 $OUT/pmc_c3s_3 --kernel "pt_path_regions_kernel" --json $OUT/pmc_c3_second_pass_sample.json --source "rocprofv3 --pmc on 'python3 tools/kbench.py c3:sample --rounds 4' (C3, PT_PCG_SAMPLE); medians over the launches; tools/prof_bench.sh $TAG" > /dev/null
 SRC="rocprofv3 --pmc (five separate passes: SQ issue counters, fp64 / integer instruction classes, fp32 / conversion classes, FETCH_SIZE, WRITE_SIZE) on 'python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline'; medians over the dispatches of the kernel; tools/prof_bench.sh $TAG"
-python3 tools/pmc_summary.py $OUT/pmc1 $OUT/pmc2 $OUT/pmc2b $OUT/pmc3 $OUT/pmc4 --kernel "pt_tile4_kernel<1>" --grid 235520 --json $OUT/pmc_c2.json --source "$SRC" > /dev/null
+python3 tools/pmc_summary.py $OUT/pmc1 $OUT/pmc2 $OUT/pmc2b $OUT/pmc3 $OUT/pmc4 --kernel "pt_tile4_kernel<1, true>" --grid 235520 --json $OUT/pmc_c2.json --source "$SRC" > /dev/null
 python3 tools/pmc_summary.py $OUT/pmc1 $OUT/pmc2 $OUT/pmc2b $OUT/pmc3 $OUT/pmc4 --kernel "pt_path_regions_kernel" --grid 131072 --json $OUT/pmc_path_second_pass.json --source "$SRC (all second-pass launches of the run: C3, C4, shares)" > /dev/null || true
 f=$(find $OUT/trace -name "*kernel_stats.csv" | head -1)
 cp $f $OUT/kernel_stats.csv
