@@ -2294,8 +2294,12 @@ PT_DEV void sphere_roots1(const PtKArgs &a, int slot, bool active, double tmin, 
 
 // SLDS (small worlds, Flat): the shapes' records (128 B + 256 B each) are staged in LDS by the workgroup and shading
 //   gathers from there instead of through the vector memory path (C2: 14.4 -> 13.9 us per frame).
-template <int RENDERER, bool SLDS = false>
+// NPX = 4: 16x16 tiles, four pixels per lane.  NPX = 2: 16x8 tiles, two pixels per lane (the upper two quadrants only) --
+//   twice the waves with half the pixels each, for frames whose 16x16 tiles would not fill the chip.
+template <int RENDERER, bool SLDS = false, int NPX = 4>
 __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))) void pt_tile4_kernel(const PtKArgs a) {
+  static_assert(NPX == 2 || NPX == 4, "two or four pixels per lane");
+  constexpr int TH = NPX == 4 ? 16 : 8;  // tile height
   constexpr bool ANYHIT = RENDERER == PT_RENDERER_ONOFF;
 #ifdef PT_DEBUG_TIME
   // cycles of this wave in: 0 prologue, 1 cone, 2 cull, 3 dome tile, 4 rays, 5 query, 6 shade, 7 store
@@ -2316,7 +2320,7 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))
   const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
   const int tx = blockIdx.x * 2 + (wib & 1), ty = blockIdx.y * 2 + (wib >> 1);
   unsigned long long nrays = 0, nres = 0;
-  const bool valid = tx * 16 < W && ty * 16 < rows_local;  // (wave-uniform; the ray count below needs every wave)
+  const bool valid = tx * 16 < W && ty * TH < rows_local;  // (wave-uniform; the ray count below needs every wave)
   if (SLDS) {  // recs[] then aux[] into LDS (8-byte words; every wave of the workgroup takes part)
     const unsigned long long *src = (const unsigned long long *)a.recs;
     for (int k = threadIdx.x; k < a.n_shapes * 16; k += PT_BLOCK) pt_lds_masks[k] = src[k];
@@ -2326,7 +2330,7 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))
   }
   if (valid) {
     // ---- cone + cull of the 16 x 16 tile ----
-    const int lr0 = ty * 16, lr1 = (lr0 + 15 < rows_local) ? lr0 + 15 : rows_local - 1;
+    const int lr0 = ty * TH, lr1 = (lr0 + TH - 1 < rows_local) ? lr0 + TH - 1 : rows_local - 1;
     const int gr0 = global_row(a, lr0);  // the tile's rows are consecutive image rows (host: n_ranks == 1 or row_block % 16 == 0)
     const float4 b_first = a.bounds[lane < a.n_shapes ? lane : 0];
     PT_T4(0);
@@ -2357,7 +2361,7 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))
     // pixel k of this lane: quadrant (k & 1, k >> 1)
     const int colA = tx * 16 + (lane & 7), colB = colA + 8;
     const int lrowA = lr0 + (lane >> 3), lrowB = lrowA + 8;
-    const bool okcA = colA < W, okcB = colB < W, okrA = lrowA < rows_local, okrB = lrowB < rows_local;
+    const bool okcA = colA < W, okcB = colB < W, okrA = lrowA < rows_local, okrB = NPX == 4 && lrowB < rows_local;
     const bool act[4] = {okcA && okrA, okcB && okrA, okcA && okrB, okcB && okrB};
     const int ccA = okcA ? colA : W - 1, ccB = okcB ? colB : W - 1;  // idle lanes stand on a real pixel
     const int crA = okrA ? lrowA : rows_local - 1, crB = okrB ? lrowB : rows_local - 1;
@@ -2383,7 +2387,7 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))
           c.z = p1.z + p2.z;
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
+        for (int k = 0; k < NPX; ++k)
           if (act[k]) {
             store_pixel(a, pix[k], c);
             nrays += 1ULL;
@@ -2432,7 +2436,7 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))
       Hit4 h4;
       bool fast = true;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
+      for (int k = 0; k < NPX; ++k) {
         h4.best_t[k] = INFINITY;
         h4.best[k] = -1;
         Ray rk;
@@ -2454,7 +2458,7 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))
               pt_kdouble h = PT_KD(&a.hoist_diag[slot]);
               const double s0 = h[0], s1 = h[1], s2 = h[2], ox = h[3], oy = h[4], oz = h[5], cc = h[6];
 #pragma unroll
-              for (int k = 0; k < 4; ++k) {
+              for (int k = 0; k < NPX; ++k) {
                 const double dx = dir[k].x * s0, dy = dir[k].y * s1, dz = dir[k].z * s2;
                 const double aa = dx * dx + dy * dy + dz * dz;
                 sphere_roots1<ANYHIT>(a, slot, act[k], tmin, ox, oy, oz, dx, dy, dz, aa, cc, h4.best_t[k], h4.best[k]);
@@ -2464,7 +2468,7 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))
               pt_kdouble h = PT_KD(&a.hoist[slot]);
               const double ox = h[0], oy = h[1], oz = h[2], cc = h[3];
 #pragma unroll
-              for (int k = 0; k < 4; ++k) {
+              for (int k = 0; k < NPX; ++k) {
                 const double dx = dir[k].x * m[0] + dir[k].y * m[1] + dir[k].z * m[2];
                 const double dy = dir[k].x * m[4] + dir[k].y * m[5] + dir[k].z * m[6];
                 const double dz = dir[k].x * m[8] + dir[k].y * m[9] + dir[k].z * m[10];
@@ -2477,7 +2481,7 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))
             const double oz = PT_KD(&a.hoist[slot])[2];
             const double tmax = INFINITY;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < NPX; ++k) {
               const double dz = dir[k].x * m[8] + dir[k].y * m[9] + dir[k].z * m[10];
               const bool active = act[k];
               double &best_t = h4.best_t[k];
@@ -2495,7 +2499,7 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))
       PT_T4(5);
       // ---- shade + store ----
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
+      for (int k = 0; k < NPX; ++k) {
         V3 c = {bgx, bgy, bgz};
         const int hit = h4.best[k];
         if (RENDERER == PT_RENDERER_ONOFF) {  // render.py:52-53

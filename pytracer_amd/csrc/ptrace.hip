@@ -21,6 +21,9 @@
 #include "pt_layout.h"
 #include "pt_post.h"
 
+#ifndef PT_TILE4_NPX_SMALL
+#define PT_TILE4_NPX_SMALL 4  // pixels per lane of pt_tile4_kernel on frames with few 16x16 tiles (2: measured slower)
+#endif
 #define PT_VERSION ((1 << 16) | 1)
 
 static thread_local char g_err[512] = "";
@@ -967,8 +970,13 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
                      (p->renderer == PT_RENDERER_ONOFF || p->renderer == PT_RENDERER_FLAT) &&
                      (a.n_ranks == 1 || a.row_block % 16 == 0);
   dim3 grid4(1, 1, 1);
+  // two pixels per lane (16x8 tiles) where the 16x16 tiles of the frame are fewer than the waves the chip holds
+  static const int env_npx = getenv("PTRACE_TILE4_NPX") ? atoi(getenv("PTRACE_TILE4_NPX")) : 0;
+  const long long tiles16 = (long long)((p->width + 15) / 16) * ((rows + 15) / 16);
+  const int npx = env_npx == 2 || env_npx == 4 ? env_npx : (tiles16 < (long long)s->n_cu * 4 * 5 ? PT_TILE4_NPX_SMALL : 4);
   if (tile4) {
-    grid4 = dim3((unsigned)(((p->width + 15) / 16 + 1) / 2), (unsigned)(((rows + 15) / 16 + 1) / 2), 1);
+    const int th = npx == 4 ? 16 : 8;
+    grid4 = dim3((unsigned)(((p->width + 15) / 16 + 1) / 2), (unsigned)(((rows + th - 1) / th + 1) / 2), 1);
     grid = (int)(grid4.x * grid4.y);
   }
   int grid_first = 0;  // path tracer, first pass (pt_tile_kernel<PATHTRACER>): one wave per 8x8 region
@@ -1179,16 +1187,19 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
     const size_t scene_bytes = (size_t)s->n_shapes * (sizeof(PtShapeRec) + sizeof(PtShapeAux));
     const bool t4lds = env_t4lds != 0 && p->renderer == PT_RENDERER_FLAT && scene_bytes <= 24 * 1024;
     s->stats.lds_bytes = t4lds ? (int)scene_bytes : 0;
+#define PT_LAUNCH4(R, L, N, LDSB)                                                                                  \
+  do {                                                                                                             \
+    main_fn = (const void *)pt_tile4_kernel<R, L, N>;                                                              \
+    hipExtLaunchKernelGGL((pt_tile4_kernel<R, L, N>), grid4, dim3(PT_BLOCK), LDSB, st, ev_a, ev_b, 0, a);          \
+  } while (0)
     if (p->renderer == PT_RENDERER_ONOFF) {
-      main_fn = (const void *)pt_tile4_kernel<PT_RENDERER_ONOFF>;
-      hipExtLaunchKernelGGL((pt_tile4_kernel<PT_RENDERER_ONOFF>), grid4, dim3(PT_BLOCK), 0, st, ev_a, ev_b, 0, a);
+      if (npx == 4) PT_LAUNCH4(PT_RENDERER_ONOFF, false, 4, 0); else PT_LAUNCH4(PT_RENDERER_ONOFF, false, 2, 0);
     } else if (t4lds) {
-      main_fn = (const void *)pt_tile4_kernel<PT_RENDERER_FLAT, true>;
-      hipExtLaunchKernelGGL((pt_tile4_kernel<PT_RENDERER_FLAT, true>), grid4, dim3(PT_BLOCK), scene_bytes, st, ev_a, ev_b, 0, a);
+      if (npx == 4) PT_LAUNCH4(PT_RENDERER_FLAT, true, 4, scene_bytes); else PT_LAUNCH4(PT_RENDERER_FLAT, true, 2, scene_bytes);
     } else {
-      main_fn = (const void *)pt_tile4_kernel<PT_RENDERER_FLAT>;
-      hipExtLaunchKernelGGL((pt_tile4_kernel<PT_RENDERER_FLAT>), grid4, dim3(PT_BLOCK), 0, st, ev_a, ev_b, 0, a);
+      if (npx == 4) PT_LAUNCH4(PT_RENDERER_FLAT, false, 4, 0); else PT_LAUNCH4(PT_RENDERER_FLAT, false, 2, 0);
     }
+#undef PT_LAUNCH4
   } else if (tile || path_tiled) {
 #ifdef PT_DEBUG_TIME
     if (p->renderer != PT_RENDERER_PATHTRACER) {
