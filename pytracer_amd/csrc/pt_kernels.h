@@ -1075,6 +1075,20 @@ PT_DEV int global_row(const PtKArgs &a, int lrow) {
   return (blk * nr + c->rank) * rb + (lrow - blk * rb);
 }
 
+// (f32: the output format, read once by the caller -- every read of the argument block is a scalar load of its own)
+PT_DEV void store_pixel(const PtKArgs &a, long long pix, V3 v, bool f32) {
+  if (f32) {
+    float *o = (float *)a.out + pix * 3;
+    o[0] = (float)v.x;
+    o[1] = (float)v.y;
+    o[2] = (float)v.z;
+  } else {
+    double *o = (double *)a.out + pix * 3;
+    o[0] = v.x;
+    o[1] = v.y;
+    o[2] = v.z;
+  }
+}
 PT_DEV void store_pixel(const PtKArgs &a, long long pix, V3 v) {
   pt_kargs c = cold_args(a);
   if (c->out_f32) {
@@ -1759,9 +1773,10 @@ __global__ __launch_bounds__(PT_BLOCK) void pt_cell_kernel(const PtKArgs a, int 
 template <int RENDERER, int WAVES, bool HIER, bool ORTHO = false, bool BLOCKS = false>
 __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) void pt_tile_kernel(const PtKArgs a, int count_base) {
   int S, W, rows_local, npass, dome_slot;
-  bool dome_on;
+  bool dome_on, out_f32;
   {
     pt_kargs c = cold_args(a);
+    out_f32 = c->out_f32 != 0;
     S = c->S;
     W = c->W;
     rows_local = c->rows_local;
@@ -1946,7 +1961,7 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
     const long long pix = (long long)clrow * W + ccol;
     if (strip_dome) {  // (settled by the strip's cull: nothing but the dome can be seen from these four tiles)
       if (strip_settled && active) {
-        store_pixel(a, pix, KEEP ? dc_cum : strip_cum);
+        store_pixel(a, pix, KEEP ? dc_cum : strip_cum, out_f32);
         nrays += (unsigned long long)nsamp;
         nres += (unsigned long long)nsamp;
       }
@@ -2069,7 +2084,7 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
       bool settled;
       if (dome_value(only, hc_, dmax2, dmin, tc.all, cum, settled)) {
         if (settled && active) {
-          store_pixel(a, pix, cum);
+          store_pixel(a, pix, cum, out_f32);
           nrays += (unsigned long long)nsamp;
           nres += (unsigned long long)nsamp;
         }
@@ -2133,7 +2148,7 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
         }
         const V3 cum = dc_cum;  // render.py:139 with cum_radiance = 0, imagetracer.py:83-101 replayed
         if (active && !hitable) {
-          store_pixel(a, pix, cum);
+          store_pixel(a, pix, cum, out_f32);
           nrays += (unsigned long long)nsamp;
           nres += (unsigned long long)nsamp;
         }
@@ -2240,7 +2255,7 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
       cum.z = cum.z * k;
     }
     if (alive) {
-      store_pixel(a, pix, cum);
+      store_pixel(a, pix, cum, out_f32);
       nrays += (unsigned long long)pix_rays;
     }
     if (RENDERER == PT_RENDERER_PATHTRACER) {
@@ -2309,9 +2324,10 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))
 #define PT_T4(k) do { } while (0)
 #endif
   int W, rows_local, npass;
-  bool dome_on;
+  bool dome_on, out_f32;
   {
     pt_kargs c = cold_args(a);
+    out_f32 = c->out_f32 != 0;
     W = c->W;
     rows_local = c->rows_local;
     npass = c->npass;
@@ -2389,7 +2405,7 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))
 #pragma unroll
         for (int k = 0; k < NPX; ++k)
           if (act[k]) {
-            store_pixel(a, pix[k], c);
+            store_pixel(a, pix[k], c, out_f32);
             nrays += 1ULL;
             nres += 1ULL;
           }
@@ -2536,7 +2552,7 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))
         }
         PT_T4(6);
         if (act[k]) {
-          store_pixel(a, pix[k], c);
+          store_pixel(a, pix[k], c, out_f32);
           nrays += 1ULL;
         }
         PT_T4(7);
@@ -3451,13 +3467,9 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAV
 //     there and resumes next round -- slower, never wrong.)
 // The sum a node keeps (cum_radiance += hit_color * child, render.py:137) is formed in child order, so the frame is
 // the sequential one bit for bit; rays are counted for committed children only.
-// LDS: per wave max(D, 1) node records of PT_TREE_FRAME doubles (parents of the node in registers).
+// LDS: per wave max(D, 1) node records of PT_TREE_FRAME doubles; of the innermost node hit_color, the running sum, the child
+// counter and the BRDF kind are also kept in registers (wave-uniform).
 #define PT_TREE_FRAME 20  // hc 0..2, em 3..5, cum 6..8, wp 9..11, n 12..14, in 15..17, brdf 18, next child 19
-struct TreeNode {        // wave-uniform: the node whose children are being traced
-  V3 hc, em, cum, wp, n, in;
-  int brdf, next;
-};
-
 PT_DEV double rl_f64(double v, int lane) {  // v_readlane of a double (lane wave-uniform)
   const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
   const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, lane);

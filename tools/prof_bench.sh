@@ -43,7 +43,7 @@ python3 tools/pmc_summary.py $OUT/pmc_tree $OUT/pmc_tree2 $OUT/pmc_tree3 --kerne
 python3 tools/pmc_summary.py $OUT/pmc_c3 $OUT/pmc_c3_2 $OUT/pmc_c3_3 --kernel "pt_path_regions_kernel" --json $OUT/pmc_c3_second_pass.json --source "rocprofv3 --pmc on 'python3 tools/kbench.py c3 --rounds 4' (C3, PT_PCG_PIXEL); medians over the launches; tools/prof_bench.sh $TAG" > /dev/null
 python3 tools/pmc_summary.py $OUT/pmc_c3s $OUT/pmc_c3s_2 $OUT/pmc_c3s_3 --kernel "pt_path_regions_kernel" --json $OUT/pmc_c3_second_pass_sample.json --source "rocprofv3 --pmc on 'python3 tools/kbench.py c3:sample --rounds 4' (C3, PT_PCG_SAMPLE); medians over the launches; tools/prof_bench.sh $TAG" > /dev/null
 SRC="rocprofv3 --pmc (five separate passes: SQ issue counters, fp64 / integer instruction classes, fp32 / conversion classes, FETCH_SIZE, WRITE_SIZE) on 'python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline'; medians over the dispatches of the kernel; tools/prof_bench.sh $TAG"
-python3 tools/pmc_summary.py $OUT/pmc1 $OUT/pmc2 $OUT/pmc2b $OUT/pmc3 $OUT/pmc4 --kernel "pt_tile4_kernel<1, true>" --grid 235520 --json $OUT/pmc_c2.json --source "$SRC" > /dev/null
+python3 tools/pmc_summary.py $OUT/pmc1 $OUT/pmc2 $OUT/pmc2b $OUT/pmc3 $OUT/pmc4 --kernel "pt_tile4_kernel<1, true, 4>" --grid 235520 --json $OUT/pmc_c2.json --source "$SRC" > /dev/null
 python3 tools/pmc_summary.py $OUT/pmc1 $OUT/pmc2 $OUT/pmc2b $OUT/pmc3 $OUT/pmc4 --kernel "pt_path_regions_kernel" --grid 131072 --json $OUT/pmc_path_second_pass.json --source "$SRC (all second-pass launches of the run: C3, C4, shares)" > /dev/null || true
 f=$(find $OUT/trace -name "*kernel_stats.csv" | head -1)
 cp $f $OUT/kernel_stats.csv
