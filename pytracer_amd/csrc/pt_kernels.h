@@ -3445,7 +3445,7 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAV
   path_trace<true, LDSF, true, SLDS>(a);
 }
 
-// ---- PathTracer with num_of_rays > 1 (perspective camera, second pass): ONE pixel per wave, a node's children on lanes --
+// ---- PathTracer with num_of_rays > 1 (second pass behind pt_tile_kernel<PATHTRACER>): ONE pixel per wave, a node's children on lanes --
 // render.py:126-139 runs the N children of a hit one after the other, each with its whole subtree, all drawing from one
 // generator: where child k starts in the stream is known only when child k-1 has returned.  path_trace gives such a
 // pixel one lane, which walks the tree ray by ray: up to sum N^d dependent steps (1 111 for the CLI's N = 10, D = 3)
@@ -3488,8 +3488,10 @@ PT_DEV V3 rl_v3(V3 v, int lane) {
 
 PT_DEV void path_tree(const PtKArgs &a) {
   int S, nsamp, N, W, rows_local, npass, D, rr, diag_lds, pcg_mode, frames_lds;
+  bool ortho;
   {
     pt_kargs c = cold_args(a);
+    ortho = c->cam_kind != PT_CAMERA_PERSPECTIVE;
     diag_lds = c->diag_lds;
     pcg_mode = c->pcg_mode;
     S = c->S;
@@ -3703,7 +3705,9 @@ PT_DEV void path_tree(const PtKArgs &a) {
       ray = primary_ray(a, col, grow, up, vp);
       {
         double tp = INFINITY;
-        const int hp = world_query_tile<false, false, true>(a, ray, mbase, npass, tp, lane == 0);
+        // (an orthogonal camera's rays have no common origin: nothing is hoisted)
+        const int hp = ortho ? world_query_tile<false, false, false>(a, ray, mbase, npass, tp, lane == 0)
+                             : world_query_tile<false, false, true>(a, ray, mbase, npass, tp, lane == 0);
         shade_ray(hp, tp, 0);
       }
       prays += 1ULL;

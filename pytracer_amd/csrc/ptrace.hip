@@ -905,11 +905,11 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
     a.frame_doubles = p->num_of_rays > 1 ? 20 : 6;
     frame_lds = (size_t)std::max(p->max_depth, 1) * a.frame_doubles * PT_BLOCK * sizeof(double);
     const size_t mask_lds = regions ? (size_t)4 * a.npass * sizeof(unsigned long long) : 0;
-    // num_of_rays > 1 behind a perspective camera: one pixel per wave, a node's children on lanes (pt_path_tree_kernel);
+    // num_of_rays > 1: one pixel per wave, a node's children on lanes (pt_path_tree_kernel);
     // its stack holds one record per NODE and wave, not one per lane
     static const int env_tree = getenv("PTRACE_TREE") ? atoi(getenv("PTRACE_TREE")) : 1;
     const size_t tree_lds = (size_t)std::max(p->max_depth, 1) * PT_TREE_FRAME * (PT_BLOCK / 64) * sizeof(double);
-    tree = regions && cam->kind == PT_CAMERA_PERSPECTIVE && p->num_of_rays > 1 && env_tree != 0 && env_ldsf != 0 &&
+    tree = regions && p->num_of_rays > 1 && env_tree != 0 && env_ldsf != 0 &&
            tree_lds + mask_lds <= PT_LDS_BUDGET / 2;
     if (tree) {
       a.frame_doubles = PT_TREE_FRAME;

@@ -231,7 +231,8 @@ def test_tree_kernel_in_a_world_without_a_dome(dev, oracle, n_rays, depth, rr):
     scene = flatten.flatten_world(w)
     W, H = 96, 56
     cam = flatten.flatten_camera(hm.PerspectiveCamera(1.0, W / H, hm.translation(hm.Vec(-1.0, 0.0, 1.0))))
-    for S, mode in ((1, abi.PCG_PIXEL), (2, abi.PCG_SAMPLE)):
+    cam_o = flatten.flatten_camera(hm.OrthogonalCamera(W / H, hm.translation(hm.Vec(-1.0, 0.0, 1.2)) * hm.scaling(hm.Vec(1.0, 2.5, 1.5))))
+    for S, mode, cam in ((1, abi.PCG_PIXEL, cam), (2, abi.PCG_SAMPLE, cam), (1, abi.PCG_PIXEL, cam_o)):
         par = abi.make_params(W, H, abi.RENDERER_PATHTRACER, samples_per_side=S, num_of_rays=n_rays, max_depth=depth, rr_limit=rr,
                               pcg_mode=mode, path_state=45, path_seq=54, background=(0.05, 0.1, 0.3))
         with dev.DeviceScene(scene) as ds:
