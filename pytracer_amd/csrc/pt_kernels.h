@@ -468,7 +468,10 @@ typedef const __attribute__((address_space(3))) PtShapeAux *pt_lds_aux;
 // ANYHIT (shadow rays, world.py:71-80 / shapes.py:133-151): a lane stops at its first sphere with a root in
 // (tmin, tmax); with a finite tmax the prefilter also drops balls that lie entirely beyond the end
 // point ((v - tmax d).d > 0 and its square > 1.001 R'^2 |d|^2 + slack).
-template <bool ANYHIT>
+// SMALL (chosen by the host for worlds without a grid and without the ball hierarchy, i.e. fewer than 128 spheres):
+// the grid walk and the chunk / group levels are compiled out -- less code and fewer live registers in kernels whose
+// time is the latency of one wave's instruction stream.
+template <bool ANYHIT, bool SMALL = false>
 PT_DEV int world_query_lanes(const PtKArgs &a, const Ray &r, double tmax, double &best_t, bool active, int diag_lds) {
   typedef float f2 __attribute__((ext_vector_type(2)));
   typedef const __attribute__((address_space(4))) float *pt_kfloat;
@@ -526,7 +529,7 @@ PT_DEV int world_query_lanes(const PtKArgs &a, const Ray &r, double tmax, double
   // Scenes of >= 128 spheres: the slots are in Morton order (pt_scene_upload), every 8 consecutive
   // spheres have a ball around their bounding spheres and so have every 64; a chunk or a group that no
   // lane's ray can touch is skipped whole.
-  const int levels = a.bs_levels;
+  const int levels = SMALL ? 0 : a.bs_levels;
   pt_kfloat gsx = bsr + a.bs_stride, gsy = gsx + a.gs_stride, gsz = gsy + a.gs_stride, gsr = gsz + a.gs_stride;
   pt_kfloat csx = gsr + a.gs_stride, csy = csx + a.cs_stride, csz = csy + a.cs_stride, csr = csz + a.cs_stride;
   // ---- the exact test of a candidate (shared by every way of finding candidates below) ----
@@ -641,7 +644,7 @@ PT_DEV int world_query_lanes(const PtKArgs &a, const Ray &r, double tmax, double
   // balls of those cells' spheres go through the conservative fp32 test of the prefilter, survivors join the lane's
   // candidate list (eight 16-bit slots); (3) the candidates are visited two at a time.  Why no hit can be lost:
   // pt_scene_upload (the margin a sphere is entered with covers the fp32 ray's deviation and the DDA's rounding).
-  if (a.grid_cells) {
+  if (!SMALL && a.grid_cells) {
     pt_kargs ga = cold_args(a);
     // spheres outside the grid (a dome, unbounded transforms): tested for every ray
     const int n_always = ga->grid_n_always;
@@ -3486,6 +3489,7 @@ PT_DEV V3 rl_v3(V3 v, int lane) {
   return r;
 }
 
+template <bool SMALL>
 PT_DEV void path_tree(const PtKArgs &a) {
   int S, nsamp, N, W, rows_local, npass, D, rr, diag_lds, pcg_mode, frames_lds;
   bool ortho;
@@ -3829,7 +3833,7 @@ PT_DEV void path_tree(const PtKArgs &a) {
         if (uniform_loop)
           hs = world_query<false, false>(a, ray, INFINITY, ts, act);
         else
-          hs = world_query_lanes<false>(a, ray, INFINITY, ts, act, diag_lds);
+          hs = world_query_lanes<false, SMALL>(a, ray, INFINITY, ts, act, diag_lds);
         PT_TT(3);
         if (act) shade_ray(hs, ts, sib ? sp - 1 : sp);
         PT_TT(4);
@@ -3921,8 +3925,9 @@ PT_DEV void path_tree(const PtKArgs &a) {
 #ifndef PT_TREE_WAVES
 #define PT_TREE_WAVES 2
 #endif
+template <bool SMALL = false>
 __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_TREE_WAVES, 8))) void pt_path_tree_kernel(const PtKArgs a) {
-  path_tree(a);
+  path_tree<SMALL>(a);
 }
 
 // ---- culling probe: cone_keeps / pixel_cone exactly as the render kernels evaluate them, one wave ---------------

@@ -1262,10 +1262,17 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
       else
       hipLaunchKernelGGL(pt_unit_scatter, dim3((nregions + PT_SCATTER_BLOCK - 1) / PT_SCATTER_BLOCK), dim3(PT_SCATTER_BLOCK), 0, st, s->region_keys, s->region_mask, nregions, s->units, s->units_cap,
                          s->queue_last, lanes_cap, nsamp, min_rounds);
-      if (tree) {
+      // worlds without a grid and without the ball hierarchy (< 128 spheres): the query's large-world paths compiled out
+      static const int env_small = getenv("PTRACE_SMALL_QUERY") ? atoi(getenv("PTRACE_SMALL_QUERY")) : 1;
+      const bool small_world = env_small != 0 && s->grid_cells == nullptr && s->bs_levels == 0;
+      if (tree && small_world) {
         s->stats.kernel = PT_KERNEL_PATH_TREE;
-        HIP_TRY(path_lds_limit((const void *)pt_path_tree_kernel, lds + frame_lds + diag_lds_bytes));
-        PT_LAUNCH((pt_path_tree_kernel), grid, lds + frame_lds + diag_lds_bytes, true, a);
+        HIP_TRY(path_lds_limit((const void *)pt_path_tree_kernel<true>, lds + frame_lds + diag_lds_bytes));
+        PT_LAUNCH((pt_path_tree_kernel<true>), grid, lds + frame_lds + diag_lds_bytes, true, a);
+      } else if (tree) {
+        s->stats.kernel = PT_KERNEL_PATH_TREE;
+        HIP_TRY(path_lds_limit((const void *)pt_path_tree_kernel<false>, lds + frame_lds + diag_lds_bytes));
+        PT_LAUNCH((pt_path_tree_kernel<false>), grid, lds + frame_lds + diag_lds_bytes, true, a);
       } else if (lds_frames && a.scene_lds >= 0) {
         HIP_TRY(path_lds_limit((const void *)pt_path_regions_kernel<true, true>, lds + frame_lds + diag_lds_bytes));
         PT_LAUNCH((pt_path_regions_kernel<true, true>), grid, lds + frame_lds + diag_lds_bytes, true, a);
