@@ -2780,7 +2780,7 @@ PT_DEV long long next_pixel(const PtKArgs &a, bool need, long long npix) {
 #ifndef PT_REGIONS_INLINE
 #define PT_REGIONS_INLINE 1  // second pass: HitRecord / scatter / transcendental code inline (1) or behind calls (0)
 #endif
-template <bool TILED, bool LDSF, bool LAT, bool SLDS = false>
+template <bool TILED, bool LDSF, bool LAT, bool SLDS = false, bool SMALL = false>
 PT_DEV void path_trace(const PtKArgs &a) {
   constexpr bool INL = LAT && PT_REGIONS_INLINE;
   static_assert(!SLDS || INL, "the scene is staged in LDS for the second pass only");
@@ -3338,7 +3338,7 @@ PT_DEV void path_trace(const PtKArgs &a) {
     }
     if (do_s) {
       double ts;
-      const int hs = LAT ? world_query_lanes<false>(a, ray, INFINITY, ts, scat, diag_lds) : world_query<false, false>(a, ray, INFINITY, ts, scat);
+      const int hs = LAT ? world_query_lanes<false, SMALL>(a, ray, INFINITY, ts, scat, diag_lds) : world_query<false, false>(a, ray, INFINITY, ts, scat);
       if (scat) {
         hit = hs;
         best_t = ts;
@@ -3443,9 +3443,9 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAV
 #ifndef PT_WAVES_REGIONS
 #define PT_WAVES_REGIONS 2
 #endif
-template <bool LDSF, bool SLDS = false>
+template <bool LDSF, bool SLDS = false, bool SMALL = false>
 __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAVES_REGIONS, 8))) void pt_path_regions_kernel(const PtKArgs a) {
-  path_trace<true, LDSF, true, SLDS>(a);
+  path_trace<true, LDSF, true, SLDS, SMALL>(a);
 }
 
 // ---- PathTracer with num_of_rays > 1 (second pass behind pt_tile_kernel<PATHTRACER>): ONE pixel per wave, a node's children on lanes --

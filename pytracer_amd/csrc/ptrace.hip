@@ -1273,6 +1273,9 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
         s->stats.kernel = PT_KERNEL_PATH_TREE;
         HIP_TRY(path_lds_limit((const void *)pt_path_tree_kernel<false>, lds + frame_lds + diag_lds_bytes));
         PT_LAUNCH((pt_path_tree_kernel<false>), grid, lds + frame_lds + diag_lds_bytes, true, a);
+      } else if (lds_frames && a.scene_lds >= 0 && small_world) {
+        HIP_TRY(path_lds_limit((const void *)pt_path_regions_kernel<true, true, true>, lds + frame_lds + diag_lds_bytes));
+        PT_LAUNCH((pt_path_regions_kernel<true, true, true>), grid, lds + frame_lds + diag_lds_bytes, true, a);
       } else if (lds_frames && a.scene_lds >= 0) {
         HIP_TRY(path_lds_limit((const void *)pt_path_regions_kernel<true, true>, lds + frame_lds + diag_lds_bytes));
         PT_LAUNCH((pt_path_regions_kernel<true, true>), grid, lds + frame_lds + diag_lds_bytes, true, a);
