@@ -471,8 +471,12 @@ typedef const __attribute__((address_space(3))) PtShapeAux *pt_lds_aux;
 // SMALL (chosen by the host for worlds without a grid and without the ball hierarchy, i.e. fewer than 128 spheres):
 // the grid walk and the chunk / group levels are compiled out -- less code and fewer live registers in kernels whose
 // time is the latency of one wave's instruction stream.
-template <bool ANYHIT, bool SMALL = false>
+// (LEAN = 1 is SMALL; LEAN = 2: worlds without a grid but with the ball hierarchy, 128 ... 1023 spheres: only the grid walk
+//  is compiled out)
+template <bool ANYHIT, int LEAN = 0>
 PT_DEV int world_query_lanes(const PtKArgs &a, const Ray &r, double tmax, double &best_t, bool active, int diag_lds) {
+  constexpr bool SMALL = LEAN == 1;
+  constexpr bool NOGRID = LEAN != 0;
   typedef float f2 __attribute__((ext_vector_type(2)));
   typedef const __attribute__((address_space(4))) float *pt_kfloat;
   int best = -1;
@@ -644,7 +648,7 @@ PT_DEV int world_query_lanes(const PtKArgs &a, const Ray &r, double tmax, double
   // balls of those cells' spheres go through the conservative fp32 test of the prefilter, survivors join the lane's
   // candidate list (eight 16-bit slots); (3) the candidates are visited two at a time.  Why no hit can be lost:
   // pt_scene_upload (the margin a sphere is entered with covers the fp32 ray's deviation and the DDA's rounding).
-  if (!SMALL && a.grid_cells) {
+  if (!NOGRID && a.grid_cells) {
     pt_kargs ga = cold_args(a);
     // spheres outside the grid (a dome, unbounded transforms): tested for every ray
     const int n_always = ga->grid_n_always;
@@ -2780,7 +2784,7 @@ PT_DEV long long next_pixel(const PtKArgs &a, bool need, long long npix) {
 #ifndef PT_REGIONS_INLINE
 #define PT_REGIONS_INLINE 1  // second pass: HitRecord / scatter / transcendental code inline (1) or behind calls (0)
 #endif
-template <bool TILED, bool LDSF, bool LAT, bool SLDS = false, bool SMALL = false>
+template <bool TILED, bool LDSF, bool LAT, bool SLDS = false, int LEAN = 0>
 PT_DEV void path_trace(const PtKArgs &a) {
   constexpr bool INL = LAT && PT_REGIONS_INLINE;
   static_assert(!SLDS || INL, "the scene is staged in LDS for the second pass only");
@@ -3338,7 +3342,7 @@ PT_DEV void path_trace(const PtKArgs &a) {
     }
     if (do_s) {
       double ts;
-      const int hs = LAT ? world_query_lanes<false, SMALL>(a, ray, INFINITY, ts, scat, diag_lds) : world_query<false, false>(a, ray, INFINITY, ts, scat);
+      const int hs = LAT ? world_query_lanes<false, LEAN>(a, ray, INFINITY, ts, scat, diag_lds) : world_query<false, false>(a, ray, INFINITY, ts, scat);
       if (scat) {
         hit = hs;
         best_t = ts;
@@ -3443,9 +3447,9 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAV
 #ifndef PT_WAVES_REGIONS
 #define PT_WAVES_REGIONS 2
 #endif
-template <bool LDSF, bool SLDS = false, bool SMALL = false>
+template <bool LDSF, bool SLDS = false, int LEAN = 0>
 __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAVES_REGIONS, 8))) void pt_path_regions_kernel(const PtKArgs a) {
-  path_trace<true, LDSF, true, SLDS, SMALL>(a);
+  path_trace<true, LDSF, true, SLDS, LEAN>(a);
 }
 
 // ---- PathTracer with num_of_rays > 1 (second pass behind pt_tile_kernel<PATHTRACER>): ONE pixel per wave, a node's children on lanes --
@@ -3833,7 +3837,7 @@ PT_DEV void path_tree(const PtKArgs &a) {
         if (uniform_loop)
           hs = world_query<false, false>(a, ray, INFINITY, ts, act);
         else
-          hs = world_query_lanes<false, SMALL>(a, ray, INFINITY, ts, act, diag_lds);
+          hs = world_query_lanes<false, SMALL ? 1 : 0>(a, ray, INFINITY, ts, act, diag_lds);
         PT_TT(3);
         if (act) shade_ray(hs, ts, sib ? sp - 1 : sp);
         PT_TT(4);

@@ -1274,11 +1274,14 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
         HIP_TRY(path_lds_limit((const void *)pt_path_tree_kernel<false>, lds + frame_lds + diag_lds_bytes));
         PT_LAUNCH((pt_path_tree_kernel<false>), grid, lds + frame_lds + diag_lds_bytes, true, a);
       } else if (lds_frames && a.scene_lds >= 0 && small_world) {
-        HIP_TRY(path_lds_limit((const void *)pt_path_regions_kernel<true, true, true>, lds + frame_lds + diag_lds_bytes));
-        PT_LAUNCH((pt_path_regions_kernel<true, true, true>), grid, lds + frame_lds + diag_lds_bytes, true, a);
+        HIP_TRY(path_lds_limit((const void *)pt_path_regions_kernel<true, true, 1>, lds + frame_lds + diag_lds_bytes));
+        PT_LAUNCH((pt_path_regions_kernel<true, true, 1>), grid, lds + frame_lds + diag_lds_bytes, true, a);
       } else if (lds_frames && a.scene_lds >= 0) {
         HIP_TRY(path_lds_limit((const void *)pt_path_regions_kernel<true, true>, lds + frame_lds + diag_lds_bytes));
         PT_LAUNCH((pt_path_regions_kernel<true, true>), grid, lds + frame_lds + diag_lds_bytes, true, a);
+      } else if (lds_frames && env_small != 0 && s->grid_cells == nullptr) {  // (no grid: its walk compiled out)
+        HIP_TRY(path_lds_limit((const void *)pt_path_regions_kernel<true, false, 2>, lds + frame_lds + diag_lds_bytes));
+        PT_LAUNCH((pt_path_regions_kernel<true, false, 2>), grid, lds + frame_lds + diag_lds_bytes, true, a);
       } else if (lds_frames) {
         HIP_TRY(path_lds_limit((const void *)pt_path_regions_kernel<true>, lds + frame_lds + diag_lds_bytes));
         PT_LAUNCH((pt_path_regions_kernel<true>), grid, lds + frame_lds + diag_lds_bytes, true, a);
