@@ -143,8 +143,18 @@ def cpu_baseline(scene, seconds_budget=20.0):
     _, rays1 = orc.render(scene, cam, par1, n_threads=1, sqr_mode=orc.SQR_MUL)
     dt1 = time.perf_counter() - t0
     orc.set_sqr_mode(orc.SQR_POW)
+    # the same loop in the interpreter: oracle/pyloop.py, pure Python, one thread, a quarter-size frame
+    from oracle import pyloop
+
+    par_py = abi.make_params(320, 180, abi.RENDERER_FLAT)
+    t0 = time.perf_counter()
+    _, rays_py = pyloop.render(scene, cam_for(320, 180), par_py)
+    dt_py = time.perf_counter() - t0
     return {
         "value": rays / dt / 1e6, "unit": "Mray/s", "cores": threads, "kind": "port",
+        "interpreted": {"value": rays_py / dt_py / 1e6, "unit": "Mray/s", "cores": 1, "kind": "port",
+                        "sample": "the C2 scene at 320x180 (57 600 rays), oracle/pyloop.py: the per-pixel loop in pure Python "
+                                  "on flattened arrays, bit-identical to the C oracle (tests/test_oracle_golden.py)"},
         "sample": f"full 1280x720 C2 frame x{reps} on {threads} threads (OpenMP rows), C oracle, x*x arithmetic",
         "cpu_model": cpu_model(), "nproc": os.cpu_count(), "usable_cores": usable,
         "ms_per_frame": dt * 1e3,

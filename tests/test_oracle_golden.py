@@ -207,6 +207,32 @@ def test_checksums_match_baseline_md():
         assert math.fsum(px.reshape(-1).tolist()) == pytest.approx(expect, rel=1e-12)
 
 
+def test_interpreted_loop_equals_the_c_oracle(oracle):
+    """oracle/pyloop.py (the interpreted baseline bench.py times on the GPU box) is the same arithmetic as pt_oracle.c in
+    its x*x mode: bit-identical frames, both renderers, both cameras, checkered planes and uv of spheres included; and it
+    agrees with the REFERENCE's own frame (x**2 arithmetic) to 1e-12."""
+    from oracle import pyloop
+    from pytracer_amd import flatten, hostmodel as hm, scenes
+
+    flat = flatten.flatten_world(scenes.synthetic_world(12, with_plane=True))
+    demo_world, demo_cam = scenes.demo_world(clock=150.0)
+    cases = [(flat, flatten.flatten_camera(scenes.synthetic_camera(40, 22)), 40, 22),
+             (flat, flatten.flatten_camera(hm.OrthogonalCamera(40 / 22, hm.translation(hm.Vec(-1.0, 0.0, 1.0)) * hm.scaling(hm.Vec(1.0, 3.0, 2.0)))), 40, 22),
+             (flatten.flatten_world(demo_world), flatten.flatten_camera(demo_cam), 32, 24)]
+    for scene, cam, W, H in cases:
+        for renderer in (abi.RENDERER_FLAT, abi.RENDERER_ONOFF):
+            par = abi.make_params(W, H, renderer)
+            got, n = pyloop.render(scene, cam, par)
+            want, n_rays = oracle.render(scene, cam, par, sqr_mode=oracle.SQR_MUL)
+            oracle.set_sqr_mode(oracle.SQR_POW)
+            assert n == n_rays == W * H
+            assert util.bits_equal(got, want), (renderer, W, H)
+    scene, cam, par, pixels = util.load_frame("g5_c2_flat_160x90")
+    small = abi.copy_params(par)
+    got, _ = pyloop.render(scene, cam, small)
+    assert util.rel_err(got, pixels).max() <= 1e-12
+
+
 def test_sqr_mode_mul_is_close(oracle):
     """x*x instead of pow(x, 2): the device arithmetic.  Not bit-identical in general, but the
     frames stay far inside the 1e-5 contract."""
