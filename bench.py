@@ -199,14 +199,23 @@ def extra_rows(device: int):
         "C4_share_of_rank_3_of_8_PT_PCG_SAMPLE": (256, False, True, 3840, 2160, 3,
                                                   dict(C4["kw"], n_ranks=8, rank=3, row_block=8, pcg_mode=abi.PCG_SAMPLE)),
     }
+    # primary + SHADOW rays (the metric's wording): PointLightRenderer over the C2 scene with two point lights
+    cases["C2_pointlight_2_lights_1280x720"] = (32, True, False, 1280, 720, 7, dict(renderer=abi.RENDERER_POINTLIGHT, _lights=2))
     scene_cache = {}
     for name, (ns, plane, wide, W, H, reps, kw) in cases.items():
-        key = (ns, plane, wide)
+        kw = dict(kw)
+        n_lights = kw.pop("_lights", 0)
+        key = (ns, plane, wide, n_lights)
         if key not in scene_cache:
             for ds_old in scene_cache.values():
                 ds_old[1].close()
             scene_cache.clear()
-            flat = flatten.flatten_world(scenes.synthetic_world(ns, with_plane=plane, wide=wide))
+            world = scenes.synthetic_world(ns, with_plane=plane, wide=wide)
+            for l in range(n_lights):
+                from pytracer_amd import hostmodel as hm
+
+                world.add_light(hm.PointLight(hm.Vec(-3.0 + 4.0 * l, 6.0 - 9.0 * l, 8.0), hm.Color(1.0, 0.9, 0.8), 0.0))
+            flat = flatten.flatten_world(world)
             scene_cache[key] = (flat, DeviceScene(flat, device=device))
         flat, ds = scene_cache[key]
         par = abi.make_params(W, H, out_format=abi.OUT_F32, **kw)
