@@ -2567,8 +2567,25 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))
     }
   }
 #ifdef PT_DEBUG_TIME
+#ifdef PT_DEBUG_HEAVY  // section sums of the HEAVY sampled waves only (more than PT_DEBUG_HEAVY cycles)
+  {
+    unsigned long long tot_ = 0;
+    for (int q = 0; q < 8; ++q) tot_ += tsum[q];
+    if ((threadIdx.x & 63) == 0 && ((blockIdx.y * gridDim.x + blockIdx.x) & 3) == 0 && tot_ > PT_DEBUG_HEAVY)
+      for (int q = 0; q < 8; ++q) atomicAdd(pt_queue(a) + 1 + q, tsum[q]);
+  }
+#else
   if ((threadIdx.x & 63) == 0 && ((blockIdx.y * gridDim.x + blockIdx.x) & 15) == 0)
     for (int q = 0; q < 8; ++q) atomicAdd(pt_queue(a) + 1 + q, tsum[q]);
+#endif
+  if ((threadIdx.x & 63) == 0 && ((blockIdx.y * gridDim.x + blockIdx.x) & 15) == 0) {  // (sampled waves) the longest one, and how many took more than 16 / 24 / 32 kcycles
+    unsigned long long tot = 0;
+    for (int q = 0; q < 8; ++q) tot += tsum[q];
+    atomicMax(pt_queue(a) + 12, tot);
+    if (tot > 16384ULL) atomicAdd(pt_queue(a) + 13, 1ULL);
+    if (tot > 24576ULL) atomicAdd(pt_queue(a) + 14, 1ULL);
+    if (tot > 32768ULL) atomicAdd(pt_queue(a) + 15, 1ULL);
+  }
 #endif
   add_ray_count(a, nrays, 0, nres, blockIdx.y * gridDim.x + blockIdx.x);
 }

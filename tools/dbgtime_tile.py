@@ -23,3 +23,5 @@ print("kernel ms", ds.stats().kernel_ms, "sampled waves", nw, "tiles/wave", 1440
 for n, v in zip(names, t):
     print(f"{n:26s} {v / nw:10.0f} cycles/wave  {100 * v / t.sum():5.1f} %")
 print("sum per wave", t.sum() / nw)
+if ds.stats().kernel == abi.KERNEL_TILE4:
+    print(f"longest wave {q[12]} cycles; waves above 16 / 24 / 32 kcycles: {q[13]} / {q[14]} / {q[15]} of the {nw} sampled")
