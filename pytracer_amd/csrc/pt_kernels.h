@@ -1781,10 +1781,16 @@ template <int RENDERER, int WAVES, bool HIER, bool ORTHO = false, bool BLOCKS = 
 __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES, 8))) void pt_tile_kernel(const PtKArgs a, int count_base) {
   int S, W, rows_local, npass, dome_slot;
   bool dome_on, out_f32;
+  unsigned long long *rmask = nullptr;  // path tracer's first pass: [region] flagged pixels, and their number
+  unsigned char *rkeys = nullptr;
   {
     pt_kargs c = cold_args(a);
     out_f32 = c->out_f32 != 0;
     S = c->S;
+    if (RENDERER == PT_RENDERER_PATHTRACER) {  // (read once: a scalar load per tile otherwise, in front of every sky tile's two stores)
+      rmask = c->region_mask;
+      rkeys = c->region_keys;
+    }
     W = c->W;
     rows_local = c->rows_local;
     npass = c->npass;
@@ -1975,9 +1981,8 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
       if (RENDERER == PT_RENDERER_PATHTRACER) {
         const unsigned long long todo = strip_settled ? 0ULL : __ballot(active);
         if (lane == 0) {
-          pt_kargs ca = cold_args(a);
-          ca->region_mask[tile] = todo;
-          ca->region_keys[tile] = (unsigned char)__popcll(todo);
+          rmask[tile] = todo;
+          rkeys[tile] = (unsigned char)__popcll(todo);
             if (todo) note_flagged(pt_queue(a), __popcll(todo));
         }
       }
@@ -2098,9 +2103,8 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
         if (RENDERER == PT_RENDERER_PATHTRACER) {
           const unsigned long long todo = settled ? 0ULL : __ballot(active);
           if (lane == 0) {
-            pt_kargs ca = cold_args(a);
-            ca->region_mask[tile] = todo;
-            ca->region_keys[tile] = (unsigned char)__popcll(todo);
+            rmask[tile] = todo;
+            rkeys[tile] = (unsigned char)__popcll(todo);
             if (todo) note_flagged(pt_queue(a), __popcll(todo));
           }
         }
@@ -2161,8 +2165,8 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
         }
         const unsigned long long todo = __ballot(active && hitable);
         if (lane == 0) {
-          ca->region_mask[tile] = todo;
-          ca->region_keys[tile] = (unsigned char)__popcll(todo);
+          rmask[tile] = todo;
+          rkeys[tile] = (unsigned char)__popcll(todo);
             if (todo) note_flagged(pt_queue(a), __popcll(todo));
         }
         __builtin_amdgcn_wave_barrier();  // the next tile overwrites this wave's mask slice
@@ -2268,9 +2272,8 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
     if (RENDERER == PT_RENDERER_PATHTRACER) {
       const unsigned long long todo = __ballot(active && !alive);
       if (lane == 0) {
-        pt_kargs c = cold_args(a);
-        c->region_mask[tile] = todo;
-        c->region_keys[tile] = (unsigned char)__popcll(todo);
+        rmask[tile] = todo;
+        rkeys[tile] = (unsigned char)__popcll(todo);
         if (todo) note_flagged(pt_queue(a), __popcll(todo));
       }
     }
