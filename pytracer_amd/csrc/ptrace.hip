@@ -909,7 +909,12 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
     // its stack holds one record per NODE and wave, not one per lane
     static const int env_tree = getenv("PTRACE_TREE") ? atoi(getenv("PTRACE_TREE")) : 1;
     const size_t tree_lds = (size_t)std::max(p->max_depth, 1) * PT_TREE_FRAME * (PT_BLOCK / 64) * sizeof(double);
-    tree = regions && p->num_of_rays > 1 && env_tree != 0 && env_ldsf != 0 &&
+    // One pixel per wave pays while the flagged pixels are few per resident wave (the frame then waits for its deepest
+    // tree); where they are MANY -- a ground plane filling a large frame -- throughput decides, and 64 one-lane trees per
+    // wave catch up: measured equal at 1280x720 with ~400 k flagged pixels (14.8 vs 15.5 ms, profiles/r03_tree_dense_frames.txt).
+    // The flagged count is not known when the kernels are enqueued, so the frame size stands in for it.
+    static const long long env_tree_px = getenv("PTRACE_TREE_MAX_PIXELS") ? atoll(getenv("PTRACE_TREE_MAX_PIXELS")) : 2100000LL;
+    tree = regions && p->num_of_rays > 1 && env_tree != 0 && env_ldsf != 0 && a.npix <= env_tree_px &&
            tree_lds + mask_lds <= PT_LDS_BUDGET / 2;
     if (tree) {
       a.frame_doubles = PT_TREE_FRAME;
