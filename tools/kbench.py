@@ -41,6 +41,8 @@ CONFIGS = {
     "f8s8": (32, False, False, 8, 8, dict(renderer=abi.RENDERER_FLAT, samples_per_side=8)),
     "c3n10": (32, False, False, 1280, 720, dict(renderer=abi.RENDERER_PATHTRACER, samples_per_side=1, num_of_rays=10,
                                                 max_depth=3, rr_limit=3, path_state=45, path_seq=54)),
+    "c2n10": (32, True, False, 1280, 720, dict(renderer=abi.RENDERER_PATHTRACER, samples_per_side=1, num_of_rays=10,
+                                               max_depth=3, rr_limit=3, path_state=45, path_seq=54)),
     "c4crop": (256, False, True, 960, 540, dict(renderer=abi.RENDERER_PATHTRACER, samples_per_side=4, num_of_rays=1,
                                                 max_depth=5, rr_limit=3, path_state=45, path_seq=54)),
     "c4": (256, False, True, 3840, 2160, dict(renderer=abi.RENDERER_PATHTRACER, samples_per_side=8, num_of_rays=1,
