@@ -3761,6 +3761,11 @@ PT_DEV void path_tree(const PtKArgs &a) {
           f[12] = o_n.x; f[13] = o_n.y; f[14] = o_n.z; f[15] = in_dir.x; f[16] = in_dir.y; f[17] = in_dir.z;
           f[18] = (double)o_brdf; f[19] = 0.0;
         }
+        // (the record is read by every lane later on: the compiler may neither move those loads above this store nor
+        //  feed them from this lane's registers)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         t_hc = rl_v3(o_hc, src);
         t_cum = {0.0, 0.0, 0.0};
         t_next = 0;
