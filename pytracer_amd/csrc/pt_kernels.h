@@ -488,8 +488,25 @@ PT_DEV int world_query_lanes(const PtKArgs &a, const Ray &r, double tmax, double
   const float ofx = (float)r.o.x, ofy = (float)r.o.y, ofz = (float)r.o.z;
   const float dfx = (float)r.d.x, dfy = (float)r.d.y, dfz = (float)r.d.z;
   const float dd = dfx * dfx + dfy * dfy + dfz * dfz;
-  const float eo = 1e-6f * fmaxf(fmaxf(fabsf(ofx), fabsf(ofy)), fabsf(ofz));
-  const float dd8 = 8e-6f * dd;
+  const float omax = fmaxf(fmaxf(fabsf(ofx), fabsf(ofy)), fabsf(ofz));
+  const float eo = 1e-6f * omax;  // (the grid's measure of "far away")
+  // The conservative filter: "is the centre of the ball farther from the ray (the segment, for shadow rays) than r'?", in
+  // fp32 with the direction normalised: with v = C - o, vd = v.d^, vc = vd clamped to [0, length],
+  //   dist^2 = |v|^2 - vd^2 + (vd - vc)^2   and the ball is rejected iff   (1 - 8e-6) |v|^2 - E - r'^2 - vd^2 + (vd - vc)^2 > 0
+  // (evaluated divided by 1 - 8e-6: d^ and the length carry 1 / sqrt(1 - 8e-6), the tables r'^2 / (1 - 8e-6)).
+  // 8e-6 |v|^2 covers the fp32 evaluation (|v|^2 and vd each within a few 2^-24, d^ within 3e-7 of unit length, vd^2 <= |v|^2);
+  // E = e (2 r'max + e) >= (r' + e)^2 - r'^2 with e = 2e-7 max|o| covers the rounding of o to fp32 (<= sqrt(3) 2^-24 max|o|);
+  // r' itself (pt_scene_upload) covers the rounding of C and the slack of the fp64 test around delta = 0.  The tables
+  // hold r'^2 rounded up, 1e38 (never rejected) where there is no usable bound; a lane whose ray is not ordinary
+  // (|o| > 1e17, |d|^2 outside 1e-30 .. 1e30, NaN) keeps everything (`wild`): with both guards no intermediate value
+  // overflows or is a NaN, so the SIGN of the last operation is the verdict -- no compare, no select.
+  const bool wild = !(omax <= 1e17f && dd >= 1e-30f && dd <= 1e30f);
+  const float rn = __builtin_amdgcn_rsqf(dd) * 1.0000041f;  // (1 / sqrt(1 - 8e-6) = 1.0000040000240...: rounded up)
+  const float hx = dfx * rn, hy = dfy * rn, hz = dfz * rn;
+  const float e7 = 2e-7f * omax;
+  const float Ek0 = e7 * (2.0f * a.bs_rmax[0] + e7) * 1.0001f, Ek1 = e7 * (2.0f * a.bs_rmax[1] + e7) * 1.0001f,
+              Ek2 = e7 * (2.0f * a.bs_rmax[2] + e7) * 1.0001f;
+  const float tlen = ANYHIT ? (float)tmax * (dd * rn) * (1.0f + 1e-5f) : 0.0f;  // (tmax = inf: inf)
   pt_kfloat bsx = (pt_kfloat)(const void *)a.bsoa, bsy = bsx + a.bs_stride, bsz = bsy + a.bs_stride, bsr = bsz + a.bs_stride;
 
   // this lane may use o*s + t, d*s for a scale+translate sphere whose translation absorbs its zero products
@@ -509,25 +526,20 @@ PT_DEV int world_query_lanes(const PtKArgs &a, const Ray &r, double tmax, double
 #endif
   typedef float f8 __attribute__((ext_vector_type(8)));
   typedef const __attribute__((address_space(4))) f8 *pt_kf8;
-  // may this lane's ray touch the balls (cx, cy, cz | radius cr), two at a time?
-  auto reject2 = [&](f2 cx, f2 cy, f2 cz, f2 cr, bool &rej0, bool &rej1) {
+  // two balls at a time (cx, cy, cz | cr2 = r'^2): NEGATIVE = this lane's ray cannot meet that ball
+  auto far2 = [&](f2 cx, f2 cy, f2 cz, f2 cr2, float Ek) -> f2 {
 #pragma clang fp contract(fast)  // (a conservative fp32 filter, not reference arithmetic: fused multiply-adds only make it more exact)
     const f2 vx = cx - ofx, vy = cy - ofy, vz = cz - ofz;
-    const f2 vd = vx * dfx + vy * dfy + vz * dfz;
-    const f2 vv = vx * vx + vy * vy + vz * vz;
-    const f2 t = vd * vd;
-    const f2 q = vv * dd - t;  // |v x d|^2 = dist^2 |d|^2
-    const f2 rk = cr + eo;
-    const f2 rdd = (rk * rk) * dd;
-    const f2 slack = vv * dd8;
-    const f2 rhs = rdd + slack, rhs_b = rdd * 1.001f + slack;
-    rej0 = (q.x > rhs.x) || (vd.x < 0.0f && t.x > rhs_b.x);
-    rej1 = (q.y > rhs.y) || (vd.y < 0.0f && t.y > rhs_b.y);
-    if (ANYHIT) {  // entirely beyond the end of the segment (tmax = inf: wd = -inf or NaN, no reject)
-      const f2 wd = vd - tmaxf_dd * dd;
-      const f2 wd2 = wd * wd;
-      rej0 = rej0 || (wd.x > 0.0f && wd2.x > rhs_b.x);
-      rej1 = rej1 || (wd.y > 0.0f && wd2.y > rhs_b.y);
+    const f2 vd = vx * hx + vy * hy + vz * hz;
+    const f2 vvm = vz * vz + (vy * vy + (vx * vx - Ek));
+    const f2 P = vvm - cr2;
+    if (!ANYHIT) {
+      const f2 vc = {__builtin_fmaxf(vd.x, 0.0f), __builtin_fmaxf(vd.y, 0.0f)};
+      return vc * vc - P;
+    } else {
+      const f2 vc = {__builtin_amdgcn_fmed3f(vd.x, 0.0f, tlen), __builtin_amdgcn_fmed3f(vd.y, 0.0f, tlen)};
+      const f2 e = vd - vc;
+      return vd * vd - (e * e + P);
     }
   };
   // Scenes of >= 128 spheres: the slots are in Morton order (pt_scene_upload), every 8 consecutive
@@ -623,24 +635,21 @@ PT_DEV int world_query_lanes(const PtKArgs &a, const Ray &r, double tmax, double
     }
   };
   // the same test for ONE ball, the ray's constants given explicitly (scalar form, see the sparse path below)
-  auto reject1 = [&](float cx, float cy, float cz, float cr, float sox, float soy, float soz, float sdx, float sdy,
-                     float sdz, float sdd, float seo, float sdd8) {
+  auto far1 = [&](float cx, float cy, float cz, float cr2, float sox, float soy, float soz, float shx, float shy, float shz,
+                  float sEk) -> float {
 #pragma clang fp contract(fast)
     const float vx = cx - sox, vy = cy - soy, vz = cz - soz;
-    const float vd = vx * sdx + vy * sdy + vz * sdz;
-    const float vv = vx * vx + vy * vy + vz * vz;
-    const float t = vd * vd;
-    const float q = vv * sdd - t;
-    const float rk = cr + seo;
-    const float rdd = (rk * rk) * sdd;
-    const float slack = vv * sdd8;
-    const float rhs = rdd + slack, rhs_b = rdd * 1.001f + slack;
-    bool rej = (q > rhs) || (vd < 0.0f && t > rhs_b);
-    if (ANYHIT) {
-      const float wd = vd - tmaxf_dd * sdd;
-      rej = rej || (wd > 0.0f && wd * wd > rhs_b);
+    const float vd = vx * shx + vy * shy + vz * shz;
+    const float vvm = vz * vz + (vy * vy + (vx * vx - sEk));
+    const float P = vvm - cr2;
+    if (!ANYHIT) {
+      const float vc = __builtin_fmaxf(vd, 0.0f);
+      return vc * vc - P;
+    } else {
+      const float vc = __builtin_amdgcn_fmed3f(vd, 0.0f, tlen);
+      const float e = vd - vc;
+      return vd * vd - (e * e + P);
     }
-    return rej;
   };
   // ---- scenes with a grid: every lane walks the cells its ray crosses ----
   // Three phases, repeated until every lane's walk has left the grid: (1) a 3D-DDA in fp32 on the fp32 copy of
@@ -766,7 +775,7 @@ PT_DEV int world_query_lanes(const PtKArgs &a, const Ray &r, double tmax, double
           const bool has_i = q < cnt_c;
           const float4 b = balls[off_c + (has_i ? q : 0u)];
           const int slot = (int)slots[off_c + (has_i ? q : 0u)];
-          const bool rej = reject1(b.x, b.y, b.z, b.w, ofx, ofy, ofz, dfx, dfy, dfz, dd, eo, dd8);
+          const bool rej = !wild && far1(b.x, b.y, b.z, b.w, ofx, ofy, ofz, hx, hy, hz, Ek0) < 0.0f;
           if (has_i && !rej && slot != last && !(ANYHIT && best >= 0)) {
             last = slot;
             if (n_ca < 4)
@@ -783,7 +792,7 @@ PT_DEV int world_query_lanes(const PtKArgs &a, const Ray &r, double tmax, double
     }
     if (__ballot(far) != 0ULL) {  // (rare: see above) every sphere for the far lanes, one ball per turn
       for (int slot = 0; slot < ns; ++slot) {
-        const bool cand = far && !(ANYHIT && best >= 0) && !reject1(bsx[slot], bsy[slot], bsz[slot], bsr[slot], ofx, ofy, ofz, dfx, dfy, dfz, dd, eo, dd8);
+        const bool cand = far && !(ANYHIT && best >= 0) && (wild || !(far1(bsx[slot], bsy[slot], bsz[slot], bsr[slot], ofx, ofy, ofz, hx, hy, hz, Ek0) < 0.0f));
         if (__ballot(cand) != 0ULL) visit2(slot, cand, 0, false);
       }
     }
@@ -825,8 +834,8 @@ PT_DEV int world_query_lanes(const PtKArgs &a, const Ray &r, double tmax, double
         const int src = __ffsll((long long)todo) - 1;
         todo &= todo - 1ULL;
 #define PT_BCAST(x) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), src))
-        const bool rej = reject1(bx, by, bz, br, PT_BCAST(ofx), PT_BCAST(ofy), PT_BCAST(ofz), PT_BCAST(dfx), PT_BCAST(dfy),
-                                 PT_BCAST(dfz), PT_BCAST(dd), PT_BCAST(eo), PT_BCAST(dd8));
+        const bool rej = far1(bx, by, bz, br, PT_BCAST(ofx), PT_BCAST(ofy), PT_BCAST(ofz), PT_BCAST(hx), PT_BCAST(hy),
+                              PT_BCAST(hz), PT_BCAST(Ek0)) < 0.0f;
 #undef PT_BCAST
         const unsigned long long m = __ballot(mine && !rej);
         if ((int)(threadIdx.x & 63) == src) mask = m;
@@ -834,31 +843,42 @@ PT_DEV int world_query_lanes(const PtKArgs &a, const Ray &r, double tmax, double
     } else {
     if (levels) {
       const int c = base >> 6;
-      bool r0, r1;
-      reject2((f2){csx[c], csx[c]}, (f2){csy[c], csy[c]}, (f2){csz[c], csz[c]}, (f2){csr[c], csr[c]}, r0, r1);
-      if (__ballot(live && !r0) == 0ULL) continue;
+      const f2 nc = far2((f2){csx[c], csx[c]}, (f2){csy[c], csy[c]}, (f2){csz[c], csz[c]}, (f2){csr[c], csr[c]}, Ek2);
+      if (__ballot(live && (wild || !(nc.x < 0.0f))) == 0ULL) continue;
       const f8 X = *(pt_kf8)(gsx + c * 8), Y = *(pt_kf8)(gsy + c * 8), Z = *(pt_kf8)(gsz + c * 8), R = *(pt_kf8)(gsr + c * 8);
       gtouch = 0u;
 #pragma unroll
       for (int k = 0; k < 8; k += 2) {
-        reject2((f2){X[k], X[k + 1]}, (f2){Y[k], Y[k + 1]}, (f2){Z[k], Z[k + 1]}, (f2){R[k], R[k + 1]}, r0, r1);
-        gtouch |= (__ballot(live && !r0) != 0ULL ? 1u << k : 0u) | (__ballot(live && !r1) != 0ULL ? 2u << k : 0u);
+        const f2 ng = far2((f2){X[k], X[k + 1]}, (f2){Y[k], Y[k + 1]}, (f2){Z[k], Z[k + 1]}, (f2){R[k], R[k + 1]}, Ek1);
+        gtouch |= (__ballot(live && (wild || !(ng.x < 0.0f))) != 0ULL ? 1u << k : 0u) |
+                  (__ballot(live && (wild || !(ng.y < 0.0f))) != 0ULL ? 2u << k : 0u);
       }
     }
-    for (int j = 0; j < cnt; j += 8) {  // eight spheres per round of scalar loads (the arrays are padded)
-      if (!((gtouch >> (j >> 3)) & 1u)) continue;
-      const f8 X = *(pt_kf8)(bsx + base + j), Y = *(pt_kf8)(bsy + base + j), Z = *(pt_kf8)(bsz + base + j),
-               R = *(pt_kf8)(bsr + base + j);
-      unsigned m8 = 0u;
+    // eight spheres per round of scalar loads (the arrays are padded); a verdict is a sign bit, shifted into the word of
+    // its 32 spheres (first sphere = highest bit: reversed below)
+    unsigned rejw[2];
 #pragma unroll
-      for (int k = 0; k < 8; k += 2) {
-        bool rej0, rej1;
-        reject2((f2){X[k], X[k + 1]}, (f2){Y[k], Y[k + 1]}, (f2){Z[k], Z[k + 1]}, (f2){R[k], R[k + 1]}, rej0, rej1);
-        m8 |= (rej0 ? 0u : 1u << k) | (rej1 ? 0u : 2u << k);
+    for (int hw = 0; hw < 2; ++hw) {
+      unsigned rej = 0u;
+      for (int j = hw * 32; j < hw * 32 + 32; j += 8) {
+        if (j >= cnt || !((gtouch >> (j >> 3)) & 1u)) {
+          rej = (rej << 8) | 0xffu;
+          continue;
+        }
+        const f8 X = *(pt_kf8)(bsx + base + j), Y = *(pt_kf8)(bsy + base + j), Z = *(pt_kf8)(bsz + base + j),
+                 R = *(pt_kf8)(bsr + base + j);
+#pragma unroll
+        for (int k = 0; k < 8; k += 2) {
+          const f2 nx = far2((f2){X[k], X[k + 1]}, (f2){Y[k], Y[k + 1]}, (f2){Z[k], Z[k + 1]}, (f2){R[k], R[k + 1]}, Ek0);
+          rej = __builtin_amdgcn_alignbit(rej, __float_as_uint(nx.x), 31);
+          rej = __builtin_amdgcn_alignbit(rej, __float_as_uint(nx.y), 31);
+        }
       }
-      mask |= (unsigned long long)m8 << j;
+      rejw[hw] = rej;
     }
+    mask = ~(((unsigned long long)__builtin_bitreverse32(rejw[1]) << 32) | (unsigned long long)__builtin_bitreverse32(rejw[0]));
     }
+    if (wild) mask = ~0ULL;
     if (cnt < 64) mask &= (1ULL << cnt) - 1ULL;
     if (!live) mask = 0ULL;
 #ifdef PT_DEBUG_TIME

@@ -86,10 +86,11 @@ struct PtKArgs {
   const PtDiagRec *diag;            // [n_diag], parallel to recs[0..n_diag)
   const PtHoistDiag *hoist_diag;    // [n_diag]
   const float4 *bounds;             // [n_shapes], slot order: (cx, cy, cz, r)
-  const float *bsoa;                // the same as four arrays x[], y[], z[], r'[] of bs_stride floats (per-ray prefilter),
+  const float *bsoa;                // the same as four arrays x[], y[], z[], r'^2[] of bs_stride floats (per-ray prefilter),
                                     // then the balls around every 8 (gs_stride) and every 64 (cs_stride) sphere slots
   int bs_stride, gs_stride, cs_stride;
   int bs_levels;                    // 1: the group/chunk balls are meaningful (>= 128 spheres, slots in Morton order)
+  float bs_rmax[3];                 // the largest ordinary r' among the spheres' balls, the groups', the chunks' (the filter's margin for |o|)
   // Uniform grid over the bounded, ordinary-sized spheres: scattered and shadow rays of scenes of >= 128 spheres walk
   // it cell by cell (world_query_lanes).  Cell c holds items [grid_cells[c] >> 8, + (grid_cells[c] & 255)): the ball
   // (x, y, z, r') of a sphere for the conservative fp32 test and its slot; grid_occ has one bit per cell ("holds

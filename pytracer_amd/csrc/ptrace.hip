@@ -44,6 +44,21 @@ static int fail(int code, const char *fmt, ...) {
                   __LINE__);                                                                 \
   } while (0)
 
+// A ball of the scattered-ray filter as the kernels want it: r'^2 / (1 - 8e-6) rounded up; where there is no usable bound
+// (r' not finite or >= 1e17, a centre that is not finite or beyond 1e17) the centre 0 and r'^2 = 1e38, which the filter's
+// arithmetic never rejects and never overflows on (pt_kernels.h: world_query_lanes).
+static void pt_ball_square(float *x, float *y, float *z, float *r, bool *ordinary) {
+  const bool ok = std::isfinite(*r) && *r >= 0.0f && *r < 1e17f && std::isfinite(*x) && std::isfinite(*y) && std::isfinite(*z) &&
+                  std::fabs(*x) < 1e17f && std::fabs(*y) < 1e17f && std::fabs(*z) < 1e17f;
+  *ordinary = ok;
+  if (ok) {
+    *r = std::nextafter((float)((double)*r * (double)*r * (1.0 + 8.1e-6)), INFINITY);
+  } else {
+    *x = *y = *z = 0.0f;
+    *r = 1e38f;
+  }
+}
+
 struct pt_scene {
   int device = 0;
   int n_shapes = 0, n_spheres = 0, n_lights = 0, n_textures = 0;
@@ -62,6 +77,7 @@ struct pt_scene {
   float grid_min[3] = {0, 0, 0}, grid_max[3] = {0, 0, 0}, grid_cell[3] = {0, 0, 0}, grid_inv[3] = {0, 0, 0};
   float *bsoa = nullptr;  // bounds as x[], y[], z[], r'[] (bs_stride floats each), then group and chunk balls
   int bs_stride = 0, gs_stride = 0, cs_stride = 0, bs_levels = 0;
+  float bs_rmax[3] = {0.0f, 0.0f, 0.0f};
   int n_diag = 0;
   PtLight *lights = nullptr;
   PtTex *tex = nullptr;
@@ -579,7 +595,6 @@ extern "C" int pt_scene_upload(const pt_scene_desc *d, int device, pt_scene **ou
     }
   UP(upload(&s->recs, recs));
   UP(upload(&s->bounds, bounds));
-  UP(upload(&s->bsoa, bsoa));
   // ---- uniform grid over the ordinary spheres (scenes of >= 128 spheres) ----
   // A sphere is entered into every cell that the box around its ball (the r' of the per-ray prefilter, already
   // inflated) overlaps after widening it by eps = 2e-3 cell + 1e-4 max|coordinate|.  The walk (world_query_lanes)
@@ -673,6 +688,8 @@ extern "C" int pt_scene_upload(const pt_scene_desc *d, int device, pt_scene **ou
             b.y = ball(k, 1);
             b.z = ball(k, 2);
             b.w = ball(k, 3);
+            bool ordinary;
+            pt_ball_square(&b.x, &b.y, &b.z, &b.w, &ordinary);
             balls.push_back(b);
           }
         }
@@ -690,6 +707,23 @@ extern "C" int pt_scene_upload(const pt_scene_desc *d, int device, pt_scene **ou
       }
     }
   }
+  // the filter compares squares (world_query_lanes): r' -> r'^2 rounded up, in all three tables
+  {
+    float *tab[3] = {bsoa.data(), bsoa.data() + (size_t)4 * s->bs_stride, bsoa.data() + (size_t)4 * (s->bs_stride + s->gs_stride)};
+    const int stride[3] = {s->bs_stride, s->gs_stride, s->cs_stride};
+    for (int lv = 0; lv < 3; ++lv) {
+      float rmax = 0.0f;
+      for (int k = 0; k < stride[lv]; ++k) {
+        float *x = tab[lv] + k, *y = x + stride[lv], *z = y + stride[lv], *r = z + stride[lv];
+        const float rp = *r;
+        bool ordinary;
+        pt_ball_square(x, y, z, r, &ordinary);
+        if (ordinary) rmax = std::max(rmax, rp);
+      }
+      s->bs_rmax[lv] = rmax;
+    }
+  }
+  UP(upload(&s->bsoa, bsoa));
   UP(upload(&s->diag, diag));
   {
     std::vector<PtHoistDiag> hd(std::max(s->n_diag, 1));
@@ -819,6 +853,7 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
   a.bounds = s->bounds;
   a.bsoa = s->bsoa;
   a.bs_stride = s->bs_stride;
+  for (int q = 0; q < 3; ++q) a.bs_rmax[q] = s->bs_rmax[q];
   a.gs_stride = s->gs_stride;
   a.cs_stride = s->cs_stride;
   a.bs_levels = s->bs_levels;
