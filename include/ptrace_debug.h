@@ -29,6 +29,14 @@ int pt_debug_cull_probe(pt_scene *scene, const pt_camera *cam, int width, int he
  * (hit 0/1, t, world_point[3], normal[3] normalised as world.py:66-68 does for the winner, u, v, World.shapes index, 0). */
 int pt_debug_hit_probe(pt_scene *scene, int shape_index, const double *rays, int n, double *out);
 
+/* World.ray_intersection (anyhit = 0; world.py:51-69) / World.is_point_visible's blocker search (anyhit = 1;
+ * world.py:71-80) through the query the scattered and shadow rays use: per-lane candidates from the conservative fp32
+ * filter -- or the cell walk in scenes with a grid -- then exact visits.  The 64 rays of a group of 64 run as one wave;
+ * a ray with tmin < 0 is an idle lane.  rays: n x 8 doubles as above; out: n x 4 doubles (hit 0/1, t, World.shapes
+ * index, 0), any-hit: (blocked 0/1, 0, 0, 0).  Must agree with pt_debug_hit_probe(scene, -1, ...), which runs every
+ * shape through the exact test: the filter may only drop shapes the ray cannot meet. */
+int pt_debug_lanes_probe(pt_scene *scene, int anyhit, const double *rays, int n, double *out);
+
 /* ImageTracer.fire_ray + Camera.fire_ray on the device (imagetracer.py:48-58, camera.py:59-78, 103-124) through the
  * kernels' own primary_ray.  pix: n x 4 doubles (col, row, u_pixel, v_pixel); out: n x 7 doubles (origin, dir, tmin). */
 int pt_debug_camera_probe(const pt_camera *cam, int width, int height, const double *pix, int n, double *out);

@@ -18,8 +18,8 @@ EXPORTS = ("pt_device_count", "pt_scene_upload", "pt_scene_free", "pt_rows_for_r
 
 
 # every symbol include/ptrace_debug.h declares for ordinary builds (diagnostics: not part of the boundary)
-DEBUG_EXPORTS = ("pt_debug_probe", "pt_debug_cull_probe", "pt_debug_hit_probe", "pt_debug_camera_probe",
-                 "pt_debug_scatter_probe", "pt_debug_read_queue")
+DEBUG_EXPORTS = ("pt_debug_probe", "pt_debug_cull_probe", "pt_debug_hit_probe", "pt_debug_lanes_probe",
+                 "pt_debug_camera_probe", "pt_debug_scatter_probe", "pt_debug_read_queue")
 
 
 class PtraceError(RuntimeError):
@@ -125,6 +125,9 @@ def lib():
         if hasattr(L, "pt_debug_hit_probe"):
             L.pt_debug_hit_probe.restype = C.c_int
             L.pt_debug_hit_probe.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        if hasattr(L, "pt_debug_lanes_probe"):
+            L.pt_debug_lanes_probe.restype = C.c_int
+            L.pt_debug_lanes_probe.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         if hasattr(L, "pt_debug_camera_probe"):
             L.pt_debug_camera_probe.restype = C.c_int
             L.pt_debug_camera_probe.argtypes = [P(abi.Camera), C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]

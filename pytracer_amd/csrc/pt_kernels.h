@@ -4029,6 +4029,29 @@ __global__ void pt_hit_probe_kernel(const PtKArgs a, int shape_index, const doub
   o[10] = (double)a.recs[slot].index;
 }
 
+// ---- the scattered / shadow rays' query on its own: candidates from the conservative fp32 filter (or the grid walk),
+// exact visits.  out: n x 4 doubles (hit 0/1, t, World.shapes index, 0); ANYHIT: (blocked 0/1, 0, 0, 0).  The 64 rays of a
+// workgroup run as one wave, as in the renderers; a ray with tmin < 0 is an idle lane.
+template <bool ANYHIT>
+__global__ void pt_lanes_probe_kernel(const PtKArgs a, const double *rays, int n, double *out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const double *rp = rays + (size_t)(i < n ? i : 0) * 8;
+  Ray r;
+  r.o = {rp[0], rp[1], rp[2]};
+  r.d = {rp[3], rp[4], rp[5]};
+  r.tmin = rp[6];
+  const double tmax = rp[7];
+  const bool active = i < n && !(r.tmin < 0.0);
+  double t = INFINITY;
+  const int hit = world_query_lanes<ANYHIT>(a, r, tmax, t, active, -1);
+  if (i >= n) return;
+  double *o = out + (size_t)i * 4;
+  o[0] = (active && hit >= 0) ? 1.0 : 0.0;
+  o[1] = (!ANYHIT && active && hit >= 0) ? t : 0.0;
+  o[2] = (!ANYHIT && active && hit >= 0) ? (double)a.recs[hit].index : 0.0;
+  o[3] = 0.0;
+}
+
 // ---- camera probe: primary_ray for caller-supplied (col, row, u_pixel, v_pixel) -------------------------------------
 __global__ void pt_camera_probe_kernel(const PtKArgs a, const double *pix, int n, double *out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;

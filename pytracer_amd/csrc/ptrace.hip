@@ -841,9 +841,8 @@ static void fill_cone_model(PtKArgs &a, const pt_camera *cam, int width, int hei
     ev_started = true;                                                                                       \
   } while (0)
 
-static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *out_dev, hipStream_t st) {
-  PtKArgs a;
-  memset(&a, 0, sizeof a);
+// the scene's tables as the kernels see them (launch(); the probes of ptrace_debug.h)
+static void fill_scene_args(const pt_scene *s, PtKArgs &a) {
   a.recs = s->recs;
   a.aux = s->aux;
   a.hoist = s->hoist;
@@ -856,7 +855,8 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
   for (int q = 0; q < 3; ++q) a.bs_rmax[q] = s->bs_rmax[q];
   a.gs_stride = s->gs_stride;
   a.cs_stride = s->cs_stride;
-  a.bs_levels = s->bs_levels;
+  static const int env_levels_min = getenv("PTRACE_LEVELS_MIN") ? atoi(getenv("PTRACE_LEVELS_MIN")) : 128;
+  a.bs_levels = s->bs_levels && s->n_spheres >= env_levels_min;
   a.grid_cells = s->grid_cells;
   a.grid_occ = s->grid_occ;
   a.grid_balls = s->grid_balls;
@@ -874,14 +874,20 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
     a.grid_inv[q] = s->grid_inv[q];
   }
   a.n_diag = s->n_diag;
-  a.dome_shortcut = s->dome_shortcut ? 1 : 0;
   a.lights = s->lights;
   a.tex = s->tex;
   a.tex_data = s->tex_data;
-  a.out = out_dev;
   a.n_shapes = s->n_shapes;
   a.n_spheres = s->n_spheres;
   a.n_lights = s->n_lights;
+}
+
+static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *out_dev, hipStream_t st) {
+  PtKArgs a;
+  memset(&a, 0, sizeof a);
+  fill_scene_args(s, a);
+  a.dome_shortcut = s->dome_shortcut ? 1 : 0;
+  a.out = out_dev;
   a.cam_kind = cam->kind;
   memcpy(a.cam_m, cam->m, sizeof a.cam_m);
   a.cam_dist = cam->screen_distance;
@@ -1796,6 +1802,32 @@ extern "C" int pt_debug_hit_probe(pt_scene *s, int shape_index, const double *ra
   hipLaunchKernelGGL(pt_hit_probe_kernel, dim3((n + 63) / 64), dim3(64), 0, 0, a, shape_index, rd, n, od);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpy(out, od, (size_t)n * 12 * sizeof(double), hipMemcpyDeviceToHost));
+  (void)hipFree(rd);
+  (void)hipFree(od);
+  return PT_OK;
+}
+
+extern "C" int pt_debug_lanes_probe(pt_scene *s, int anyhit, const double *rays, int n, double *out) {
+  if (!s || !rays || !out || n <= 0) return fail(PT_ERR_INVALID, "bad probe arguments");
+  HIP_TRY(hipSetDevice(s->device));
+  PtKArgs a;
+  memset(&a, 0, sizeof a);
+  fill_scene_args(s, a);
+  PtKArgs *a_dev = nullptr;
+  double *rd = nullptr, *od = nullptr;
+  HIP_TRY(hipMalloc((void **)&a_dev, sizeof a));
+  HIP_TRY(hipMalloc((void **)&rd, (size_t)n * 8 * sizeof(double)));
+  HIP_TRY(hipMalloc((void **)&od, (size_t)n * 4 * sizeof(double)));
+  a.cold = a_dev;
+  HIP_TRY(hipMemcpy(a_dev, &a, sizeof a, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(rd, rays, (size_t)n * 8 * sizeof(double), hipMemcpyHostToDevice));
+  if (anyhit)
+    hipLaunchKernelGGL(pt_lanes_probe_kernel<true>, dim3((n + 63) / 64), dim3(64), 0, 0, a, rd, n, od);
+  else
+    hipLaunchKernelGGL(pt_lanes_probe_kernel<false>, dim3((n + 63) / 64), dim3(64), 0, 0, a, rd, n, od);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpy(out, od, (size_t)n * 4 * sizeof(double), hipMemcpyDeviceToHost));
+  (void)hipFree(a_dev);
   (void)hipFree(rd);
   (void)hipFree(od);
   return PT_OK;

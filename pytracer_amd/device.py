@@ -138,6 +138,15 @@ class DeviceScene:
                                                  out.ctypes.data_as(C.c_void_p)))
         return out
 
+    def lanes_probe(self, rays, anyhit: bool = False) -> np.ndarray:
+        """Diagnostics (include/ptrace_debug.h): the same rays through the query the scattered and shadow rays use
+        (conservative fp32 filter or grid walk, then exact visits).  -> ``[n, 4]``: hit (or blocked), t, index, 0."""
+        rays = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 8)
+        out = np.zeros((rays.shape[0], 4), dtype=np.float64)
+        _lib.check(_lib.lib().pt_debug_lanes_probe(self._h, int(bool(anyhit)), rays.ctypes.data_as(C.c_void_p), rays.shape[0],
+                                                   out.ctypes.data_as(C.c_void_p)))
+        return out
+
     def sync(self) -> None:
         _lib.check(_lib.lib().pt_sync(self._h))
 
