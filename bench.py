@@ -394,6 +394,47 @@ def bracketed_loop(ds, loop, steps):
     return e0.elapsed_time(e1) * 1e-3 / steps
 
 
+def in_flight_rows(flat, cam, par, steps, local_rank, rays_per_step, pmc, n_simd, clock_hz):
+    """The same K frames with 2 and 4 of them in flight (pytracer_amd.pipeline.FramePipeline: one scene handle and one
+    HIP stream per slot): what an animation gets.  NOT the headline -- `value` above is one frame after the other on one
+    stream -- but the same kernel, the same frames (checked), and the figure that says how much of the chip one frame
+    leaves idle."""
+    from pytracer_amd.pipeline import FramePipeline
+
+    rows = {"note": "K frames dealt round-robin to n scene handles / HIP streams, wall clock between two device "
+                    "synchronisations; valu_issue_utilisation = the headline kernel's priced issue cycles per launch "
+                    "(roofline.executed) / (SIMDs x clock x time per frame)"}
+    H, W = par.height, par.width
+    ref = None
+    for n in (1, 2, 4):
+        with FramePipeline(flat, n_in_flight=n, device=local_rank) as pipe:
+            pipe.set_count_rays(False)
+            pipe.set_timing(False)
+            outs = [torch.empty((H, W, 3), dtype=torch.float32, device=f"cuda:{local_rank}") for _ in range(n)]
+            for i in range(2 * n):
+                pipe.submit(cam, par, outs[i % n])
+            pipe.wait()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                pipe.submit(cam, par, outs[i % n])
+            pipe.wait()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            if ref is None:
+                ref = outs[0].clone()
+            same = all(bool(torch.equal(ref, o)) for o in outs)
+        row = {"value": rays_per_step * steps / dt / 1e6, "unit": "Mray/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+               "frames_identical_to_one_stream": same}
+        if pmc is not None:
+            pr = priced_issue(pmc["counters"], n_simd * (dt / steps) * clock_hz)
+            if pr is not None:
+                row["valu_issue_utilisation"] = pr["frac"]
+                row["fp64_pipe_frac"] = pr["fp64_pipe_frac"]
+        rows[str(n)] = row
+    return rows
+
+
 def run_single(args, local_rank):
     W, H = 1280, 720
     world = scenes.synthetic_world(32, with_plane=True)
@@ -514,6 +555,7 @@ def run_single(args, local_rank):
         "roofline": roofline,
     }
     ds.close()
+    result["frames_in_flight"] = in_flight_rows(flat, cam, par, args.steps, local_rank, rays_per_step, pmc, n_simd, clock_hz)
     if not args.no_extras:
         result["extra"] = extra_rows(local_rank)
         result["boundary"] = boundary_rows(flat, local_rank, rays_per_step)

@@ -1,0 +1,67 @@
+"""Several frames in flight on one GPU.
+
+The reference renders an animation as one process per frame (``main.py:76-214`` called once per camera angle); here a
+frame is one kernel launch of ~10 us whose waves are bound by dependent fp64 latency, and a launch has a fixed cost of
+~2-3 us (dispatch, ramp, drain: ``tools/micro/ramp.hip``) that nothing inside the frame can hide.  Consecutive frames
+are independent, so the next frame can: ``FramePipeline`` keeps ``n_in_flight`` scene handles (each with its own
+per-camera tables and counters: one handle must not render two frames at once) and as many HIP streams, and frame ``i``
+goes to slot ``i % n_in_flight``.  The frames are bit-identical to the ones a single stream renders.
+"""
+from typing import List, Optional
+
+import torch
+
+from . import abi
+from .device import DeviceScene
+
+
+class FramePipeline:
+    def __init__(self, flat: abi.FlatScene, n_in_flight: int = 2, device: int = 0):
+        if n_in_flight < 1:
+            raise ValueError("n_in_flight must be >= 1")
+        self.device = torch.device("cuda", device)
+        self.scenes: List[DeviceScene] = [DeviceScene(flat, device=device) for _ in range(n_in_flight)]
+        self.streams = [torch.cuda.Stream(device=self.device) for _ in range(n_in_flight)]
+        self._busy: List[Optional[torch.Tensor]] = [None] * n_in_flight  # keeps a slot's output alive while it renders
+        self._next = 0
+
+    @property
+    def n_in_flight(self) -> int:
+        return len(self.scenes)
+
+    def submit(self, cam: abi.Camera, params: abi.Params, out: torch.Tensor) -> int:
+        """Enqueue one frame into ``out`` (a CUDA tensor of ``pt_output_bytes`` bytes) on the next slot's stream; returns
+        the slot.  Work already queued on that slot runs first (stream order); nothing here waits on the host."""
+        if not out.is_cuda or not out.is_contiguous():
+            raise ValueError("out must be a contiguous CUDA tensor")
+        slot = self._next
+        self._next = (slot + 1) % len(self.scenes)
+        self.scenes[slot].render_into(cam, params, out.data_ptr(), out.numel() * out.element_size(), self.streams[slot].cuda_stream)
+        self._busy[slot] = out
+        return slot
+
+    def wait(self, slot: Optional[int] = None) -> None:
+        """Block until the frames of ``slot`` (default: of every slot) are done."""
+        for s in range(len(self.scenes)) if slot is None else (slot,):
+            self.streams[s].synchronize()
+            self._busy[s] = None
+
+    def set_count_rays(self, enable: bool) -> None:
+        for ds in self.scenes:
+            ds.set_count_rays(enable)
+
+    def set_timing(self, enable: bool) -> None:
+        for ds in self.scenes:
+            ds.set_timing(enable)
+
+    def close(self) -> None:
+        self.wait()
+        for ds in self.scenes:
+            ds.close()
+        self.scenes = []
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()

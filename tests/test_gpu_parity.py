@@ -1129,3 +1129,30 @@ def test_tile_kernels_keep_their_occupancy(dev):
         for renderer, limit in ((abi.RENDERER_FLAT, 96), (abi.RENDERER_ONOFF, 80)):
             ds.render_into(cam, abi.make_params(320, 180, renderer, out_format=abi.OUT_F32), out.data_ptr(), out.numel() * 4, None)
             assert 0 < ds.stats().vgprs <= limit, (renderer, ds.stats().vgprs)
+
+
+def test_frames_in_flight_are_the_frames_of_one_stream(dev):
+    """pytracer_amd.pipeline.FramePipeline: an animation (the camera turns from frame to frame, as the reference's demo
+    does with --angle-deg) with three frames in flight; every frame bit-identical to the one a single handle renders."""
+    import torch
+
+    from pytracer_amd import flatten, hostmodel as hm, scenes
+    from pytracer_amd.pipeline import FramePipeline
+
+    W, H = 320, 176
+    flat = flatten.flatten_world(scenes.synthetic_world(32, with_plane=True))
+    cams = [flatten.flatten_camera(hm.PerspectiveCamera(1.0, W / H, hm.rotation_z(7.0 * k) * hm.translation(hm.Vec(-1.0, 0.0, 1.0))))
+            for k in range(9)]
+    for renderer, kw in ((abi.RENDERER_FLAT, {}), (abi.RENDERER_PATHTRACER, dict(samples_per_side=2, num_of_rays=1, max_depth=3,
+                                                                                 rr_limit=2, path_state=45, path_seq=54))):
+        par = abi.make_params(W, H, renderer, out_format=abi.OUT_F32, **kw)
+        outs = [torch.empty((H, W, 3), dtype=torch.float32, device="cuda") for _ in cams]
+        with FramePipeline(flat, n_in_flight=3) as pipe:
+            for cam, out in zip(cams, outs):
+                pipe.submit(cam, par, out)
+            pipe.wait()
+        with dev.DeviceScene(flat) as ds:
+            for k, cam in enumerate(cams):
+                ref = ds.render(cam, abi.copy_params(par, out_format=abi.OUT_F64)).astype(np.float32)
+                assert np.array_equal(outs[k].cpu().numpy().view(np.uint32), ref.view(np.uint32)), (renderer, k)
+        assert not np.array_equal(outs[0].cpu().numpy(), outs[5].cpu().numpy())

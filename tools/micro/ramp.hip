@@ -1,0 +1,115 @@
+// How long does a launch of G workgroups take to get going and to drain on MI355X (gfx950)?  Every wave spins for a fixed
+// number of cycles (s_memtime) and records when it started and ended; the kernel's duration (hipEvents around a batch of
+// launches) minus the spin is what dispatch, ramp and drain cost for that launch shape.
+//
+//   ./ramp            table over launch shapes (workgroups x threads, LDS per workgroup, registers per lane)
+// Build: hipcc --offload-arch=gfx950 -O2 -o ramp tools/micro/ramp.hip
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <vector>
+#define CHK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+template <int NV>
+__global__ void __launch_bounds__(256) spin_kernel(unsigned long long spin, unsigned long long *stamps, float *sink) {
+  extern __shared__ char lds_claim[];
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  float v[NV];  // registers the launch has to hand out
+#pragma unroll
+  for (int k = 0; k < NV; ++k) v[k] = (float)(threadIdx.x + k);
+  unsigned long long t = t0;
+  while (t - t0 < spin) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = v[k] * 1.0001f + 0.5f;
+    t = __builtin_amdgcn_s_memtime();
+  }
+  float acc = 0.0f;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) acc += v[k];
+  if (acc == 123.456f) sink[0] = acc;
+  if (stamps && (threadIdx.x & 63) == 0) {
+    const size_t w = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    stamps[2 * w] = t0;
+    stamps[2 * w + 1] = __builtin_amdgcn_s_memtime();
+  }
+}
+
+template <int NV>
+static int run(int G, int B, int lds, unsigned long long spin, double clock_hz) {
+  unsigned long long *stamps = nullptr;
+  float *sink = nullptr;
+  const size_t nw = (size_t)G * (B / 64);
+  CHK(hipMalloc(&stamps, nw * 16));
+  CHK(hipMalloc(&sink, 4));
+  hipEvent_t e0, e1;
+  CHK(hipEventCreate(&e0));
+  CHK(hipEventCreate(&e1));
+  CHK(hipFuncSetAttribute((const void *)spin_kernel<NV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  for (int k = 0; k < 5; ++k) hipLaunchKernelGGL(spin_kernel<NV>, dim3(G), dim3(B), lds, 0, spin, stamps, sink);
+  CHK(hipDeviceSynchronize());
+  const int K = 200;
+  CHK(hipEventRecord(e0));
+  for (int k = 0; k < K; ++k) hipLaunchKernelGGL(spin_kernel<NV>, dim3(G), dim3(B), lds, 0, spin, stamps, sink);
+  CHK(hipEventRecord(e1));
+  CHK(hipEventSynchronize(e1));
+  float ms = 0.0f;
+  CHK(hipEventElapsedTime(&ms, e0, e1));
+  std::vector<unsigned long long> h(nw * 2);
+  CHK(hipMemcpy(h.data(), stamps, nw * 16, hipMemcpyDeviceToHost));
+  unsigned long long first = ~0ULL, last_start = 0, last_end = 0;
+  for (size_t w = 0; w < nw; ++w) {
+    first = std::min(first, h[2 * w]);
+    last_start = std::max(last_start, h[2 * w]);
+    last_end = std::max(last_end, h[2 * w + 1]);
+  }
+  // s_memtime counts at 100 MHz on this part (tools/micro/clk.hip): report in microseconds
+  const double tick_us = 1e6 / clock_hz;
+  printf("%5d x %3d thr  LDS %6d B  %3d regs  spin %5.2f us | launch %6.2f us  first->last wave start %6.2f us  first start->last end %6.2f us\n", G, B,
+         lds, NV, spin * tick_us, ms * 1e3 / K, (last_start - first) * tick_us, (last_end - first) * tick_us);
+  (void)hipFree(stamps);
+  (void)hipFree(sink);
+  return 0;
+}
+
+int main() {
+  // the clock s_memtime runs at: measured against hipEvents
+  double clock_hz = 1e8;
+  {
+    unsigned long long *stamps = nullptr;
+    float *sink = nullptr;
+    CHK(hipMalloc(&stamps, 16));
+    CHK(hipMalloc(&sink, 4));
+    hipEvent_t e0, e1;
+    CHK(hipEventCreate(&e0));
+    CHK(hipEventCreate(&e1));
+    const unsigned long long spin = 2000000ULL;
+    hipLaunchKernelGGL(spin_kernel<8>, dim3(1), dim3(64), 0, 0, 1000ULL, stamps, sink);
+    CHK(hipDeviceSynchronize());
+    CHK(hipEventRecord(e0));
+    hipLaunchKernelGGL(spin_kernel<8>, dim3(1), dim3(64), 0, 0, spin, stamps, sink);
+    CHK(hipEventRecord(e1));
+    CHK(hipEventSynchronize(e1));
+    float ms = 0.0f;
+    CHK(hipEventElapsedTime(&ms, e0, e1));
+    clock_hz = (double)spin / (ms * 1e-3);
+    printf("s_memtime: %.1f MHz (a spin of %llu ticks took %.3f ms)\n", clock_hz / 1e6, spin, ms);
+  }
+  const unsigned long long us8 = (unsigned long long)(8e-6 * clock_hz), us0 = 0ULL;
+  printf("-- no work: what the launch itself costs\n");
+  run<8>(1, 64, 0, us0, clock_hz);
+  run<8>(920, 256, 0, us0, clock_hz);
+  run<8>(920, 256, 12672, us0, clock_hz);
+  run<88>(920, 256, 12672, us0, clock_hz);
+  printf("-- every wave spins 8 us (the 16x16-tile kernel's waves live ~8 us)\n");
+  run<8>(256, 256, 0, us8, clock_hz);
+  run<8>(920, 256, 0, us8, clock_hz);
+  run<8>(920, 256, 12672, us8, clock_hz);
+  run<88>(920, 256, 12672, us8, clock_hz);
+  run<88>(1840, 128, 6336, us8, clock_hz);
+  run<88>(3680, 64, 3168, us8, clock_hz);
+  run<88>(460, 512, 25344, us8, clock_hz);
+  run<88>(1024, 256, 12672, us8, clock_hz);
+  run<88>(512, 256, 12672, us8, clock_hz);
+  run<88>(2048, 256, 12672, us8, clock_hz);
+  return 0;
+}
