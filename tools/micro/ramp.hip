@@ -1,6 +1,7 @@
 // How long does a launch of G workgroups take to get going and to drain on MI355X (gfx950)?  Every wave spins for a fixed
-// number of cycles (s_memtime) and records when it started and ended; the kernel's duration (hipEvents around a batch of
-// launches) minus the spin is what dispatch, ramp and drain cost for that launch shape.
+// number of cycles (s_memtime); the time per launch (hipEvents around a batch of launches on one stream) minus the spin
+// is what dispatch, ramp and drain cost for that launch shape.  (Wave time stamps are not compared across the chip: the
+// XCDs' counters do not share an origin.)
 //
 //   ./ramp            table over launch shapes (workgroups x threads, LDS per workgroup, registers per lane)
 // Build: hipcc --offload-arch=gfx950 -O2 -o ramp tools/micro/ramp.hip
@@ -13,6 +14,11 @@
 template <int NV>
 __global__ void __launch_bounds__(256) spin_kernel(unsigned long long spin, unsigned long long *stamps, float *sink) {
   extern __shared__ char lds_claim[];
+  // census: waves running at this moment / the most there ever were (stamps[0], stamps[1])
+  if (stamps && (threadIdx.x & 63) == 0) {
+    const unsigned long long c = atomicAdd(stamps, 1ULL) + 1ULL;
+    atomicMax(stamps + 1, c);
+  }
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
   float v[NV];  // registers the launch has to hand out
 #pragma unroll
@@ -27,11 +33,7 @@ __global__ void __launch_bounds__(256) spin_kernel(unsigned long long spin, unsi
 #pragma unroll
   for (int k = 0; k < NV; ++k) acc += v[k];
   if (acc == 123.456f) sink[0] = acc;
-  if (stamps && (threadIdx.x & 63) == 0) {
-    const size_t w = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    stamps[2 * w] = t0;
-    stamps[2 * w + 1] = __builtin_amdgcn_s_memtime();
-  }
+  if (stamps && (threadIdx.x & 63) == 0) atomicAdd(stamps, ~0ULL);  // (-1)
 }
 
 template <int NV>
@@ -45,27 +47,30 @@ static int run(int G, int B, int lds, unsigned long long spin, double clock_hz) 
   CHK(hipEventCreate(&e0));
   CHK(hipEventCreate(&e1));
   CHK(hipFuncSetAttribute((const void *)spin_kernel<NV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  for (int k = 0; k < 5; ++k) hipLaunchKernelGGL(spin_kernel<NV>, dim3(G), dim3(B), lds, 0, spin, stamps, sink);
+  for (int k = 0; k < 5; ++k) hipLaunchKernelGGL(spin_kernel<NV>, dim3(G), dim3(B), lds, 0, spin, (unsigned long long *)nullptr, sink);
   CHK(hipDeviceSynchronize());
+  CHK(hipMemset(stamps, 0, 16));
+  hipLaunchKernelGGL(spin_kernel<NV>, dim3(G), dim3(B), lds, 0, spin, stamps, sink);
+  CHK(hipDeviceSynchronize());
+  unsigned long long census[2] = {0, 0};
+  CHK(hipMemcpy(census, stamps, 16, hipMemcpyDeviceToHost));
   const int K = 200;
   CHK(hipEventRecord(e0));
-  for (int k = 0; k < K; ++k) hipLaunchKernelGGL(spin_kernel<NV>, dim3(G), dim3(B), lds, 0, spin, stamps, sink);
+  for (int k = 0; k < K; ++k) hipLaunchKernelGGL(spin_kernel<NV>, dim3(G), dim3(B), lds, 0, spin, (unsigned long long *)nullptr, sink);
   CHK(hipEventRecord(e1));
   CHK(hipEventSynchronize(e1));
   float ms = 0.0f;
   CHK(hipEventElapsedTime(&ms, e0, e1));
-  std::vector<unsigned long long> h(nw * 2);
-  CHK(hipMemcpy(h.data(), stamps, nw * 16, hipMemcpyDeviceToHost));
-  unsigned long long first = ~0ULL, last_start = 0, last_end = 0;
-  for (size_t w = 0; w < nw; ++w) {
-    first = std::min(first, h[2 * w]);
-    last_start = std::max(last_start, h[2 * w]);
-    last_end = std::max(last_end, h[2 * w + 1]);
+  int regs = 0, resident = 0;
+  {
+    hipFuncAttributes fa;
+    CHK(hipFuncGetAttributes(&fa, (const void *)spin_kernel<NV>));
+    regs = fa.numRegs;
+    CHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, (const void *)spin_kernel<NV>, B, lds));
   }
-  // s_memtime counts at 100 MHz on this part (tools/micro/clk.hip): report in microseconds
   const double tick_us = 1e6 / clock_hz;
-  printf("%5d x %3d thr  LDS %6d B  %3d regs  spin %5.2f us | launch %6.2f us  first->last wave start %6.2f us  first start->last end %6.2f us\n", G, B,
-         lds, NV, spin * tick_us, ms * 1e3 / K, (last_start - first) * tick_us, (last_end - first) * tick_us);
+  printf("%5d x %3d threads  LDS %6d B  %3d VGPRs (runtime: %d workgroups fit a CU; most waves running at once: %llu of %llu)  every wave spins %5.2f us | %6.2f us per launch, back to back -> %5.2f us beyond the spin\n", G, B,
+         lds, regs, resident, census[1], (unsigned long long)nw, spin * tick_us, ms * 1e3 / K, ms * 1e3 / K - spin * tick_us);
   (void)hipFree(stamps);
   (void)hipFree(sink);
   return 0;
@@ -83,10 +88,10 @@ int main() {
     CHK(hipEventCreate(&e0));
     CHK(hipEventCreate(&e1));
     const unsigned long long spin = 2000000ULL;
-    hipLaunchKernelGGL(spin_kernel<8>, dim3(1), dim3(64), 0, 0, 1000ULL, stamps, sink);
+    hipLaunchKernelGGL(spin_kernel<8>, dim3(1), dim3(64), 0, 0, 1000ULL, (unsigned long long *)nullptr, sink);
     CHK(hipDeviceSynchronize());
     CHK(hipEventRecord(e0));
-    hipLaunchKernelGGL(spin_kernel<8>, dim3(1), dim3(64), 0, 0, spin, stamps, sink);
+    hipLaunchKernelGGL(spin_kernel<8>, dim3(1), dim3(64), 0, 0, spin, (unsigned long long *)nullptr, sink);
     CHK(hipEventRecord(e1));
     CHK(hipEventSynchronize(e1));
     float ms = 0.0f;
@@ -99,17 +104,24 @@ int main() {
   run<8>(1, 64, 0, us0, clock_hz);
   run<8>(920, 256, 0, us0, clock_hz);
   run<8>(920, 256, 12672, us0, clock_hz);
-  run<88>(920, 256, 12672, us0, clock_hz);
+  run<40>(920, 256, 12672, us0, clock_hz);
   printf("-- every wave spins 8 us (the 16x16-tile kernel's waves live ~8 us)\n");
   run<8>(256, 256, 0, us8, clock_hz);
   run<8>(920, 256, 0, us8, clock_hz);
   run<8>(920, 256, 12672, us8, clock_hz);
+  run<40>(920, 256, 12672, us8, clock_hz);
+  run<40>(1840, 128, 6336, us8, clock_hz);
+  run<40>(3680, 64, 3168, us8, clock_hz);
+  run<40>(1024, 256, 12672, us8, clock_hz);
+  run<40>(512, 256, 12672, us8, clock_hz);
   run<88>(920, 256, 12672, us8, clock_hz);
-  run<88>(1840, 128, 6336, us8, clock_hz);
-  run<88>(3680, 64, 3168, us8, clock_hz);
-  run<88>(460, 512, 25344, us8, clock_hz);
-  run<88>(1024, 256, 12672, us8, clock_hz);
-  run<88>(512, 256, 12672, us8, clock_hz);
-  run<88>(2048, 256, 12672, us8, clock_hz);
+  printf("-- how many waves are resident at once?  64-thread workgroups, every wave spins 8 us: the launch takes ~10 us while all of\n"
+         "   them fit and ~18 us as soon as some have to wait for a slot\n");
+  for (int g = 2048; g <= 9216; g += 512) run<4>(g, 64, 0, us8, clock_hz);
+  for (int g = 2048; g <= 9216; g += 512) run<24>(g, 64, 0, us8, clock_hz);
+  for (int g = 2048; g <= 6144; g += 512) run<40>(g, 64, 0, us8, clock_hz);
+  for (int g = 1024; g <= 5632; g += 512) run<56>(g, 64, 0, us8, clock_hz);
+  for (int g = 1024; g <= 5632; g += 512) run<88>(g, 64, 0, us8, clock_hz);
+  for (int g = 1024; g <= 4608; g += 512) run<120>(g, 64, 0, us8, clock_hz);
   return 0;
 }
