@@ -7,9 +7,13 @@ import ctypes as C
 from pytracer_amd import _lib
 W, H = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (1280, 720)
 nsph = int(sys.argv[3]) if len(sys.argv) > 3 else 32
-flat = flatten.flatten_world(scenes.synthetic_world(nsph, wide=nsph > 64, with_plane=bool(int(os.environ.get('DBG_PLANE', 0)))))
+world = scenes.synthetic_world(nsph, wide=nsph > 64, with_plane=bool(int(os.environ.get('DBG_PLANE', 0))))
+for l in range(int(os.environ.get('DBG_LIGHTS', 0))):  # (as tools/kbench.py's "pl")
+    from pytracer_amd import hostmodel as hm
+    world.add_light(hm.PointLight(hm.Vec(-3.0 + 4.0 * l, 6.0 - 9.0 * l, 8.0), hm.Color(1.0, 0.9, 0.8), 0.0))
+flat = flatten.flatten_world(world)
 cam = flatten.flatten_camera(scenes.synthetic_camera(W, H))
-REND = {'path': abi.RENDERER_PATHTRACER, 'flat': abi.RENDERER_FLAT, 'onoff': abi.RENDERER_ONOFF}[os.environ.get('DBG_RENDERER', 'path')]
+REND = {'path': abi.RENDERER_PATHTRACER, 'flat': abi.RENDERER_FLAT, 'onoff': abi.RENDERER_ONOFF, 'pointlight': abi.RENDERER_POINTLIGHT}[os.environ.get('DBG_RENDERER', 'path')]
 par = abi.make_params(W, H, REND, samples_per_side=int(os.environ.get('DBG_S', 4)), num_of_rays=int(os.environ.get('DBG_N', 1)), max_depth=int(os.environ.get('DBG_D', 3)), rr_limit=3, path_state=45, path_seq=54,
                       pcg_mode=int(os.environ.get('DBG_MODE', 1)), n_ranks=int(os.environ.get('DBG_RANKS', 1)), rank=int(os.environ.get('DBG_RANK', 0)), row_block=8)
 ds = DeviceScene(flat)
