@@ -406,8 +406,6 @@ def in_flight_rows(flat, cam, par, steps, local_rank, rays_per_step, pmc, n_simd
                     "(roofline.executed) / (SIMDs x clock x time per frame)"}
     H, W = par.height, par.width
     ref = None
-    steps = max(40, steps // 4)  # (short: these launches overlap, and rocprofv3's average of the headline kernel over the
-    #                                whole command should stay the back-to-back figure)
     for n in (1, 2, 4):
         with FramePipeline(flat, n_in_flight=n, device=local_rank) as pipe:
             pipe.set_count_rays(False)
@@ -558,7 +556,8 @@ def run_single(args, local_rank):
         "roofline": roofline,
     }
     ds.close()
-    result["frames_in_flight"] = in_flight_rows(flat, cam, par, args.steps, local_rank, rays_per_step, pmc, n_simd, clock_hz)
+    if args.in_flight:
+        result["frames_in_flight"] = in_flight_rows(flat, cam, par, args.steps, local_rank, rays_per_step, pmc, n_simd, clock_hz)
     if not args.no_extras:
         result["extra"] = extra_rows(local_rank)
         result["boundary"] = boundary_rows(flat, local_rank, rays_per_step)
@@ -781,6 +780,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--in-flight", action="store_true",
+                    help="N=1: also time the same frames with 2 and 4 of them in flight (pytracer_amd.pipeline); off by default so "
+                         "that every launch of the headline kernel in the default command runs back to back")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Profile bench.py itself on the GPU box: kernel trace + PMC passes (each in its own run, nothing combined
 # with a trace domain), then condense them into the JSON files bench.py reads.
-# usage: tools/prof_bench.sh <tag>          (run from the repository root on the GPU box)
+# usage: tools/prof_bench.sh <tag> [trace-only]   (run from the repository root on the GPU box)
 set -e
 TAG=$1
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -13,6 +13,12 @@ BENCH="python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline"
 # the kernel trace runs bench.py's DEFAULT command (the one the driver runs): most launches of the headline kernel
 # in it are the timed ones, so its average is comparable with roofline.avg_kernel_ms of the line
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py --no-cpu-baseline > $OUT/trace.json 2> $OUT/trace.err
+if [ "$2" = "trace-only" ]; then
+  f=$(find $OUT/trace -name "*kernel_stats.csv" | head -1)
+  cp $f $OUT/kernel_stats.csv
+  head -12 $OUT/kernel_stats.csv | cut -d, -f1-4
+  exit 0
+fi
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY --output-format csv -d $OUT/pmc1 -- $BENCH > $OUT/pmc1.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY --output-format csv -d $OUT/pmc2 -- $BENCH > $OUT/pmc2.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_CVT SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_BRANCH --output-format csv -d $OUT/pmc2b -- $BENCH > $OUT/pmc2b.log 2>&1
