@@ -2731,7 +2731,7 @@ PT_DEV int nth_set_bit(unsigned long long m, int n) {
 
 #ifdef PT_DEBUG_TIME
 #define PT_TRACE_LEN 8192
-__device__ unsigned long long pt_trace[PT_TRACE_LEN];
+__device__ unsigned long long pt_trace[PT_TRACE_LEN + 64 * 80];  // (+ the traced unit's validated draw counts: [pixel][sample], tools/dbgdraws.py)
 #define PT_UNITLOG_LEN 16384
 // per work unit of the second pass: start tick, end tick, rounds | iterations << 32, pixels | lanes per pixel << 8 |
 // workgroup << 16, then the unit's cycles in: scattered-ray queries, shade, sample start + primary query, commit + fetch
@@ -2808,9 +2808,10 @@ PT_DEV long long next_pixel(const PtKArgs &a, bool need, long long npix) {
 //   PT_PCG_SAMPLE  every sample owns its generator: the L samples are independent, all of them count.
 //   PT_PCG_PIXEL   the samples of a pixel share ONE generator, consumed in program order: where sample k+1
 //     starts in the stream depends on how many numbers sample k drew, which is only known once its path has
-//     ended.  Lane j therefore SPECULATES: it assumes that each of the j samples before it draws `cpred`
-//     numbers (what the last validated sample of this pixel drew) and starts from the state j * cpred draws
-//     ahead (pcg_advance).  After the round the samples are validated in order: sample j counts if and only
+//     ended.  Lane j therefore SPECULATES: it guesses what each of the j samples before it draws -- what the last
+//     validated sample of the pixel drew, or, where that has been the better guess for this pixel so far, what each
+//     sample's upper neighbour in the S x S grid of strata drew (a pixel across an edge repeats its row of short and
+//     long paths; `hist`, `pscore`) -- and starts from the state that many draws ahead (pcg_advance).  After the round the samples are validated in order: sample j counts if and only
 //     if the state it started from IS the state sample j-1 ended with -- then everything it computed is what
 //     the sequential program computes -- and the first one that started elsewhere is thrown away together
 //     with everything behind it and repeated in the next round, now from the right state.  The first lane
@@ -2917,7 +2918,13 @@ PT_DEV void path_trace(const PtKArgs &a) {
   bool in_unit = false;             // the lane belongs to a pixel of the unit
   int vbase = 0;                    // samples of the pixel validated so far (same in all lanes of the pixel)
   uint64_t vstate = 0;              // PT_PCG_PIXEL: generator state behind the last validated sample
-  unsigned cpred = 0;               // PT_PCG_PIXEL: draws per sample the next round assumes
+  // PT_PCG_PIXEL: what the pixel's last eight validated samples drew, a byte each, the latest in the low byte.  The guess
+  // for sample k is what sample k - S drew -- its neighbour one row up in the S x S grid of strata (imagetracer.py:86-93):
+  // a pixel across an edge repeats its pattern of short and long paths row after row, where "what the last sample drew"
+  // is wrong twice per row.  (S > 8: the sample before it.)
+  uint64_t hist = 0;
+  int pscore = 0;                   // ... how much more often the upper neighbour was the better guess than the predecessor (per pixel)
+  const int hperiod = (S >= 1 && S <= 8) ? S : 1;
   uint64_t st_start = 0;            // state this lane's sample started from
   unsigned srays = 0, prays = 0;    // rays of the current sample; of the pixel's validated samples
   unsigned long long gpix = 0;      // global pixel index (seeds)
@@ -2948,7 +2955,18 @@ PT_DEV void path_trace(const PtKArgs &a) {
     if (pcg_mode == PT_PCG_SAMPLE)
       pcg_seed(pcg, c->s0, c->q0 + gpix * (unsigned)nsamp + (unsigned)samp);
     else
-      pcg.state = pcg_advance(vstate, pcg.inc, (unsigned)jlane * cpred);
+    {
+      // (sample vbase + i: what its upper neighbour vbase + i - period drew, if the pixel has got that far and that guess
+      //  has been the better one so far; else what the last validated sample drew)
+      const int period = hperiod;
+      unsigned ahead = (unsigned)jlane * ((unsigned)hist & 0xffu);
+      if (pscore > 0) {
+        ahead = 0;
+        for (int i = 0; i < jlane; ++i)
+          ahead += (unsigned)(hist >> (vbase + (i % period) >= period ? 8 * (period - 1 - (i % period)) : 0)) & 0xffu;
+      }
+      pcg.state = pcg_advance(vstate, pcg.inc, ahead);
+    }
     pcg.n = 0;
     st_start = pcg.state;
     srays = 0;
@@ -3131,7 +3149,7 @@ PT_DEV void path_trace(const PtKArgs &a) {
         if (__any(mode == 3)) {
           // ---- end of a round: validate the pixel's samples in order, add them up in order ----
           // (every lane of a pixel runs the same loop over the pixel's L lanes and ends with the same
-          //  vbase / vstate / cpred; only the values in the leader are used for the pixel's result)
+          //  vbase / vstate / hist; only the values in the leader are used for the pixel's result)
           const bool fin = mode == 3;
           bool chain = true;
 #ifdef PT_DEBUG_TIME
@@ -3166,9 +3184,15 @@ PT_DEV void path_trace(const PtKArgs &a) {
                 cum.z = rz_;
               }
               vstate = s_to;
-              cpred = s_draws;
+              if (vbase >= hperiod)  // which guess would have been right for this sample: its upper neighbour's draws, or its predecessor's?
+                pscore += (int)(((unsigned)(hist >> (8 * (hperiod - 1))) & 0xffu) == (s_draws & 0xffu)) - (int)(((unsigned)hist & 0xffu) == (s_draws & 0xffu));
+              hist = (hist << 8) | (uint64_t)(s_draws & 0xffu);
               prays += s_rays;
               vbase++;
+#ifdef PT_DEBUG_TIME
+              if (tracing && in_unit && lane == leader && (leader / L) < 64 && vbase <= 80)
+                pt_trace[PT_TRACE_LEN + (leader / L) * 80 + (vbase - 1)] = ((unsigned long long)s_draws << 16) | ((unsigned long long)(leader / L) << 8) | 0xEEULL;
+#endif
             }
           }
           mode = 2;
@@ -3320,7 +3344,8 @@ PT_DEV void path_trace(const PtKArgs &a) {
               pcg_seed(pcg, ca->s0, ca->q0 + gpix);
               vstate = pcg.state;
             }
-            cpred = (unsigned)ca->spec_draws;
+            hist = 0x0101010101010101ULL * (uint64_t)(ca->spec_draws & 0xff);
+            pscore = 0;
             vbase = 0;
             prays = 0;
             cum.x = 0.0;

@@ -1730,7 +1730,7 @@ extern "C" int pt_debug_read_unitlog(unsigned long long *out, int n_units) {
 }
 extern "C" int pt_debug_read_trace(unsigned long long *out, int n) {
   HIP_TRY(hipDeviceSynchronize());
-  HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(pt_trace), (size_t)std::min(n, PT_TRACE_LEN) * sizeof(unsigned long long)));
+  HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(pt_trace), (size_t)std::min(n, PT_TRACE_LEN + 64 * 80) * sizeof(unsigned long long)));
   return PT_OK;
 }
 #endif
