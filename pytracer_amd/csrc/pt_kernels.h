@@ -3191,7 +3191,7 @@ PT_DEV void path_trace(const PtKArgs &a) {
               vbase++;
 #ifdef PT_DEBUG_TIME
               if (tracing && in_unit && lane == leader && (leader / L) < 64 && vbase <= 80)
-                pt_trace[PT_TRACE_LEN + (leader / L) * 80 + (vbase - 1)] = ((unsigned long long)s_draws << 16) | ((unsigned long long)(leader / L) << 8) | 0xEEULL;
+                pt_trace[PT_TRACE_LEN + (leader / L) * 80 + (vbase - 1)] = ((unsigned long long)ulog_rounds << 32) | ((unsigned long long)s_draws << 16) | ((unsigned long long)(leader / L) << 8) | 0xEEULL;
 #endif
             }
           }
@@ -3266,7 +3266,7 @@ PT_DEV void path_trace(const PtKArgs &a) {
           const int seq = (int)__builtin_amdgcn_readfirstlane((int)uid);
           PT_STAMP(6);
 #ifdef PT_DEBUG_TIME
-          tracing = seq == cold_args(a)->dbg_trace_unit;
+          tracing = seq == cold_args(a)->dbg_trace_unit;  // (or, below, the unit that starts at a given flagged pixel of a given region)
           if (LAT && tracing && lane == 0) {
             const unsigned long long *wv = pt_dbg_wave + (size_t)((blockIdx.x * PT_BLOCK + threadIdx.x) >> 6) * 8;
             for (int q = 0; q < 3; ++q) dbg_q[q] = __hip_atomic_load(wv + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -3304,6 +3304,9 @@ PT_DEV void path_trace(const PtKArgs &a) {
           const int4 unit = ca->units[seq];
 #endif
           const int region = unit.x, first = unit.y & 0xff, count = (unit.y >> 8) & 0xff;
+#ifdef PT_DEBUG_TIME
+          if (cold_args(a)->dbg_trace_unit <= -2) tracing = (-2 - cold_args(a)->dbg_trace_unit) == region * 64 + first;  // (unit numbers vary from frame to frame)
+#endif
           const unsigned long long todo = (unsigned long long)(unsigned)unit.z | ((unsigned long long)(unsigned)unit.w << 32);  // the region's flagged pixels
           const int ry = region / regions_x, rx = region - ry * regions_x;
           const int gr0 = global_row(a, ry * PT_REGION);
@@ -3326,7 +3329,8 @@ PT_DEV void path_trace(const PtKArgs &a) {
 #ifdef PT_DEBUG_TIME
           if (lane == 0 && seq < PT_UNITLOG_LEN) {
             pt_unitlog[seq * 8 + 0] = __builtin_amdgcn_s_memtime();
-            pt_unitlog[seq * 8 + 3] = (unsigned long long)count | ((unsigned long long)L << 8) | ((unsigned long long)blockIdx.x << 16);
+            pt_unitlog[seq * 8 + 3] = (unsigned long long)count | ((unsigned long long)L << 8) | ((unsigned long long)(blockIdx.x & 0x3ff) << 16) |
+                                      ((unsigned long long)first << 26) | ((unsigned long long)region << 32);
           }
 #endif
           const int pidx = lane / L;

@@ -41,11 +41,12 @@ for name in sys.argv[1:]:
     dur = end - start
     rounds, iters = a[:, 2] & 0xffffffff, a[:, 2] >> 32
     count, L = a[:, 3] & 0xff, (a[:, 3] >> 8) & 0xff
+    first, region = (a[:, 3] >> 26) & 0x3f, a[:, 3] >> 32
     print(f"{name}: kernel {st.kernel_ms:.3f} ms, {n} units (ppu {q[10]}), unit duration kcycles: mean {dur.mean():.0f} p50 {np.median(dur):.0f} "
           f"p90 {np.percentile(dur, 90):.0f} max {dur.max():.0f}; last end {end.max():.0f} kcycles; late starters (start > 10 kcyc): {(start > 10).sum()}")
     order = np.argsort(-dur)[:8]
     for i in order:
-        print(f"   unit {i}: count {count[i]} L {L[i]} rounds {rounds[i]} iterations {iters[i]} start {start[i]:.0f} dur {dur[i]:.0f} kcyc -> {dur[i] / max(1, rounds[i]):.1f} per round, {dur[i] / max(1, iters[i]):.1f} per iteration")
+        print(f"   unit {i} (PTRACE_TRACE_UNIT={-2 - (int(region[i]) * 64 + int(first[i]))}): count {count[i]} L {L[i]} rounds {rounds[i]} iterations {iters[i]} start {start[i]:.0f} dur {dur[i]:.0f} kcyc -> {dur[i] / max(1, rounds[i]):.1f} per round, {dur[i] / max(1, iters[i]):.1f} per iteration")
     for lo, hi in ((0, 25), (25, 50), (50, 75), (75, 100)):
         sel = (dur >= np.percentile(dur, lo)) & (dur <= np.percentile(dur, hi))
         print(f"   duration quartile {lo}-{hi}: rounds {rounds[sel].mean():.1f} iterations {iters[sel].mean():.1f} count {count[sel].mean():.1f} per-iteration {(dur[sel] / np.maximum(1, iters[sel])).mean():.1f} kcyc"
