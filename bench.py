@@ -363,12 +363,14 @@ def timed_loop(ds, loop, steps, dist, gather, events=True):
     ds.set_count_rays(False)
     ds.set_timing(events)
     loop.step(0, gather=gather)  # one uncounted frame so the timed region starts from the steady state
+    loop.finish()
     fence(dist)
     if events:
         ds.profile_begin(steps + 2)
     t0 = time.perf_counter()
     for i in range(steps):
         loop.step(i, gather=gather)
+    loop.finish()  # (the gather runs one frame behind the render: the last frame is assembled here, inside the timed region)
     fence(dist)
     elapsed = time.perf_counter() - t0
     kernel_total_ms, launches = ds.profile_end() if events else (0.0, 0)
@@ -624,6 +626,7 @@ def run_multi(args, rank, local_rank, world_size, dist, backend):
             ds.set_timing(True)
             for i in range(max(2, args.warmup)):
                 loop[0].step(i, gather=True)
+            loop[0].finish()
             fence(dist)
             ds.sync()
             st = ds.stats()
@@ -662,8 +665,10 @@ def run_multi(args, rank, local_rank, world_size, dist, backend):
         def check_and_solo():
             # the frame assembled on rank 0 must be bit-identical to the same frame rendered by one rank ...
             loop[0].step(0, gather=True)
+            loop[0].finish()
             fence(dist)
             if rank == 0:
+                rows[(mode, "gather_bytes")] = loop[0].gather_bytes
                 # ... and the SAME workload on ONE GPU, by the same wall clock as `value` (rank 0 alone, the others wait)
                 solo = ShardedFrameLoop(ds, cam, par, row_block=8, solo=True)
                 el1, _, _ = timed_loop(ds, solo, args.steps, None, False, events=False)
@@ -685,6 +690,7 @@ def run_multi(args, rank, local_rank, world_size, dist, backend):
 
         def mode_rows(mode):
             out = dict(line(mode, True), without_gather=line(mode, False), gather_check=rows.get((mode, "check")),
+                       gather_bytes_per_frame_sent=rows.get((mode, "gather_bytes")),
                        rays_per_frame=rays_frame[mode],
                        traced_ray_fraction=1.0 - resolved_frame[mode] / max(1, rays_frame[mode]))
             if (mode, "dome_off") in rows:
@@ -713,10 +719,14 @@ def run_multi(args, rank, local_rank, world_size, dist, backend):
             "config": {"workload": "C4 path tracer 3840x2160, 256 spheres, N=1, D=5, rr=3, S=8 (64 spp), fp32 RGB assembled on rank 0",
                        "width": W, "height": H, "n_shapes": flat.n_shapes, "renderer": "PathTracer",
                        "pcg_mode": "PT_PCG_SAMPLE (one generator per sample = per lane of the second pass: 'PCG random state per-thread' of the north star; headline since round 2 -- round 1's headline was the PT_PCG_PIXEL frame, now the row pcg_pixel)",
-                       "partition": f"interleaved 8-row blocks over {world_size} ranks; one batched RCCL send/recv group per frame: ONE "
-                                    "transfer per remote rank into a staging buffer on rank 0 + a strided placement copy per rank, "
-                                    "double-buffered behind the next frame's render"},
-            "gather": plan,
+                       "partition": f"interleaved 8-row blocks over {world_size} ranks; a frame's shards reach rank 0 in batched RCCL send/recv groups "
+                                    "(sparse: a fixed-size part and the runs that are not one colour; whole: ONE transfer per remote rank), "
+                                    "then a strided placement copy per rank; the gather of a frame runs behind the next frame's render"},
+            "gather": dict(plan, sparse=ptdist.sparse_default(),
+                           note="gather_bytes_per_frame is what the shards weigh whole; with `sparse` (pytracer_amd/dist.py: runs of "
+                                "128 pixels that are one colour to the bit travel as one pixel, lossless) what the remote ranks "
+                                "really sent for a frame is gather_bytes_per_frame_sent; two messages per remote rank then, the "
+                                "second one sized by a count the first one carries; PT_GATHER_SPARSE=0 sends the shards whole"),
             "value_note": "`value` counts every primary ray of the frame, including those of sky tiles that are resolved without "
                           "being generated (exact: DESIGN.md 4 items 6/8); traced_Mray_s counts only rays that went through a "
                           "world query, dome_off is the same loop with the shortcut switched off",

@@ -218,6 +218,28 @@ int pt_image_average_luminosity(int device, const void *img_dev, int fmt, int wi
  * (int(255 * pow(x, 1/gamma)); :160-166) into rgb8_dev (W*H*3 bytes, row 0 on top; may be NULL). */
 int pt_image_tonemap(int device, void *img_dev, int fmt, int width, int height, double scale, int clamp,
                      double gamma, unsigned char *rgb8_dev, int write_back, void *stream);
+/* ---- a rank's shard in sparse form, for the gather of a sharded frame (the reference has no multi-GPU
+ * path: this serves pytracer_amd/dist.py's gather, which replaces nothing in the reference) ----
+ * A shard of n_pixels RGB pixels of `fmt` is cut into runs of 128 consecutive pixels; a run whose pixels all equal its
+ * first one bit for bit is kept as that one pixel, the others whole and in order.  Lossless.
+ *   fixed   (pt_image_sparse_fixed_bytes bytes): int64 count of runs that are not constant | int32 per run: its place
+ *            among those, -1 = constant (padded to a multiple of 8 bytes) | the first pixel of every run
+ *   payload ([count][128][3] values of fmt; capacity: every run): the runs that are not constant, the shard's last run
+ *            filled up with its last pixel.
+ * All pointers are device pointers; `stream` as in pt_render_device.  The count is read from fixed[0..8) by the caller. */
+long long pt_image_sparse_fixed_bytes(long long n_pixels, int fmt);
+int pt_image_sparse_encode(int device, const void *shard_dev, long long n_pixels, int fmt, void *fixed_dev,
+                           void *payload_dev, void *stream);
+/* ... and back, in one pass.  n_ranks <= 1: out_dev receives the shard's n_pixels pixels.  n_ranks > 1: out_dev is the
+ * FRAME (rows of `width` pixels) the shard of rank `rank` belongs to under pt_params' row_block / n_ranks partition, and the
+ * shard's rows are written where pt_rows_for_rank puts them.  payload_dev may be NULL when the count is 0. */
+int pt_image_sparse_decode(int device, const void *fixed_dev, const void *payload_dev, long long n_pixels, int fmt,
+                           void *out_dev, int width, int row_block, int n_ranks, int rank, void *stream);
+/* ... the shards of up to 64 ranks into one frame, in ONE launch: fixed_dev[k] / payload_dev[k] / n_pixels[k] / ranks[k]
+ * (host arrays of device pointers, pixel counts and ranks) as the single call takes them. */
+int pt_image_sparse_decode_many(int device, int n_shards, const void *const *fixed_dev, const void *const *payload_dev,
+                                const long long *n_pixels, const int *ranks, int fmt, void *frame_dev, int width,
+                                int row_block, int n_ranks, void *stream);
 /* Copy the last error message of the calling thread (NUL-terminated) into buf; returns its length. */
 int pt_last_error(char *buf, size_t n);
 /* Library/ABI version: (major<<16)|minor. */

@@ -14,7 +14,8 @@ _lib = None
 EXPORTS = ("pt_device_count", "pt_scene_upload", "pt_scene_free", "pt_rows_for_rank", "pt_output_bytes",
            "pt_render", "pt_render_device", "pt_get_stats", "pt_set_count_rays", "pt_sync", "pt_last_error",
            "pt_version", "pt_profile_begin", "pt_profile_end", "pt_set_timing", "pt_image_pack_pfm",
-           "pt_image_average_luminosity", "pt_image_tonemap", "pt_host_alloc", "pt_host_free", "pt_set_dome_shortcut", "pt_device_info")
+           "pt_image_average_luminosity", "pt_image_tonemap", "pt_host_alloc", "pt_host_free", "pt_set_dome_shortcut", "pt_device_info",
+           "pt_image_sparse_fixed_bytes", "pt_image_sparse_encode", "pt_image_sparse_decode", "pt_image_sparse_decode_many")
 
 
 # every symbol include/ptrace_debug.h declares for ordinary builds (diagnostics: not part of the boundary)
@@ -108,6 +109,15 @@ def lib():
         L.pt_image_average_luminosity.restype = C.c_int
         L.pt_image_average_luminosity.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double,
                                                   P(C.c_double), C.c_void_p]
+        L.pt_image_sparse_fixed_bytes.restype = C.c_longlong
+        L.pt_image_sparse_fixed_bytes.argtypes = [C.c_longlong, C.c_int]
+        L.pt_image_sparse_encode.restype = C.c_int
+        L.pt_image_sparse_encode.argtypes = [C.c_int, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.pt_image_sparse_decode.restype = C.c_int
+        L.pt_image_sparse_decode.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.pt_image_sparse_decode_many.restype = C.c_int
+        L.pt_image_sparse_decode_many.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                                  C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.pt_image_tonemap.restype = C.c_int
         L.pt_image_tonemap.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double,
                                        C.c_void_p, C.c_int, C.c_void_p]

@@ -1635,6 +1635,102 @@ extern "C" int pt_image_pack_pfm(int device, const void *img, int fmt, int width
   return PT_OK;
 }
 
+// ---- sparse shards for the multi-GPU gather (pt_post.h) ----
+extern "C" long long pt_image_sparse_fixed_bytes(long long n_pixels, int fmt) {
+  if (n_pixels <= 0 || (fmt != PT_OUT_F64 && fmt != PT_OUT_F32)) return -1;
+  const long long nt = (n_pixels + PT_SPARSE_RUN - 1) / PT_SPARSE_RUN;
+  return 8 + (nt + 1) / 2 * 8 + nt * 3 * (fmt == PT_OUT_F32 ? 4 : 8);
+}
+
+static int sparse_check(int device, const void *a, const void *b, long long n_pixels, int fmt) {
+  if (!a || !b) return fail(PT_ERR_INVALID, "null buffer");
+  if (n_pixels <= 0 || n_pixels > (1LL << 37)) return fail(PT_ERR_INVALID, "bad pixel count %lld", n_pixels);
+  if (fmt != PT_OUT_F64 && fmt != PT_OUT_F32) return fail(PT_ERR_INVALID, "unknown pixel format %d", fmt);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(PT_ERR_NODEVICE, "no HIP device visible");
+  if (device < 0 || device >= ndev) return fail(PT_ERR_INVALID, "device %d out of range", device);
+  HIP_TRY(hipSetDevice(device));
+  return PT_OK;
+}
+
+extern "C" int pt_image_sparse_encode(int device, const void *shard_dev, long long n_pixels, int fmt, void *fixed_dev,
+                                      void *payload_dev, void *stream) {
+  int rc = sparse_check(device, shard_dev, fixed_dev, n_pixels, fmt);
+  if (rc) return rc;
+  if (!payload_dev) return fail(PT_ERR_INVALID, "null buffer");
+  hipStream_t st = (hipStream_t)stream;
+  const long long nt = (n_pixels + PT_SPARSE_RUN - 1) / PT_SPARSE_RUN, ntp = (nt + 1) / 2 * 2;
+  int *place = (int *)((unsigned char *)fixed_dev + 8);
+  void *firsts = (unsigned char *)fixed_dev + 8 + ntp * 4;
+  const unsigned grid = (unsigned)((nt + 3) / 4);
+  if (fmt == PT_OUT_F32)
+    hipLaunchKernelGGL(pt_sparse_classify_kernel<uint32_t>, dim3(grid), dim3(256), 0, st, (const uint32_t *)shard_dev, n_pixels, nt, place, (uint32_t *)firsts);
+  else
+    hipLaunchKernelGGL(pt_sparse_classify_kernel<uint64_t>, dim3(grid), dim3(256), 0, st, (const uint64_t *)shard_dev, n_pixels, nt, place, (uint64_t *)firsts);
+  hipLaunchKernelGGL(pt_sparse_scan_kernel, dim3(1), dim3(1024), 0, st, place, nt, ntp, (long long *)fixed_dev);
+  if (fmt == PT_OUT_F32)
+    hipLaunchKernelGGL(pt_sparse_pack_kernel<uint32_t>, dim3(grid), dim3(256), 0, st, (const uint32_t *)shard_dev, n_pixels, nt, (const int *)place, (uint32_t *)payload_dev);
+  else
+    hipLaunchKernelGGL(pt_sparse_pack_kernel<uint64_t>, dim3(grid), dim3(256), 0, st, (const uint64_t *)shard_dev, n_pixels, nt, (const int *)place, (uint64_t *)payload_dev);
+  HIP_TRY(hipGetLastError());
+  if (!stream) HIP_TRY(hipStreamSynchronize(st));
+  return PT_OK;
+}
+
+extern "C" int pt_image_sparse_decode(int device, const void *fixed_dev, const void *payload_dev, long long n_pixels, int fmt,
+                                      void *out_dev, int width, int row_block, int n_ranks, int rank, void *stream) {
+  int rc = sparse_check(device, fixed_dev, out_dev, n_pixels, fmt);
+  if (rc) return rc;
+  if (n_ranks > 1 && (width <= 0 || row_block <= 0 || rank < 0 || rank >= n_ranks || n_pixels % width != 0 || n_pixels >= (1LL << 31)))
+    return fail(PT_ERR_INVALID, "bad placement: width %d, row_block %d, rank %d of %d", width, row_block, rank, n_ranks);
+  hipStream_t st = (hipStream_t)stream;
+  const long long nt = (n_pixels + PT_SPARSE_RUN - 1) / PT_SPARSE_RUN, ntp = (nt + 1) / 2 * 2;
+  const int *place = (const int *)((const unsigned char *)fixed_dev + 8);
+  const void *firsts = (const unsigned char *)fixed_dev + 8 + ntp * 4;
+  const unsigned grid = (unsigned)((nt + 3) / 4);
+  // (payload_dev may be null when no run needs it: then no run reads it)
+  if (fmt == PT_OUT_F32)
+    hipLaunchKernelGGL(pt_sparse_unpack_kernel<uint32_t>, dim3(grid), dim3(256), 0, st, place, (const uint32_t *)firsts, (const uint32_t *)payload_dev,
+                       n_pixels, nt, (uint32_t *)out_dev, width, row_block, n_ranks, rank);
+  else
+    hipLaunchKernelGGL(pt_sparse_unpack_kernel<uint64_t>, dim3(grid), dim3(256), 0, st, place, (const uint64_t *)firsts, (const uint64_t *)payload_dev,
+                       n_pixels, nt, (uint64_t *)out_dev, width, row_block, n_ranks, rank);
+  HIP_TRY(hipGetLastError());
+  if (!stream) HIP_TRY(hipStreamSynchronize(st));
+  return PT_OK;
+}
+
+extern "C" int pt_image_sparse_decode_many(int device, int n_shards, const void *const *fixed_dev, const void *const *payload_dev,
+                                           const long long *n_pixels, const int *ranks, int fmt, void *frame_dev, int width,
+                                           int row_block, int n_ranks, void *stream) {
+  if (n_shards <= 0 || n_shards > PT_SPARSE_MANY || !fixed_dev || !payload_dev || !n_pixels || !ranks)
+    return fail(PT_ERR_INVALID, "bad shard list (%d shards, at most %d)", n_shards, PT_SPARSE_MANY);
+  if (n_ranks <= 1 || width <= 0 || row_block <= 0) return fail(PT_ERR_INVALID, "bad placement: width %d, row_block %d, %d ranks", width, row_block, n_ranks);
+  PtSparseMany m;
+  memset(&m, 0, sizeof m);
+  long long most = 0;
+  for (int k = 0; k < n_shards; ++k) {
+    int rc = sparse_check(device, fixed_dev[k], frame_dev, n_pixels[k], fmt);
+    if (rc) return rc;
+    if (ranks[k] < 0 || ranks[k] >= n_ranks || n_pixels[k] % width != 0 || n_pixels[k] >= (1LL << 31))
+      return fail(PT_ERR_INVALID, "bad shard %d: rank %d of %d, %lld pixels", k, ranks[k], n_ranks, n_pixels[k]);
+    m.fixed[k] = fixed_dev[k];
+    m.payload[k] = payload_dev[k];
+    m.npix[k] = n_pixels[k];
+    m.rank[k] = ranks[k];
+    most = std::max(most, n_pixels[k]);
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned gx = (unsigned)(((most + PT_SPARSE_RUN - 1) / PT_SPARSE_RUN + 3) / 4);
+  if (fmt == PT_OUT_F32)
+    hipLaunchKernelGGL(pt_sparse_unpack_many_kernel<uint32_t>, dim3(gx, n_shards), dim3(256), 0, st, m, (uint32_t *)frame_dev, width, row_block, n_ranks);
+  else
+    hipLaunchKernelGGL(pt_sparse_unpack_many_kernel<uint64_t>, dim3(gx, n_shards), dim3(256), 0, st, m, (uint64_t *)frame_dev, width, row_block, n_ranks);
+  HIP_TRY(hipGetLastError());
+  if (!stream) HIP_TRY(hipStreamSynchronize(st));
+  return PT_OK;
+}
+
 extern "C" int pt_image_average_luminosity(int device, const void *img, int fmt, int width, int height,
                                            double delta, double *out, void *stream) {
   int rc = post_check(device, img, fmt, width, height);

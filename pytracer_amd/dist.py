@@ -15,6 +15,14 @@ tail block).  The render granularity (8-row blocks, for load balance) and the ga
 share) are thereby independent: ``world - 1`` transfers per frame, all in one batched point-to-point group
 (``batch_isend_irecv``: a single ncclGroupStart/End on RCCL), and ``gather_plan()`` reports their number and bytes.
 
+Most of a frame is usually the same colour to the bit -- the sky: 99 % of the pixels of BASELINE's 4K configuration --
+and at 12 bytes per pixel the full shards of a 4K frame (87 MB into rank 0 at 8 ranks, 50 MB over ONE link at 2) take
+longer to move than to render.  So a shard travels SPARSE by default (``encode_sparse`` / ``decode_sparse``; lossless):
+cut into runs of ``SPARSE_TILE`` consecutive pixels, a run whose pixels are all bitwise equal to its first is sent as
+that one pixel, the others whole.  Two messages per remote rank: a fixed-size part (count, one flag and one pixel per
+run), then the runs that are not constant -- the receiver learns their number from the first.  ``PT_GATHER_SPARSE=0``
+(or ``sparse=False``) sends the shards whole in one message, as in round 2.
+
 Which transport a process group uses is decided ONCE and COLLECTIVELY (``choose_transport``): every rank, also one
 that owns no rows, runs the same probe and the verdicts are all-reduced, so no rank can end up in a different
 collective from the others; an error inside a frame's gather is raised, never retried on another transport.
@@ -126,6 +134,129 @@ def place_shard(out: torch.Tensor, shard: torch.Tensor, height: int, row_block: 
         out[g0:g0 + n].copy_(shard[ng * rb: ng * rb + n], non_blocking=True)
 
 
+SPARSE_TILE = 128  # pixels per run (csrc/pt_post.h: PT_SPARSE_RUN)
+last_gather = {}   # on dst, after a gather: {"bytes": what the remote ranks sent for that frame, "sparse": bool}
+_sparse_scratch = {}  # (device, dtype, runs) -> payload buffer at full capacity: reused frame after frame
+
+
+def sparse_default() -> bool:
+    import os
+
+    return os.environ.get("PT_GATHER_SPARSE", "1") != "0"
+
+
+def _fmt_of(dtype: torch.dtype) -> int:
+    return abi.OUT_F32 if dtype == torch.float32 else abi.OUT_F64
+
+
+def _int_view(t: torch.Tensor) -> torch.Tensor:
+    return t.view(torch.int32 if t.element_size() == 4 else torch.int64)
+
+
+def sparse_fixed_bytes(n_pixels: int, itemsize: int, tile: int = SPARSE_TILE) -> int:
+    nt = (n_pixels + tile - 1) // tile
+    return 8 + (nt + 1) // 2 * 8 + nt * 3 * itemsize
+
+
+def encode_sparse(shard: torch.Tensor, tile: int = SPARSE_TILE) -> Tuple[torch.Tensor, torch.Tensor]:
+    """``[rows, W, 3]`` (contiguous) -> ``(fixed, payload)``: ``fixed`` is a uint8 tensor of ``sparse_fixed_bytes`` bytes
+    -- the number n of runs that are not constant (int64), for every run its place among those or -1 if it is constant
+    (int32, padded to a multiple of 8 bytes), the first pixel of every run -- and ``payload`` the ``[n, tile, 3]`` runs
+    that are not constant, in order.  Equality is BITWISE (-0.0 and 0.0 differ, a NaN equals itself).  Reads n back
+    to the host (one synchronisation of the current stream).  On a HIP device: three small kernels
+    (``pt_image_sparse_encode``, csrc/pt_post.h); elsewhere the torch restatement below -- same bytes."""
+    flat = shard.reshape(-1, 3)
+    npx = flat.shape[0]
+    nt = (npx + tile - 1) // tile
+    if shard.is_cuda and tile == SPARSE_TILE:
+        from . import _lib
+
+        dev = shard.device
+        fixed = torch.empty((sparse_fixed_bytes(npx, shard.element_size()),), dtype=torch.uint8, device=dev)
+        key = (dev, shard.dtype, nt)
+        if key not in _sparse_scratch:
+            _sparse_scratch[key] = torch.empty((nt, tile, 3), dtype=shard.dtype, device=dev)
+        payload = _sparse_scratch[key]
+        _lib.check(_lib.lib().pt_image_sparse_encode(dev.index or 0, shard.contiguous().data_ptr(), npx, _fmt_of(shard.dtype),
+                                                     fixed.data_ptr(), payload.data_ptr(),
+                                                     torch.cuda.current_stream(dev).cuda_stream))
+        return fixed, payload[: sparse_count(fixed)]
+    if nt * tile != npx:  # the last run is filled up with its own last pixel: that does not make it less constant
+        flat = torch.cat([flat, flat[-1:].expand(nt * tile - npx, 3)])
+    tiles = flat.contiguous().view(nt, tile, 3)
+    bits = _int_view(tiles)
+    const = (bits == bits[:, :1, :]).all(dim=2).all(dim=1)
+    idx = (~const).nonzero().squeeze(1)
+    payload = tiles.index_select(0, idx)
+    count = torch.tensor([idx.numel()], dtype=torch.int64, device=shard.device)
+    place = torch.full(((nt + 1) // 2 * 2,), -1, dtype=torch.int32, device=shard.device)
+    place[idx] = torch.arange(idx.numel(), dtype=torch.int32, device=shard.device)
+    fixed = torch.cat([count.view(torch.uint8), place.view(torch.uint8), tiles[:, 0, :].contiguous().view(torch.uint8).reshape(-1)])
+    return fixed, payload
+
+
+def sparse_count(fixed: torch.Tensor) -> int:
+    return int(fixed[:8].clone().view(torch.int64).item())
+
+
+def decode_sparse(fixed: torch.Tensor, payload: Optional[torch.Tensor], n_pixels: int, dtype: torch.dtype,
+                  tile: int = SPARSE_TILE, frame: Optional[torch.Tensor] = None, row_block: int = 0, world: int = 1,
+                  rank: int = 0) -> torch.Tensor:
+    """The inverse of ``encode_sparse``.  Without ``frame``: -> the shard, ``[n_pixels, 3]``.  With ``frame``
+    (``[H, W, 3]``): the shard's rows are written where the partition (``row_block``, ``world``, ``rank``) puts them, in
+    the same pass on a HIP device; -> ``frame``."""
+    nt = (n_pixels + tile - 1) // tile
+    pl_bytes = (nt + 1) // 2 * 8
+    if fixed.is_cuda and tile == SPARSE_TILE:
+        from . import _lib
+
+        dev = fixed.device
+        n = 0 if payload is None else payload.shape[0]
+        out = frame if frame is not None else torch.empty((n_pixels, 3), dtype=dtype, device=dev)
+        W = frame.shape[1] if frame is not None else 0
+        _lib.check(_lib.lib().pt_image_sparse_decode(dev.index or 0, fixed.data_ptr(), payload.data_ptr() if n else None, n_pixels,
+                                                     _fmt_of(dtype), out.data_ptr(), W, int(row_block), world if frame is not None else 1,
+                                                     rank, torch.cuda.current_stream(dev).cuda_stream))
+        return out
+    place = fixed[8:8 + 4 * nt].view(torch.int32)
+    firsts = fixed[8 + pl_bytes:].view(dtype).view(nt, 1, 3)
+    tiles = firsts.expand(nt, tile, 3).contiguous()
+    idx = (place >= 0).nonzero().squeeze(1)
+    n = 0 if payload is None else payload.shape[0]
+    if idx.numel() != n:
+        raise RuntimeError(f"sparse shard: {n} runs received, {idx.numel()} flagged")
+    if n:
+        tiles.index_copy_(0, idx, payload.index_select(0, place[idx].to(torch.int64)))
+    shard = tiles.view(nt * tile, 3)[:n_pixels]
+    if frame is None:
+        return shard
+    W = frame.shape[1]
+    place_shard(frame, shard.view(n_pixels // W, W, 3), frame.shape[0], row_block, world, rank)
+    return frame
+
+
+def decode_sparse_many(fixed: List[torch.Tensor], payload: List[torch.Tensor], ranks: List[int], frame: torch.Tensor,
+                       row_block: int, world: int) -> None:
+    """The shards of ``ranks`` (as ``encode_sparse`` made them) straight into their rows of ``frame``: on a HIP device ONE
+    launch for all of them (``pt_image_sparse_decode_many``), elsewhere one ``decode_sparse`` each."""
+    W = frame.shape[1]
+    npx = [len(shard_rows(frame.shape[0], row_block, world, r)) * W for r in ranks]
+    if frame.is_cuda and len(ranks) <= 64:
+        import ctypes as C
+
+        from . import _lib
+
+        k = len(ranks)
+        fx = (C.c_void_p * k)(*[f.data_ptr() for f in fixed])
+        py = (C.c_void_p * k)(*[p.data_ptr() if p is not None and p.shape[0] else None for p in payload])
+        _lib.check(_lib.lib().pt_image_sparse_decode_many(frame.device.index or 0, k, fx, py, (C.c_longlong * k)(*npx), (C.c_int * k)(*ranks),
+                                                          _fmt_of(frame.dtype), frame.data_ptr(), W, int(row_block), world,
+                                                          torch.cuda.current_stream(frame.device).cuda_stream))
+        return
+    for f, p, r, n in zip(fixed, payload, ranks, npx):
+        decode_sparse(f, p, n, frame.dtype, frame=frame, row_block=row_block, world=world, rank=r)
+
+
 def _gather_padded(local, height, row_block, world, rank, group, dst, out):
     """The collective for a backend without batched point-to-point: one ``gather`` of shards padded to a common size."""
     pad = max_shard_rows(height, row_block, world)
@@ -141,8 +272,47 @@ def _gather_padded(local, height, row_block, world, rank, group, dst, out):
         dist.gather(shard, None, dst=dst, group=group)
 
 
+def _gather_sparse(local, height, row_block, world, rank, group, dst, out, nrows):
+    """Point-to-point gather of sparse shards: the fixed parts first (sizes known from the partition), then -- once
+    ``dst`` has read the counts -- the runs that are not constant."""
+    W = local.shape[1]
+    esize = local.element_size()
+
+    def peer_of(r):
+        return dist.get_global_rank(group, r) if group is not None else r
+
+    if rank == dst:
+        remote = [r for r in range(world) if r != dst and nrows[r] > 0]
+        fixed = {r: torch.empty((sparse_fixed_bytes(nrows[r] * W, esize),), dtype=torch.uint8, device=local.device) for r in remote}
+        if remote:
+            for req in dist.batch_isend_irecv([dist.P2POp(dist.irecv, fixed[r], peer_of(r), group) for r in remote]):
+                req.wait()
+        counts = {}
+        if remote:
+            heads = torch.stack([fixed[r][:8] for r in remote]).view(torch.int64).reshape(-1).cpu()  # (one synchronisation)
+            counts = {r: int(heads[k]) for k, r in enumerate(remote)}
+        payload = {r: torch.empty((counts[r], SPARSE_TILE, 3), dtype=local.dtype, device=local.device) for r in remote}
+        ops = [dist.P2POp(dist.irecv, payload[r], peer_of(r), group) for r in remote if counts[r] > 0]
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        if nrows[dst] > 0:
+            place_shard(out, local, height, row_block, world, dst)
+        if remote:
+            decode_sparse_many([fixed[r] for r in remote], [payload[r] for r in remote], remote, out, row_block, world)
+        last_gather.update(bytes=sum(fixed[r].numel() + payload[r].numel() * esize for r in remote), sparse=True)
+    elif nrows[rank] > 0:
+        fixed, payload = encode_sparse(local[: nrows[rank]].contiguous())
+        for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, fixed, peer_of(dst), group)]):
+            req.wait()
+        if payload.shape[0] > 0:
+            for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, payload, peer_of(dst), group)]):
+                req.wait()
+
+
 def gather_image(local: torch.Tensor, height: int, row_block: int, group=None, dst: int = 0,
-                 out: Optional[torch.Tensor] = None, staging: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+                 out: Optional[torch.Tensor] = None, staging: Optional[torch.Tensor] = None,
+                 sparse: Optional[bool] = None) -> Optional[torch.Tensor]:
     """Assemble the frame on ``dst`` from the ranks' compact row shards.
 
     ``local`` is this rank's ``[>= rows_of_this_rank, W, 3]`` shard (rows beyond its own are ignored).
@@ -164,8 +334,12 @@ def gather_image(local: torch.Tensor, height: int, row_block: int, group=None, d
     if rank == dst and out is None:
         out = torch.empty((height,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     nrows = [len(shard_rows(height, row_block, world, r)) for r in range(world)]
+    if sparse is None:
+        sparse = sparse_default()  # (the same on every rank: an argument or the environment of the job)
     if transport == PADDED:
         _gather_padded(local, height, row_block, world, rank, group, dst, out)
+    elif sparse:
+        _gather_sparse(local, height, row_block, world, rank, group, dst, out, nrows)
     elif rank == dst:
         if staging is None:
             staging = torch.empty((world, max(nrows)) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
@@ -180,6 +354,7 @@ def gather_image(local: torch.Tensor, height: int, row_block: int, group=None, d
         for r in range(world):
             if nrows[r] > 0:
                 place_shard(out, local if r == dst else staging[r], height, row_block, world, r)
+        last_gather.update(bytes=sum(nrows[r] for r in range(world) if r != dst) * local[0].numel() * local.element_size(), sparse=False)
     elif nrows[rank] > 0:
         peer = dist.get_global_rank(group, dst) if group is not None else dst
         for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, local[: nrows[rank]], peer, group)]):
@@ -208,11 +383,13 @@ def render_sharded(render_local: Callable[[abi.Params], torch.Tensor], params: a
 class ShardedFrameLoop:
     """Frame loop for one GPU rank: render into HBM, gather over RCCL on a side stream.
 
-    Double-buffered: the gather of frame ``i`` (comm stream) overlaps the render of frame ``i+1``
-    (compute stream).  ``finish()`` drains both streams."""
+    Double-buffered and one frame behind: ``step(i)`` enqueues the render of frame ``i`` (compute stream) and THEN
+    runs the gather of frame ``i - 1`` (comm stream) -- the sparse gather reads a count back to the host, and the host
+    should wait for that while the GPU renders the next frame, not before it has been given it.  ``finish()`` gathers
+    the last frame and drains both streams."""
 
     def __init__(self, scene, cam: abi.Camera, params: abi.Params, group=None, row_block: int = 8,
-                 device: Optional[torch.device] = None, solo: bool = False):
+                 device: Optional[torch.device] = None, solo: bool = False, sparse: Optional[bool] = None):
         """``solo``: this process renders the WHOLE frame by itself, whatever process group exists (the one-GPU
         reference loop of the sharded bench)."""
         self.scene, self.cam = scene, cam
@@ -242,11 +419,19 @@ class ShardedFrameLoop:
         if self.world > 1:
             choose_transport(group)  # collective, before the first frame
         self._free = [None, None]  # event: the gather that last read buffer b is done
+        self._rendered = [None, None]
+        self._pending = None       # buffer whose frame is rendered (or being rendered) and not gathered yet
+        self.sparse = sparse_default() if sparse is None else bool(sparse)
+        self.gather_bytes = None   # rank 0: what the remote ranks sent for the last gathered frame
         self.last = 0
 
     def step(self, i: int, gather: bool = True) -> None:
-        """Render frame ``i`` into this rank's buffer; with ``gather`` also assemble it on rank 0."""
+        """Enqueue the render of frame ``i`` into this rank's buffer; with ``gather`` also assemble a frame on rank 0 --
+        the one before this (frame ``i`` itself is assembled by the next ``step`` or by ``finish``)."""
         b = i & 1
+        if self._pending is not None and not gather:  # (a frame still waiting to be assembled must not be overwritten)
+            prev, self._pending = self._pending, None
+            self._gather(prev)
         if self._free[b] is not None:
             self.stream.wait_event(self._free[b])
         self.scene.render_into(self.cam, self.params, self.bufs[b].data_ptr(), self.nbytes,
@@ -255,16 +440,27 @@ class ShardedFrameLoop:
         if self.world > 1 and gather:
             rendered = torch.cuda.Event()
             rendered.record(self.stream)
-            with torch.cuda.stream(self.comm):
-                self.comm.wait_event(rendered)
-                gather_image(self.bufs[b], self.height, self.row_block, group=self.group, dst=0,
-                             out=self.full[b] if self.rank == 0 else None,
-                             staging=self.staging if self.rank == 0 else None)
-                done = torch.cuda.Event()
-                done.record(self.comm)
-                self._free[b] = done
+            self._rendered[b] = rendered
+            prev, self._pending = self._pending, b
+            if prev is not None:
+                self._gather(prev)
+
+    def _gather(self, b: int) -> None:
+        with torch.cuda.stream(self.comm):
+            self.comm.wait_event(self._rendered[b])
+            gather_image(self.bufs[b], self.height, self.row_block, group=self.group, dst=0,
+                         out=self.full[b] if self.rank == 0 else None,
+                         staging=self.staging if self.rank == 0 else None, sparse=self.sparse)
+            if self.rank == 0:
+                self.gather_bytes = last_gather.get("bytes")
+            done = torch.cuda.Event()
+            done.record(self.comm)
+            self._free[b] = done
 
     def finish(self) -> None:
+        if self._pending is not None:
+            b, self._pending = self._pending, None
+            self._gather(b)
         torch.cuda.synchronize()
 
     def image(self) -> Optional[torch.Tensor]:

@@ -73,7 +73,7 @@ def test_sharded_render_matches_single_process(world, renderer, S, height, row_b
     assert ret["shape"] == (height, 48, 3)
 
 
-def _gather_worker(rank, world, port, transport, H, ret):
+def _gather_worker(rank, world, port, transport, H, ret, sparse=None, W=5, kind="ramp"):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -83,18 +83,30 @@ def _gather_worker(rank, world, port, transport, H, ret):
 
         if transport is not None:
             ptdist.choose_transport(force=transport)  # (else: the collective probe inside the first gather decides)
-        W = 5
-        full = torch.arange(H * W * 3, dtype=torch.float64).reshape(H, W, 3)
+        if kind == "ramp":  # no two pixels alike
+            full = torch.arange(H * W * 3, dtype=torch.float64).reshape(H, W, 3)
+        else:  # a sky of one colour (with -0.0 in it) and a few patches of "geometry", fp32 as the frames are
+            g = torch.Generator().manual_seed(5)
+            full = torch.empty((H, W, 3), dtype=torch.float32)
+            full[...] = torch.tensor([0.25, -0.0, 0.75])
+            if kind == "patches":
+                for _ in range(6):
+                    r0, c0 = int(torch.randint(0, H, (1,), generator=g)), int(torch.randint(0, W, (1,), generator=g))
+                    full[r0:r0 + 3, c0:c0 + 40] = torch.rand((min(3, H - r0), min(40, W - c0), 3), generator=g)
+                full[H // 2, W // 2, 1] = 0.0  # differs from the sky's -0.0 in the sign bit only
         rows = ptdist.shard_rows(H, 8, world, rank)
-        shard = full[rows].contiguous() if rows else torch.zeros((1, W, 3), dtype=torch.float64)
-        out = ptdist.gather_image(shard, H, 8)
+        shard = full[rows].contiguous() if rows else torch.zeros((1, W, 3), dtype=full.dtype)
+        out = ptdist.gather_image(shard, H, 8, sparse=sparse)
         if rank == 0:
-            ret["ok"] = bool(torch.equal(out, full))
+            bits = torch.int64 if full.dtype == torch.float64 else torch.int32
+            ret["ok"] = bool(torch.equal(out.view(bits), full.view(bits)))
             ret["transport"] = ptdist.choose_transport()
+            ret["bytes"] = int(ptdist.last_gather.get("bytes", -1))
+            ret["sparse"] = bool(ptdist.last_gather.get("sparse", False))
         else:
             assert out is None
         # a second frame through the same (now settled) transport
-        out = ptdist.gather_image(shard + 1.0, H, 8)
+        out = ptdist.gather_image(shard + 1.0, H, 8, sparse=sparse)
         if rank == 0:
             ret["ok2"] = bool(torch.equal(out, full + 1.0))
         dist.barrier()
@@ -118,6 +130,69 @@ def test_gather_one_transfer_per_rank_and_the_padded_transport(world, transport,
     mp.spawn(_gather_worker, args=(world, port, transport, H, ret), nprocs=world, join=True)
     assert ret["ok"] is True and ret["ok2"] is True
     assert ret["transport"] == (transport or "p2p")
+
+
+@pytest.mark.parametrize("world,H,W,kind,sparse", [
+    (2, 27, 5, "ramp", False),        # shards whole, one message per rank (round 2's gather)
+    (3, 50, 300, "patches", True),    # a sky and patches: runs of 128 pixels, most of them constant
+    (3, 50, 300, "patches", False),
+    (2, 64, 257, "sky", True),        # nothing but sky: no second message at all
+    (3, 10, 300, "patches", True),    # rank 2 owns no rows
+    (2, 27, 5, "ramp", True),         # no run is constant: everything travels, plus the fixed part
+])
+def test_sparse_gather_is_lossless_and_smaller(world, H, W, kind, sparse):
+    """dist.encode_sparse / decode_sparse behind gather_image: runs of 128 pixels that are one colour to the bit (-0.0 is
+    not 0.0) travel as one pixel, the frame on rank 0 is the frame bit for bit, and what crossed the wire is counted."""
+    from pytracer_amd import dist as ptdist
+
+    port = _free_port()
+    ret = mp.Manager().dict()
+    mp.spawn(_gather_worker, args=(world, port, "p2p", H, ret, sparse, W, kind), nprocs=world, join=True)
+    assert ret["ok"] is True and ret["ok2"] is True
+    assert ret["sparse"] is sparse
+    esize = 8 if kind == "ramp" else 4
+    dense = sum(len(ptdist.shard_rows(H, 8, world, r)) for r in range(1, world)) * W * 3 * esize
+    if not sparse:
+        assert ret["bytes"] == dense
+    elif kind == "sky":
+        assert ret["bytes"] == sum(ptdist.sparse_fixed_bytes(len(ptdist.shard_rows(H, 8, world, r)) * W, 4) for r in range(1, world))
+        assert ret["bytes"] < dense // 20
+    elif kind == "patches":
+        assert ret["bytes"] < dense // 2
+    else:  # everything travels: the runs (the last one of a shard filled up to 128 pixels) plus the fixed part
+        worst = 0
+        for r in range(1, world):
+            npx = len(ptdist.shard_rows(H, 8, world, r)) * W
+            worst += ptdist.sparse_fixed_bytes(npx, esize) + (npx + 127) // 128 * 128 * 3 * esize
+        assert dense < ret["bytes"] == worst
+
+
+def test_sparse_codec_round_trip():
+    from pytracer_amd import dist as ptdist
+
+    g = torch.Generator().manual_seed(1)
+    for dtype, bits in ((torch.float32, torch.int32), (torch.float64, torch.int64)):
+        for rows, W in ((1, 1), (3, 129), (8, 128), (5, 37), (2, 1000)):
+            x = torch.empty((rows, W, 3), dtype=dtype)
+            x[...] = torch.tensor([0.3, 0.5, float("nan")], dtype=dtype)  # (a NaN equals itself bitwise)
+            if W > 9:
+                x[rows // 2, 5:9] = torch.rand((4, 3), generator=g, dtype=dtype)
+            fixed, payload = ptdist.encode_sparse(x)
+            assert fixed.numel() == ptdist.sparse_fixed_bytes(rows * W, x.element_size())
+            assert ptdist.sparse_count(fixed) == payload.shape[0] <= 2
+            y = ptdist.decode_sparse(fixed, payload, rows * W, dtype).view(rows, W, 3)
+            assert torch.equal(x.view(bits), y.contiguous().view(bits))
+    with pytest.raises(RuntimeError):
+        ptdist.decode_sparse(fixed, payload[:0], rows * W, dtype)
+    # straight into a frame: the rows land where the partition puts them
+    full = torch.rand((27, 40, 3), generator=g)
+    full[:, :20] = 0.5
+    got = torch.zeros_like(full)
+    for r in range(3):
+        rws = ptdist.shard_rows(27, 8, 3, r)
+        f, p = ptdist.encode_sparse(full[rws].contiguous())
+        ptdist.decode_sparse(f, p, len(rws) * 40, torch.float32, frame=got, row_block=8, world=3, rank=r)
+    assert torch.equal(got, full)
 
 
 def test_gather_plan_counts_transfers():
