@@ -576,6 +576,17 @@ class Agreement:
     def __init__(self, dist):
         self.dist = dist
         self.error = None
+        self.soft = {}
+
+    def attempt(self, phase, fn):
+        """Like run(), but a failure is remembered as `soft[phase]` only: the job goes on (used for a choice that has a
+        fallback)."""
+        saved, self.error = self.error, None
+        ok = self.run(phase, fn)
+        if not ok:
+            self.soft[phase] = self.error
+        self.error = saved
+        return ok
 
     def run(self, phase, fn):
         """Run `fn()` on this rank; -> True iff EVERY rank completed it (collective)."""
@@ -614,6 +625,43 @@ def run_multi(args, rank, local_rank, world_size, dist, backend):
             raise RuntimeError(f"{seen[0]} ranks answered, {world_size} expected")
 
     agree.run("rank count", count_ranks)
+
+    # How the shards travel: sparse (runs of one colour as one pixel; two messages per rank and a count read back) or whole
+    # (one message per rank).  Both assemble the same frame; which one is faster is a property of the node's links and of
+    # the frame, so a few frames of each are timed before the measured loops and the faster one is used -- by all ranks.
+    gather_choice = {"sparse": ptdist.sparse_default(), "probe_ms_per_frame": {}}
+
+    def probe_gathers():
+        par0 = abi.make_params(W, H, out_format=abi.OUT_F32, pcg_mode=abi.PCG_SAMPLE, **C4["kw"])
+        images = {}
+        for name, sp in (("sparse", True), ("whole", False)):
+            lp = ShardedFrameLoop(ds, cam, par0, row_block=8, sparse=sp)
+            ds.set_count_rays(False)
+            ds.set_timing(False)
+            for i in range(2):
+                lp.step(i, gather=True)
+            lp.finish()
+            fence(dist)
+            n = 6
+            t0 = time.perf_counter()
+            for i in range(n):
+                lp.step(i, gather=True)
+            lp.finish()
+            fence(dist)
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            gather_choice["probe_ms_per_frame"][name] = float(t.item()) / n * 1e3
+            images[name] = lp.image().clone() if rank == 0 else None
+        if rank == 0 and not torch.equal(images["sparse"], images["whole"]):
+            raise RuntimeError("the sparse gather assembled a different frame")
+
+    if gather_choice["sparse"] and agree.error is None:
+        if agree.attempt("gather probe", probe_gathers):
+            pr = gather_choice["probe_ms_per_frame"]
+            gather_choice["sparse"] = pr["sparse"] <= pr["whole"]
+        else:
+            gather_choice["sparse"] = False
+            gather_choice["probe_error"] = agree.soft.get("gather probe")
     for mode in (abi.PCG_SAMPLE, abi.PCG_PIXEL):
         if agree.error is not None:
             break
@@ -621,7 +669,7 @@ def run_multi(args, rank, local_rank, world_size, dist, backend):
         loop = [None]
 
         def warm():
-            loop[0] = ShardedFrameLoop(ds, cam, par, row_block=8)
+            loop[0] = ShardedFrameLoop(ds, cam, par, row_block=8, sparse=gather_choice["sparse"])
             ds.set_count_rays(True)
             ds.set_timing(True)
             for i in range(max(2, args.warmup)):
@@ -722,11 +770,14 @@ def run_multi(args, rank, local_rank, world_size, dist, backend):
                        "partition": f"interleaved 8-row blocks over {world_size} ranks; a frame's shards reach rank 0 in batched RCCL send/recv groups "
                                     "(sparse: a fixed-size part and the runs that are not one colour; whole: ONE transfer per remote rank), "
                                     "then a strided placement copy per rank; the gather of a frame runs behind the next frame's render"},
-            "gather": dict(plan, sparse=ptdist.sparse_default(),
+            "gather": dict(plan, sparse=gather_choice["sparse"], probe_ms_per_frame=gather_choice["probe_ms_per_frame"],
+                           probe_error=gather_choice.get("probe_error"),
                            note="gather_bytes_per_frame is what the shards weigh whole; with `sparse` (pytracer_amd/dist.py: runs of "
                                 "128 pixels that are one colour to the bit travel as one pixel, lossless) what the remote ranks "
                                 "really sent for a frame is gather_bytes_per_frame_sent; two messages per remote rank then, the "
-                                "second one sized by a count the first one carries; PT_GATHER_SPARSE=0 sends the shards whole"),
+                                "second one sized by a count the first one carries.  Six frames of each way are timed before the "
+                                "measured loops (probe_ms_per_frame, max over ranks) and the faster one is used; PT_GATHER_SPARSE=0 "
+                                "sends the shards whole without asking"),
             "value_note": "`value` counts every primary ray of the frame, including those of sky tiles that are resolved without "
                           "being generated (exact: DESIGN.md 4 items 6/8); traced_Mray_s counts only rays that went through a "
                           "world query, dome_off is the same loop with the shortcut switched off",
