@@ -568,6 +568,49 @@ def run_single(args, local_rank):
     print(json.dumps(result), flush=True)
 
 
+class SceneGroup:
+    """n handles of the same scene on one GPU (a frame in flight each, pytracer_amd/dist.py: ShardedFrameLoop); the
+    switches go to all of them, counters and times are summed, `stats()` is the first handle's last frame."""
+
+    def __init__(self, flat, n, device):
+        self.scenes = [DeviceScene(flat, device=device) for _ in range(max(1, n))]
+
+    def set_count_rays(self, on):
+        for d in self.scenes:
+            d.set_count_rays(on)
+
+    def set_timing(self, on):
+        for d in self.scenes:
+            d.set_timing(on)
+
+    def set_dome_shortcut(self, on):
+        for d in self.scenes:
+            d.set_dome_shortcut(on)
+
+    def sync(self):
+        for d in self.scenes:
+            d.sync()
+
+    def profile_begin(self, capacity):
+        for d in self.scenes:
+            d.profile_begin(capacity)
+
+    def profile_end(self):
+        total, launches = 0.0, 0
+        for d in self.scenes:
+            t, n = d.profile_end()
+            total += t
+            launches += n
+        return total, launches
+
+    def stats(self):
+        return self.scenes[0].stats()
+
+    def close(self):
+        for d in self.scenes:
+            d.close()
+
+
 class Agreement:
     """Ranks agree after every phase on whether all of them got through it: a rank that raised still enters this
     all-reduce, so the others learn of it here instead of waiting in the next collective until the watchdog ends
@@ -611,7 +654,11 @@ def run_multi(args, rank, local_rank, world_size, dist, backend):
     W, H = C4["W"], C4["H"]
     flat = flatten.flatten_world(scenes.synthetic_world(C4["n_spheres"], wide=C4["wide"]))
     cam = cam_for(W, H)
-    ds = DeviceScene(flat, device=local_rank)
+    # frames in flight per rank: a rank's share of the frame is short and latency-bound (0.11 ms for an eighth of C4 against
+    # 0.55 ms for the whole), and only another frame fills what it leaves idle (tools/share_in_flight.py: 0.108 -> 0.077 ms
+    # per frame with two).  The one-GPU reference loop (n1_same_workload) runs with the same number in flight.
+    n_in_flight = max(1, int(os.environ.get("PT_FRAMES_IN_FLIGHT", "2")))
+    ds = SceneGroup(flat, n_in_flight, local_rank)
     agree = Agreement(dist)
     rows = {}
     rays_frame, resolved_frame = {}, {}
@@ -635,7 +682,7 @@ def run_multi(args, rank, local_rank, world_size, dist, backend):
         par0 = abi.make_params(W, H, out_format=abi.OUT_F32, pcg_mode=abi.PCG_SAMPLE, **C4["kw"])
         images = {}
         for name, sp in (("sparse", True), ("whole", False)):
-            lp = ShardedFrameLoop(ds, cam, par0, row_block=8, sparse=sp)
+            lp = ShardedFrameLoop(ds.scenes, cam, par0, row_block=8, sparse=sp)
             ds.set_count_rays(False)
             ds.set_timing(False)
             for i in range(2):
@@ -669,7 +716,7 @@ def run_multi(args, rank, local_rank, world_size, dist, backend):
         loop = [None]
 
         def warm():
-            loop[0] = ShardedFrameLoop(ds, cam, par, row_block=8, sparse=gather_choice["sparse"])
+            loop[0] = ShardedFrameLoop(ds.scenes, cam, par, row_block=8, sparse=gather_choice["sparse"])
             ds.set_count_rays(True)
             ds.set_timing(True)
             for i in range(max(2, args.warmup)):
@@ -718,8 +765,13 @@ def run_multi(args, rank, local_rank, world_size, dist, backend):
             if rank == 0:
                 rows[(mode, "gather_bytes")] = loop[0].gather_bytes
                 # ... and the SAME workload on ONE GPU, by the same wall clock as `value` (rank 0 alone, the others wait)
-                solo = ShardedFrameLoop(ds, cam, par, row_block=8, solo=True)
+                solo = ShardedFrameLoop(ds.scenes[:1], cam, par, row_block=8, solo=True)
                 el1, _, _ = timed_loop(ds, solo, args.steps, None, False, events=False)
+                if len(ds.scenes) > 1:  # ... with as many frames in flight as the ranks have, if that is faster on one GPU
+                    many = ShardedFrameLoop(ds.scenes, cam, par, row_block=8, solo=True)
+                    el_many, _, _ = timed_loop(ds, many, args.steps, None, False, events=False)
+                    rows[(mode, "n1_in_flight")] = (el1, el_many)
+                    el1 = min(el1, el_many)
                 _, k1, n1 = timed_loop(ds, solo, max(2, args.steps // 2), None, False, events=True)
                 rows[(mode, "check")] = "ok" if torch.equal(solo.image(), loop[0].image()) else "MISMATCH"
                 rows[(mode, "n1")] = (el1, k1 / max(1, n1))
@@ -749,7 +801,12 @@ def run_multi(args, rank, local_rank, world_size, dist, backend):
                 el1, k1 = rows[(mode, "n1")]
                 n1 = {"value": rays_frame[mode] * args.steps / el1 / 1e6, "unit": "Mray/s", "ms_per_step": el1 / args.steps * 1e3,
                       "avg_render_kernels_ms": k1,
-                      "note": "the same C4 frame loop on rank 0 alone (no partition, no gather), same wall clock as `value`"}
+                      "note": "the same C4 frame loop on rank 0 alone (no partition, no gather), same wall clock as `value`; the "
+                              "faster of one frame after the other and as many frames in flight as the ranks have"}
+                if (mode, "n1_in_flight") in rows:
+                    a1, am = rows[(mode, "n1_in_flight")]
+                    n1["ms_per_step_one_after_the_other"] = a1 / args.steps * 1e3
+                    n1["ms_per_step_frames_in_flight"] = am / args.steps * 1e3
                 out["n1_same_workload"] = n1
                 out["speedup"] = out["value"] / n1["value"]
                 out["parallel_efficiency"] = out["speedup"] / world_size
@@ -767,6 +824,7 @@ def run_multi(args, rank, local_rank, world_size, dist, backend):
             "config": {"workload": "C4 path tracer 3840x2160, 256 spheres, N=1, D=5, rr=3, S=8 (64 spp), fp32 RGB assembled on rank 0",
                        "width": W, "height": H, "n_shapes": flat.n_shapes, "renderer": "PathTracer",
                        "pcg_mode": "PT_PCG_SAMPLE (one generator per sample = per lane of the second pass: 'PCG random state per-thread' of the north star; headline since round 2 -- round 1's headline was the PT_PCG_PIXEL frame, now the row pcg_pixel)",
+                       "frames_in_flight_per_rank": n_in_flight,
                        "partition": f"interleaved 8-row blocks over {world_size} ranks; a frame's shards reach rank 0 in batched RCCL send/recv groups "
                                     "(sparse: a fixed-size part and the runs that are not one colour; whole: ONE transfer per remote rank), "
                                     "then a strided placement copy per rank; the gather of a frame runs behind the next frame's render"},

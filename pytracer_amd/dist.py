@@ -383,16 +383,20 @@ def render_sharded(render_local: Callable[[abi.Params], torch.Tensor], params: a
 class ShardedFrameLoop:
     """Frame loop for one GPU rank: render into HBM, gather over RCCL on a side stream.
 
-    Double-buffered and one frame behind: ``step(i)`` enqueues the render of frame ``i`` (compute stream) and THEN
-    runs the gather of frame ``i - 1`` (comm stream) -- the sparse gather reads a count back to the host, and the host
-    should wait for that while the GPU renders the next frame, not before it has been given it.  ``finish()`` gathers
-    the last frame and drains both streams."""
+    ``scene`` is a scene handle or a list of n of them (the same scene uploaded n times): frame ``i`` is rendered by
+    handle ``i % n`` on that handle's own stream, so up to n frames are in flight on the GPU -- a rank's share of a frame
+    is short and latency-bound, and only another frame can fill what it leaves idle (``pytracer_amd/pipeline.py``).  The
+    gather runs n frames BEHIND the render: ``step(i)`` enqueues the render of frame ``i`` and then gathers frame
+    ``i - n`` on the comm stream -- the sparse gather reads a count back to the host, and the host should wait for that
+    while the GPU has work, not before it has been given it.  ``finish()`` gathers the frames still waiting and drains
+    the streams."""
 
     def __init__(self, scene, cam: abi.Camera, params: abi.Params, group=None, row_block: int = 8,
                  device: Optional[torch.device] = None, solo: bool = False, sparse: Optional[bool] = None):
         """``solo``: this process renders the WHOLE frame by itself, whatever process group exists (the one-GPU
         reference loop of the sharded bench)."""
-        self.scene, self.cam = scene, cam
+        self.scenes = list(scene) if isinstance(scene, (list, tuple)) else [scene]
+        self.scene, self.cam = self.scenes[0], cam
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() and not solo else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() and not solo else 0
@@ -402,48 +406,59 @@ class ShardedFrameLoop:
         self.rows = len(shard_rows(self.height, row_block, self.world, self.rank))
         dt = torch.float32 if params.out_format == abi.OUT_F32 else torch.float64
         self.device = device or torch.device("cuda", torch.cuda.current_device())
-        self.bufs = [torch.zeros((max(self.rows, 1), self.width, 3), dtype=dt, device=self.device) for _ in range(2)]
+        n = len(self.scenes)
+        self.lag = n if self.world > 1 else 0
+        nb = n + 2 if self.world > 1 else max(2, n)
+        self.bufs = [torch.zeros((max(self.rows, 1), self.width, 3), dtype=dt, device=self.device) for _ in range(nb)]
         self.nbytes = self.rows * self.width * 3 * self.bufs[0].element_size()
-        # a dedicated non-blocking stream: launches on the legacy default stream serialise the host with
+        # dedicated non-blocking streams: launches on the legacy default stream serialise the host with
         # the device (measured: ~51 us/launch on the null stream vs ~4 us on a side stream)
-        self.stream = torch.cuda.Stream(device=self.device)
+        self.streams = [torch.cuda.Stream(device=self.device) for _ in range(n)]
+        self.stream = self.streams[0]
         self.comm = torch.cuda.Stream() if self.world > 1 else None
         self.full = None
         self.staging = None
         if self.world > 1 and self.rank == 0:
-            self.full = [torch.empty((self.height, self.width, 3), dtype=dt, device=self.device) for _ in range(2)]
-            # the remote shards of a frame land here; the comm stream runs receive -> placement copies -> next receive
-            # in order, so one staging buffer serves both frame buffers
+            self.full = [torch.empty((self.height, self.width, 3), dtype=dt, device=self.device) for _ in range(nb)]
+            # (whole shards only) the remote shards of a frame land here; the comm stream runs receive -> placement
+            # copies -> next receive in order, so one staging buffer serves all frame buffers
             self.staging = torch.empty((self.world, max_shard_rows(self.height, row_block, self.world), self.width, 3),
                                        dtype=dt, device=self.device)
         if self.world > 1:
             choose_transport(group)  # collective, before the first frame
-        self._free = [None, None]  # event: the gather that last read buffer b is done
-        self._rendered = [None, None]
-        self._pending = None       # buffer whose frame is rendered (or being rendered) and not gathered yet
+        self._free = [None] * nb      # event: the gather that last read buffer b is done
+        self._rendered = [None] * nb
+        self._pending = []            # buffers whose frames are rendered (or being rendered) and not gathered yet, oldest first
         self.sparse = sparse_default() if sparse is None else bool(sparse)
-        self.gather_bytes = None   # rank 0: what the remote ranks sent for the last gathered frame
+        self.gather_bytes = None      # rank 0: what the remote ranks sent for the last gathered frame
         self.last = 0
+        self._count = 0
 
     def step(self, i: int, gather: bool = True) -> None:
-        """Enqueue the render of frame ``i`` into this rank's buffer; with ``gather`` also assemble a frame on rank 0 --
-        the one before this (frame ``i`` itself is assembled by the next ``step`` or by ``finish``)."""
-        b = i & 1
-        if self._pending is not None and not gather:  # (a frame still waiting to be assembled must not be overwritten)
-            prev, self._pending = self._pending, None
-            self._gather(prev)
+        """Enqueue the render of the next frame into one of this rank's buffers; with ``gather`` also assemble a frame on
+        rank 0 -- the one ``lag`` frames before this (the last ones are assembled by ``finish``).  ``i`` is ignored but for
+        documentation: frames are numbered by the calls."""
+        k = self._count
+        self._count += 1
+        slot, b = k % len(self.scenes), k % len(self.bufs)
+        if self._pending and not gather:  # (frames still waiting to be assembled must not be overwritten)
+            self._drain()
+        st = self.streams[slot]
         if self._free[b] is not None:
-            self.stream.wait_event(self._free[b])
-        self.scene.render_into(self.cam, self.params, self.bufs[b].data_ptr(), self.nbytes,
-                               self.stream.cuda_stream)
+            st.wait_event(self._free[b])
+        self.scenes[slot].render_into(self.cam, self.params, self.bufs[b].data_ptr(), self.nbytes, st.cuda_stream)
         self.last = b
         if self.world > 1 and gather:
             rendered = torch.cuda.Event()
-            rendered.record(self.stream)
+            rendered.record(st)
             self._rendered[b] = rendered
-            prev, self._pending = self._pending, b
-            if prev is not None:
-                self._gather(prev)
+            self._pending.append(b)
+            if len(self._pending) > self.lag:
+                self._gather(self._pending.pop(0))
+
+    def _drain(self) -> None:
+        while self._pending:
+            self._gather(self._pending.pop(0))
 
     def _gather(self, b: int) -> None:
         with torch.cuda.stream(self.comm):
@@ -458,9 +473,7 @@ class ShardedFrameLoop:
             self._free[b] = done
 
     def finish(self) -> None:
-        if self._pending is not None:
-            b, self._pending = self._pending, None
-            self._gather(b)
+        self._drain()
         torch.cuda.synchronize()
 
     def image(self) -> Optional[torch.Tensor]:
