@@ -61,6 +61,28 @@ static int run(int G, int B, int lds, unsigned long long spin, double clock_hz) 
   CHK(hipEventSynchronize(e1));
   float ms = 0.0f;
   CHK(hipEventElapsedTime(&ms, e0, e1));
+  // the same K launches captured in a hipGraph and replayed: does the graph shorten the gap between dependent kernels?
+  float ms_graph = -1.0f;
+  {
+    hipStream_t st;
+    CHK(hipStreamCreate(&st));
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+    CHK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
+    for (int k = 0; k < K; ++k) hipLaunchKernelGGL(spin_kernel<NV>, dim3(G), dim3(B), lds, st, spin, (unsigned long long *)nullptr, sink);
+    CHK(hipStreamEndCapture(st, &graph));
+    CHK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    CHK(hipGraphLaunch(exec, st));
+    CHK(hipStreamSynchronize(st));
+    CHK(hipEventRecord(e0, st));
+    CHK(hipGraphLaunch(exec, st));
+    CHK(hipEventRecord(e1, st));
+    CHK(hipEventSynchronize(e1));
+    CHK(hipEventElapsedTime(&ms_graph, e0, e1));
+    (void)hipGraphExecDestroy(exec);
+    (void)hipGraphDestroy(graph);
+    (void)hipStreamDestroy(st);
+  }
   int regs = 0, resident = 0;
   {
     hipFuncAttributes fa;
@@ -69,8 +91,8 @@ static int run(int G, int B, int lds, unsigned long long spin, double clock_hz) 
     CHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, (const void *)spin_kernel<NV>, B, lds));
   }
   const double tick_us = 1e6 / clock_hz;
-  printf("%5d x %3d threads  LDS %6d B  %3d VGPRs (runtime: %d workgroups fit a CU; most waves running at once: %llu of %llu)  every wave spins %5.2f us | %6.2f us per launch, back to back -> %5.2f us beyond the spin\n", G, B,
-         lds, regs, resident, census[1], (unsigned long long)nw, spin * tick_us, ms * 1e3 / K, ms * 1e3 / K - spin * tick_us);
+  printf("%5d x %3d threads  LDS %6d B  %3d VGPRs (runtime: %d workgroups fit a CU; most waves running at once: %llu of %llu)  every wave spins %5.2f us | %6.2f us per launch, back to back -> %5.2f us beyond the spin; as a hipGraph of %d nodes: %6.2f us per launch\n", G, B,
+         lds, regs, resident, census[1], (unsigned long long)nw, spin * tick_us, ms * 1e3 / K, ms * 1e3 / K - spin * tick_us, K, ms_graph * 1e3 / K);
   (void)hipFree(stamps);
   (void)hipFree(sink);
   return 0;
@@ -115,13 +137,5 @@ int main() {
   run<40>(1024, 256, 12672, us8, clock_hz);
   run<40>(512, 256, 12672, us8, clock_hz);
   run<88>(920, 256, 12672, us8, clock_hz);
-  printf("-- how many waves are resident at once?  64-thread workgroups, every wave spins 8 us: the launch takes ~10 us while all of\n"
-         "   them fit and ~18 us as soon as some have to wait for a slot\n");
-  for (int g = 2048; g <= 9216; g += 512) run<4>(g, 64, 0, us8, clock_hz);
-  for (int g = 2048; g <= 9216; g += 512) run<24>(g, 64, 0, us8, clock_hz);
-  for (int g = 2048; g <= 6144; g += 512) run<40>(g, 64, 0, us8, clock_hz);
-  for (int g = 1024; g <= 5632; g += 512) run<56>(g, 64, 0, us8, clock_hz);
-  for (int g = 1024; g <= 5632; g += 512) run<88>(g, 64, 0, us8, clock_hz);
-  for (int g = 1024; g <= 4608; g += 512) run<120>(g, 64, 0, us8, clock_hz);
   return 0;
 }
