@@ -23,6 +23,10 @@ pytestmark = pytest.mark.gpu
 
 TOL = 1e-5
 
+# (measurement switches may force the round-2 kernels, e.g. PTRACE_TREE=0 PTRACE_TILE4=0 pytest -m gpu: same images)
+TREE_KERNEL = abi.KERNEL_PATH_TREE if os.environ.get("PTRACE_TREE", "1") != "0" else abi.KERNEL_PATH_REGIONS
+TILE4_KERNEL = abi.KERNEL_TILE4 if os.environ.get("PTRACE_TILE4", "1") != "0" else abi.KERNEL_TILE
+
 
 @pytest.fixture(scope="module")
 def dev():
@@ -189,7 +193,7 @@ def test_tree_kernel_deep_and_wide(dev, oracle):
         with dev.DeviceScene(scene) as ds:
             out = ds.render(cam, par)
             st = ds.stats()
-        assert st.kernel == abi.KERNEL_PATH_TREE
+        assert st.kernel == TREE_KERNEL
         ora, n = oracle.render(scene, cam, par, sqr_mode=oracle.SQR_MUL)
         oracle.set_sqr_mode(oracle.SQR_POW)
         bad = int((util.rel_err(out, ora) > TOL).any(axis=-1).sum())
@@ -205,7 +209,7 @@ def test_tree_kernel_deep_and_wide(dev, oracle):
         for rank in range(3):
             p = abi.copy_params(par, n_ranks=3, rank=rank, row_block=5)
             got[abi.rows_for_rank(16, 5, 3, rank)] = ds.render(cam, p)
-            assert ds.stats().kernel == abi.KERNEL_PATH_TREE
+            assert ds.stats().kernel == TREE_KERNEL
             n_sum += int(ds.stats().n_rays)
     assert util.bits_equal(got, full) and n_sum == n_full
 
@@ -238,7 +242,7 @@ def test_tree_kernel_in_a_world_without_a_dome(dev, oracle, n_rays, depth, rr):
         with dev.DeviceScene(scene) as ds:
             out = ds.render(cam, par)
             st = ds.stats()
-        assert st.kernel == abi.KERNEL_PATH_TREE
+        assert st.kernel == TREE_KERNEL
         ora, n = oracle.render(scene, cam, par, sqr_mode=oracle.SQR_MUL)
         oracle.set_sqr_mode(oracle.SQR_POW)
         bad = int((util.rel_err(out, ora) > TOL).any(axis=-1).sum())
@@ -260,7 +264,7 @@ def test_sixteen_by_sixteen_tiles_at_awkward_frame_sizes(dev, oracle, W, H):
                 ds.set_dome_shortcut(dome)
                 out = ds.render(cam, par)
                 st = ds.stats()
-                assert st.kernel == abi.KERNEL_TILE4
+                assert st.kernel == TILE4_KERNEL
                 assert util.bits_equal(out, ora), (renderer, dome)
                 assert int(st.n_rays) == n_rays == W * H
                 assert (st.n_rays_resolved == 0) if not dome else (st.n_rays_resolved <= st.n_rays)
@@ -367,7 +371,7 @@ def test_tile_culling_is_invisible(dev, oracle, n, spread, rotated, W, H, S, ren
                 p = abi.copy_params(par, n_ranks=3, rank=rank, row_block=rb)
                 got[abi.rows_for_rank(H, rb, 3, rank)] = ds.render(cam, p)
                 if S == 0 and n <= 254 and renderer in (abi.RENDERER_FLAT, abi.RENDERER_ONOFF):
-                    assert ds.stats().kernel == (abi.KERNEL_TILE4 if rb % 16 == 0 else abi.KERNEL_TILE), (rb, ds.stats().kernel)
+                    assert ds.stats().kernel == (TILE4_KERNEL if rb % 16 == 0 else abi.KERNEL_TILE), (rb, ds.stats().kernel)
             assert util.bits_equal(got, ora), rb
 
 
@@ -529,7 +533,7 @@ def test_c3_pathtracer_vs_oracle(dev, oracle, n_rays, depth, S, mode):
     with dev.DeviceScene(scene) as ds:
         out = ds.render(cam, par)
         st = ds.stats()
-    assert st.kernel == (abi.KERNEL_PATH_TREE if n_rays > 1 else abi.KERNEL_PATH_REGIONS)
+    assert st.kernel == (TREE_KERNEL if n_rays > 1 else abi.KERNEL_PATH_REGIONS)
     ora, n = oracle.render(scene, cam, par, sqr_mode=oracle.SQR_MUL)
     oracle.set_sqr_mode(oracle.SQR_POW)
     err = util.rel_err(out, ora)
