@@ -15,7 +15,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libptrace.so")
 SOURCES = ["ptrace.hip"]
-DEPS = ["ptrace.hip", "pt_kernels.h", "pt_layout.h", "pt_post.h", os.path.join("..", "..", "include", "ptrace.h"),
+DEPS = ["ptrace.hip", "pt_kernels.h", "pt_math.h", "pt_query.h", "pt_shade.h", "pt_camera.h", "pt_simple.h", "pt_tile.h", "pt_path.h",
+        "pt_tree.h", "pt_probes.h", "pt_layout.h", "pt_post.h", os.path.join("..", "..", "include", "ptrace.h"),
         os.path.join("..", "..", "include", "ptrace_debug.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-fast-math", "-std=c++17", "-fPIC",
          "-shared", "-Wall", "-Wno-unused-function", "-Wno-pass-failed"]

@@ -113,7 +113,7 @@ struct PtKArgs {
   void *out;                       // this rank's rows, compact
   double *ws;                      // path-tracer frame stack: [slot][field][thread]
   unsigned long long *ray_counter; // per-workgroup partial counts; may be null
-  unsigned long long *queue;       // path tracer: the two queue blocks (pt_kernels.h: pt_queue)
+  unsigned long long *queue;       // path tracer: the two queue blocks (pt_path.h: pt_queue)
   int block_h;                     // path tracer's first pass, BLOCKS variant: strips per block (4 or 2)
   int qpar;                        // ... and which of them this frame uses (by value; the device copy of the block holds 0)
   const int4 *units;               // path tracer, second pass: (region, first flagged pixel | pixels << 8, region mask) per work unit

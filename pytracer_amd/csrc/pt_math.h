@@ -1,0 +1,83 @@
+// pt_math.h -- PCG-XSH-RR and Transformation products (pcg.py, transformations.py).
+// A part of pt_kernels.h (which includes the parts in order: each relies on the ones before it); not a header of its own.
+// ---- PCG-XSH-RR 64/32 (pcg.py:23-62) -----------------------------------------------------------
+struct Pcg {
+  uint64_t state, inc;
+  unsigned n;  // draws since the counter was last cleared (only the path tracer's second pass reads it)
+};
+PT_DEV uint32_t pcg_next(Pcg &p) {
+  const uint64_t old = p.state;
+  p.n++;
+  p.state = old * 6364136223846793005ULL + p.inc;
+  const uint32_t xs = (uint32_t)(((old >> 18) ^ old) >> 27);
+  const uint32_t rot = (uint32_t)(old >> 59);
+  return (xs >> rot) | (xs << ((0u - rot) & 31u));
+}
+PT_DEV void pcg_seed(Pcg &p, uint64_t init_state, uint64_t init_seq) {
+  p.state = 0;
+  p.inc = (init_seq << 1) | 1ULL;
+  pcg_next(p);
+  p.state += init_state;
+  pcg_next(p);
+  p.n = 0;
+}
+// The state `delta` draws further on: state -> state * M^delta + inc * (M^(delta-1) + ... + 1) mod 2^64, by
+// repeated squaring (the generator is a linear congruential one; identical to `delta` calls of pcg_next).
+PT_DEV uint64_t pcg_advance(uint64_t state, uint64_t inc, unsigned delta) {
+  uint64_t acc_mul = 1ULL, acc_add = 0ULL, cur_mul = 6364136223846793005ULL, cur_add = inc;
+  while (delta) {
+    if (delta & 1u) {
+      acc_mul *= cur_mul;
+      acc_add = acc_add * cur_mul + cur_add;
+    }
+    cur_add = (cur_mul + 1ULL) * cur_add;
+    cur_mul *= cur_mul;
+    delta >>= 1;
+  }
+  return acc_mul * state + acc_add;
+}
+// pcg.py:60-62: random() / 0xFFFFFFFF, an fp64 division (inclusive 1.0)
+PT_DEV double pcg_float(Pcg &p) { return (double)pcg_next(p) / 4294967295.0; }
+
+// ---- transformations.py:58-86 ----------------------------------------------------------------------
+template <typename P>
+PT_DEV V3 xf_point(P m, V3 p) {
+  V3 r;
+  r.x = p.x * m[0] + p.y * m[1] + p.z * m[2] + m[3];
+  r.y = p.x * m[4] + p.y * m[5] + p.z * m[6] + m[7];
+  r.z = p.x * m[8] + p.y * m[9] + p.z * m[10] + m[11];
+  return r;
+}
+template <typename P>
+PT_DEV V3 xf_vec(P m, V3 v) {
+  V3 r;
+  r.x = v.x * m[0] + v.y * m[1] + v.z * m[2];
+  r.y = v.x * m[4] + v.y * m[5] + v.z * m[6];
+  r.z = v.x * m[8] + v.y * m[9] + v.z * m[10];
+  return r;
+}
+template <typename P>
+PT_DEV V3 xf_normal(P im, V3 n) {  // transpose of the inverse
+  V3 r;
+  r.x = n.x * im[0] + n.y * im[4] + n.z * im[8];
+  r.y = n.x * im[1] + n.y * im[5] + n.z * im[9];
+  r.z = n.x * im[2] + n.y * im[6] + n.z * im[10];
+  return r;
+}
+PT_DEV double dot3(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+// Vec.normalize / Normal.normalize (geometry.py:130-136, 219-225): x*x here
+PT_DEV V3 normalize3(V3 a) {
+  const double n = sqrt(a.x * a.x + a.y * a.y + a.z * a.z);
+  V3 r = {a.x / n, a.y / n, a.z / n};
+  return r;
+}
+// ocml's fp64 sin/cos/atan2/acos are polynomial kernels with ~25 double constants each.  Inlined, LICM
+// hoists those constants out of the pixel loops into VGPRs that stay live for the whole kernel (~50
+// registers for code that runs once per bounce at most).  Behind a call they live only in the callee.
+#define PT_NOINLINE static __device__ __attribute__((noinline))
+PT_NOINLINE double pt_sin(double x) { return sin(x); }
+PT_NOINLINE double pt_cos(double x) { return cos(x); }
+PT_NOINLINE double pt_atan2(double y, double x) { return atan2(y, x); }
+PT_NOINLINE double pt_acos(double x) { return acos(x); }
+
+PT_DEV double max2(double a, double b) { return (b > a) ? b : a; }  // Python max(a, b)

@@ -1,0 +1,909 @@
+// pt_path.h -- PathTracer: work units and the per-lane state machine (pt_path_kernel, pt_path_regions_kernel).
+// A part of pt_kernels.h (which includes the parts in order: each relies on the ones before it); not a header of its own.
+// ---- work units for the path tracer's second pass ---------------------------------------------------------
+// The first pass (pt_tile_kernel<PATHTRACER>) leaves, per 8x8 region, the mask of the pixels that need real
+// path tracing and their number as a key.  The second pass works in UNITS: a unit is up to `ppu` flagged
+// pixels of one region, rendered by one wave whose 64 lanes are shared out L = min(S*S, 64 / pixels) to a
+// pixel -- the lanes of a pixel trace different samples of it at the same time (path_trace).  ppu is chosen
+// from the frame's total F of flagged pixels: with few of them (a rank's share of a frame, a sparse frame) a
+// region is cut into several units so that the whole chip works on samples in parallel instead of a few
+// waves walking their pixels' S*S samples one after the other; with many, ppu = 64 (a unit = a region) and
+// nothing is spent on idle lanes.  Regions without flagged pixels yield nothing.  The order of the units only
+// changes WHEN a pixel is rendered, never its value.
+// Units with the most pixels come first (they have the fewest lanes per pixel, hence the longest chains): a
+// counting sort by size over any number of workgroups, one region per thread -- the first pass counts the regions
+// by their number of flagged pixels, pt_unit_scatter turns the counts into descending offsets of the unit sizes
+// (every workgroup for itself: 64 numbers) and places the units.
+// queue[0] = queue head, [9] = number of units, [10] = ppu (for the statistics), [11] = F (summed up by the first
+// pass), [16 + k] = regions with k flagged pixels (first pass), [96 + s] = units of s pixels placed so far; [PT_QUEUE_HEADS + 32 s] = head of shard s
+// of the unit list (the second pass pulls units through PT_UNIT_SHARDS heads, 256 B apart: one word takes ~88
+// dequeues/us, and thousands of waves pull); all zeroed before the first pass.
+PT_DEV int unit_ppu(const unsigned long long *queue, long long lanes_cap, int nsamp, int min_rounds) {
+  // lanes per pixel every unit gets at least: the largest power of two (<= S*S, <= 64) at which all flagged
+  // pixels together still fit the lanes the launch keeps resident ...
+  const unsigned long long total = queue[11];
+  int lg = 1;
+  while (lg * 2 <= 64 && lg * 2 <= nsamp && (long long)total * (lg * 2) <= lanes_cap) lg *= 2;
+  // ... or more, up to four units per resident wave, as long as a unit keeps `min_rounds` rounds of work: many
+  // short units spread over the chip more evenly than few long ones (a unit's time varies a lot with what its
+  // pixels see), but every unit costs a fetch and a cull, and lanes beyond what speculation can use are wasted
+  // (PT_PCG_PIXEL asks for more rounds per unit than PT_PCG_SAMPLE for that reason).  min_rounds < 0: -min_rounds
+  // rounds, and single-round units where even those come to three or more per resident wave (a full frame of
+  // PT_PCG_SAMPLE: the fetch is cheap next to what finer balancing saves; with fewer units it is not).
+  const int mr = min_rounds < 0 ? -min_rounds : min_rounds;
+  while (lg * 2 <= 64 && lg * 2 * mr <= nsamp && (long long)total * (lg * 2) <= 4 * lanes_cap) lg *= 2;
+  if (min_rounds < 0 && lg * 2 <= 64 && lg * 2 <= nsamp && (long long)total * (lg * 2) <= 4 * lanes_cap &&
+      (long long)total * (lg * 2) >= 3 * lanes_cap)
+    lg *= 2;
+  return 64 / lg;
+}
+#ifndef PT_SCATTER_BLOCK
+#define PT_SCATTER_BLOCK 256
+#endif
+__global__ void pt_unit_scatter(const unsigned char *keys, const unsigned long long *masks, int n, int4 *units, int units_cap,
+                                unsigned long long *queue, long long lanes_cap, int nsamp, int min_rounds) {
+  __shared__ int cnt[65], offs[65];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int k = i < n ? keys[i] : 0;
+  const unsigned long long m = i < n ? masks[i] : 0ULL;  // carried in the unit: one dependent load less when a wave fetches it
+  const int h = threadIdx.x < 64 ? (int)queue[16 + threadIdx.x + 1] : 0;  // (requested together with F: one round trip)
+  const int ppu = unit_ppu(queue, lanes_cap, nsamp, min_rounds);
+  // regions with k flagged pixels (counted by the first pass) -> units of s pixels: a region yields k / ppu units
+  // of ppu pixels and one of k % ppu.  The first wave does it, lane k - 1 for the regions of k pixels.
+  if (threadIdx.x < 65) cnt[threadIdx.x] = 0;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int kk = threadIdx.x + 1;
+    if (h) {
+      if (kk >= ppu) atomicAdd(&cnt[ppu], h * (kk / ppu));
+      if (kk % ppu) atomicAdd(&cnt[kk % ppu], h);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {  // offs[s] = units of more than s pixels (descending order of size)
+    const int sz = 64 - threadIdx.x;  // lane 0 holds the largest size
+    const int c = cnt[sz];
+    int upto = c;
+    for (int off = 1; off < 64; off <<= 1) {
+      const int v = __shfl_up(upto, off, 64);
+      if ((int)threadIdx.x >= off) upto += v;
+    }
+    offs[sz] = upto - c;
+    if (threadIdx.x == 63 && blockIdx.x == 0) {
+      queue[9] = (unsigned long long)(upto < units_cap ? upto : units_cap);
+      queue[10] = (unsigned long long)ppu;
+    }
+  }
+  __syncthreads();
+  const int full = k / ppu, rem = k - full * ppu;
+  // the units of ppu pixels (most of them): one returning atomic per wave, the lanes share out what it reserved
+  const int lane = threadIdx.x & 63;
+  int upto = full;  // inclusive prefix sum over the wave
+  for (int off = 1; off < 64; off <<= 1) {
+    const int v = __shfl_up(upto, off, 64);
+    if (lane >= off) upto += v;
+  }
+  const int wave_total = __shfl(upto, 63, 64);
+  int base = 0;
+  if (wave_total) {
+    if (lane == 63) base = (int)atomicAdd(queue + 96 + ppu, (unsigned long long)wave_total);
+    base = __shfl(base, 63, 64);
+  }
+  if (!k) return;
+  const int mlo = (int)(unsigned)m, mhi = (int)(unsigned)(m >> 32);
+  if (full) {
+    const int at = offs[ppu] + base + upto - full;
+    for (int g = 0; g < full; ++g)
+      if (at + g < units_cap) units[at + g] = make_int4(i, (g * ppu) | (ppu << 8), mlo, mhi);  // (region, first | count << 8, mask)
+  }
+  if (rem) {
+    const int at = offs[rem] + (int)atomicAdd(queue + 96 + rem, 1ULL);
+    if (at < units_cap) units[at] = make_int4(i, (full * ppu) | (rem << 8), mlo, mhi);
+  }
+}
+
+// position of the n-th (0-based) set bit of m (which has more than n bits set)
+PT_DEV int nth_set_bit(unsigned long long m, int n) {
+  int pos = 0;
+#pragma unroll
+  for (int w = 32; w >= 1; w >>= 1) {
+    const int c = __popcll((m >> pos) & ((1ULL << w) - 1ULL));
+    if (n >= c) {
+      pos += w;
+      n -= c;
+    }
+  }
+  return pos & 63;
+}
+
+#ifdef PT_DEBUG_TIME
+#define PT_TRACE_LEN 8192
+__device__ unsigned long long pt_trace[PT_TRACE_LEN + 64 * 80];  // (+ the traced unit's validated draw counts: [pixel][sample], tools/dbgdraws.py)
+#define PT_UNITLOG_LEN 16384
+// per work unit of the second pass: start tick, end tick, rounds | iterations << 32, pixels | lanes per pixel << 8 |
+// workgroup << 16, then the unit's cycles in: scattered-ray queries, shade, sample start + primary query, commit + fetch
+__device__ unsigned long long pt_unitlog[PT_UNITLOG_LEN * 8];
+#endif
+
+// ---- PathTracer (render.py:99-139) as a per-lane state machine ----------------------------------------
+// The reference recursion is depth-first; frame `k` of the explicit stack is the call at depth k.
+// Frame fields (in ws, [slot][field][thread] so a wave's accesses are contiguous):
+//   0..2 hit_color (after Russian roulette)   3..5 emitted
+//   N > 1 only: 6..8 cum_radiance, 9 children done, 10..12 hit point, 13..15 normal,
+//               16..18 incoming direction, 19 brdf kind
+// Pixels are handed out dynamically (one wave-aggregated atomic per refill): a lane that finishes
+// a cheap pixel (sky) immediately takes the next one, so a few expensive pixels (deep recursion,
+// num_of_rays > 1) do not hold 63 idle lanes hostage.  Per-pixel seeds make the image independent
+// of which lane renders which pixel.
+struct PathCtx {
+  double *ws;
+  size_t stride;  // frame_doubles * nthreads
+  size_t nthreads;
+  int gtid;
+  int lds_base, lds_frame;  // LDS frames: first double of the frame area, doubles per frame
+};
+// The frame stack lives in LDS whenever (max_depth x frame) x 256 lanes fits beside the survivor masks
+// (LDSF): the second pass is a chain of dependent steps per pixel, and a frame access that goes to
+// HBM costs more than the step's arithmetic.  Same [slot][field][lane] layout in both homes.
+extern __shared__ double pt_lds_f64[];  // the same dynamic LDS block as pt_lds_masks
+template <bool LDSF>
+PT_DEV double ws_get(const PathCtx &w, int slot, int field) {
+  if (LDSF) return pt_lds_f64[w.lds_base + (slot * w.lds_frame + field) * PT_BLOCK + (int)threadIdx.x];
+  return w.ws[(size_t)slot * w.stride + (size_t)field * w.nthreads + w.gtid];
+}
+template <bool LDSF>
+PT_DEV void ws_put(const PathCtx &w, int slot, int field, double v) {
+  if (LDSF)
+    pt_lds_f64[w.lds_base + (slot * w.lds_frame + field) * PT_BLOCK + (int)threadIdx.x] = v;
+  else
+    w.ws[(size_t)slot * w.stride + (size_t)field * w.nthreads + w.gtid] = v;
+}
+
+// next pixel for every lane with `need` set; returns -1 when the frame is exhausted
+PT_DEV long long next_pixel(const PtKArgs &a, bool need, long long npix) {
+  const unsigned long long mask = __ballot(need);
+  long long pix = -1;
+  if (need) {
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)mask) - 1;
+    const int rank = __popcll(mask & ((1ULL << lane) - 1ULL));
+    unsigned long long base = 0;
+    if (lane == leader) base = atomicAdd(pt_queue(a), (unsigned long long)__popcll(mask));
+    base = __shfl(base, leader, 64);
+    const long long p = (long long)(base + rank);
+    pix = p < npix ? p : -1;
+  }
+  return pix;
+}
+
+// Two kinds of work alternate inside a wave, each executed only by the lanes that need it and only
+// when enough of them do (the bodies are skipped wave-wide otherwise):
+//   P  lanes starting a sample (mode 0): jitter draws, primary ray, query against the survivors.
+//   S  lanes holding a scattered ray (mode 1): query against ALL shapes.
+// Both kinds then share one shade + unwind block (deliver radiance up the frame stack, scatter the
+// next child) which leaves each lane with a ray to query (mode 1), a finished sample (mode 0 / 3) or a
+// finished pixel (mode 2).  S queries are batched until >= 16 lanes wait, so the 32..10k-shape loop
+// does not run for one or two lanes at a time; regions of pure background never run it.
+//
+// !TILED (orthogonal camera): 1 lane = 1 pixel, pixels come from one global queue, a lane walks its pixel's
+// samples one after the other and P-steps run the full shape loop.
+//
+// TILED (perspective camera, second pass): a wave works through UNITS (pt_unit_scatter): up to 64 flagged pixels
+// of one 8x8 region.  The unit's P-steps use the hoisted, culled tile query against the region's survivor
+// masks.  The wave's lanes are shared out L = min(S*S, 64 / pixels) to a pixel, and the L lanes of a pixel
+// trace L consecutive samples of it AT THE SAME TIME (a "round"):
+//   PT_PCG_SAMPLE  every sample owns its generator: the L samples are independent, all of them count.
+//   PT_PCG_PIXEL   the samples of a pixel share ONE generator, consumed in program order: where sample k+1
+//     starts in the stream depends on how many numbers sample k drew, which is only known once its path has
+//     ended.  Lane j therefore SPECULATES: it guesses what each of the j samples before it draws -- what the last
+//     validated sample of the pixel drew, or, where that has been the better guess for this pixel so far, what each
+//     sample's upper neighbour in the S x S grid of strata drew (a pixel across an edge repeats its row of short and
+//     long paths; `hist`, `pscore`) -- and starts from the state that many draws ahead (pcg_advance).  After the round the samples are validated in order: sample j counts if and only
+//     if the state it started from IS the state sample j-1 ended with -- then everything it computed is what
+//     the sequential program computes -- and the first one that started elsewhere is thrown away together
+//     with everything behind it and repeated in the next round, now from the right state.  The first lane
+//     always starts from the validated state, so every round completes at least one sample.
+// A round's radiances are added to the pixel's sum in sample order (imagetracer.py:97: cum_color += ...), one
+// lane after the other through wave shuffles, so the sum is the sequential one bit for bit; rays are counted
+// for validated samples only.  Per-pixel / per-sample seeds depend on the global pixel index alone: the image
+// does not depend on how regions are cut into units or how many lanes a pixel gets.
+// LAT: the second pass is built for few waves per SIMD; its time is set by chains of dependent steps:
+// everything inline, registers no object.
+#ifndef PT_REGIONS_INLINE
+#define PT_REGIONS_INLINE 1  // second pass: HitRecord / scatter / transcendental code inline (1) or behind calls (0)
+#endif
+template <bool TILED, bool LDSF, bool LAT, bool SLDS = false, int LEAN = 0>
+PT_DEV void path_trace(const PtKArgs &a) {
+  constexpr bool INL = LAT && PT_REGIONS_INLINE;
+  static_assert(!SLDS || INL, "the scene is staged in LDS for the second pass only");
+  PathCtx w;
+  int S, nsamp, N, W = 0, rows_local = 0, npass = 0, D = 0, rr = 0, diag_lds = -1, pcg_mode = PT_PCG_PIXEL;
+  bool ortho = false;
+  {
+    pt_kargs c = cold_args(a);
+    w.ws = c->ws;
+    w.nthreads = (size_t)c->nthreads;
+    w.stride = (size_t)c->frame_doubles * w.nthreads;
+    w.gtid = blockIdx.x * PT_BLOCK + threadIdx.x;
+    w.lds_frame = c->frame_doubles;
+    w.lds_base = TILED ? 4 * c->npass : 0;  // behind the four waves' survivor masks (8-byte units)
+    ortho = c->cam_kind != PT_CAMERA_PERSPECTIVE;
+    diag_lds = c->diag_lds;
+    pcg_mode = c->pcg_mode;
+    S = c->S;
+    N = c->N;
+    W = c->W;
+    rows_local = c->rows_local;
+    npass = c->npass;
+    D = c->D;
+    rr = c->rr;
+  }
+  if (blockIdx.x == gridDim.x - 1) {  // the next frame's queue block (nothing of this frame reads it)
+    unsigned long long *qn = pt_queue_next(a);
+    for (int k = threadIdx.x; k < PT_QUEUE_WORDS; k += PT_BLOCK) qn[k] = 0ULL;
+  }
+  if (LAT && diag_lds >= 0) {
+    // scale+translate records into LDS: world_query_lanes fetches them by lane-private index
+    const unsigned long long *src = (const unsigned long long *)a.diag;
+    for (int k = threadIdx.x; k < a.n_diag * 8; k += PT_BLOCK) pt_lds_masks[diag_lds + k] = src[k];
+    __syncthreads();
+  }
+  int scene_lds = 0;
+  if (SLDS) {
+    // the shapes' records (128 B + 256 B each) into LDS: shading gathers ~20 values of the hit shape per lane, and a
+    // gather from LDS costs a fraction of one through the vector memory path (8 waves of a CU share one of those)
+    scene_lds = cold_args(a)->scene_lds;
+    const unsigned long long *src = (const unsigned long long *)a.recs;
+    for (int k = threadIdx.x; k < a.n_shapes * 16; k += PT_BLOCK) pt_lds_masks[scene_lds + k] = src[k];
+    src = (const unsigned long long *)a.aux;
+    for (int k = threadIdx.x; k < a.n_shapes * 32; k += PT_BLOCK) pt_lds_masks[scene_lds + a.n_shapes * 16 + k] = src[k];
+    __syncthreads();
+  }
+  if (LAT) {  // the grid's occupancy bits into LDS: the cell walk of world_query_lanes reads one per step
+    pt_kargs c = cold_args(a);
+    const int occ_lds = c->grid_occ_lds;
+    if (occ_lds >= 0) {
+      const int nwords = (c->grid_res[0] * c->grid_res[1] * c->grid_res[2] + 31) / 32;
+      unsigned *dst = (unsigned *)pt_lds_masks;
+      for (int k = threadIdx.x; k < nwords; k += PT_BLOCK) dst[occ_lds + k] = c->grid_occ[k];
+      __syncthreads();
+    }
+  }
+  nsamp = S > 0 ? S * S : 1;
+  const double invN = 1.0 / (double)N;
+  const int lane = threadIdx.x & 63;
+  const int mbase = (threadIdx.x >> 6) * npass;
+  const int regions_x = (W + PT_REGION - 1) / PT_REGION;
+  bool exhausted = false;           // !TILED: the global queue is empty
+  bool first_unit = true;           // TILED (wave-uniform)
+  // TILED: units of the frame (written by pt_unit_scatter before this kernel started; read once -- not from the heads' lines)
+  const int n_units = TILED ? (int)pt_queue(a)[9] : 0;
+  unsigned long long nrays = 0;
+
+  // lane state.  mode 0: starts a sample at the next P-step; 1: inside a path (S-steps); 2: nothing to do;
+  // 3 (TILED): sample finished, waits for the end of the round
+  int mode = 2;
+  long long pix = -1;
+  Pcg pcg;
+  pcg.state = 0;
+  pcg.inc = 1;
+  pcg.n = 0;
+  int samp = 0, sp = 0, col = 0, grow = 0;
+  V3 cum = {0.0, 0.0, 0.0};
+  Ray ray;
+  ray.o = {0.0, 0.0, 0.0};
+  ray.d = {1.0, 0.0, 0.0};
+  ray.tmin = 1e-5;
+  // what shade() hands to the unwind loop of the same step: a value to deliver, or a child to spawn
+  V3 ret = {0.0, 0.0, 0.0};
+  bool spawn = false;
+  V3 f_wp = {0.0, 0.0, 0.0}, f_n = {0.0, 0.0, 1.0}, f_in = {1.0, 0.0, 0.0};
+  int f_brdf = 0;
+  // TILED: the unit (wave-uniform) and this lane's place in it
+  int L = 1;                        // lanes per pixel
+  int leader = lane, jlane = 0;     // first lane of this lane's pixel; this lane's sample slot in a round
+  bool in_unit = false;             // the lane belongs to a pixel of the unit
+  int vbase = 0;                    // samples of the pixel validated so far (same in all lanes of the pixel)
+  uint64_t vstate = 0;              // PT_PCG_PIXEL: generator state behind the last validated sample
+  // PT_PCG_PIXEL: what the pixel's last eight validated samples drew, a byte each, the latest in the low byte.  The guess
+  // for sample k is what sample k - S drew -- its neighbour one row up in the S x S grid of strata (imagetracer.py:86-93):
+  // a pixel across an edge repeats its pattern of short and long paths row after row, where "what the last sample drew"
+  // is wrong twice per row.  (S > 8: the sample before it.)
+  uint64_t hist = 0;
+  int pscore = 0;                   // ... how much more often the upper neighbour was the better guess than the predecessor (per pixel)
+  const int hperiod = (S >= 1 && S <= 8) ? S : 1;
+  uint64_t st_start = 0;            // state this lane's sample started from
+  unsigned srays = 0, prays = 0;    // rays of the current sample; of the pixel's validated samples
+  unsigned long long gpix = 0;      // global pixel index (seeds)
+
+  // pixel coordinates + seeds + the sample's primary ray (imagetracer.py:86-97)
+  auto start_sample = [&]() {
+    pt_kargs c = cold_args(a);
+    if (!TILED) {
+      if (samp == 0) {
+        pixel_coords(a, pix, col, grow);
+        if (c->pcg_mode == PT_PCG_PIXEL) pcg_seed(pcg, c->s0, c->q0 + ((unsigned long long)grow * c->W + col));
+      }
+      if (c->pcg_mode == PT_PCG_SAMPLE)
+        pcg_seed(pcg, c->s0, c->q0 + ((unsigned long long)grow * c->W + col) * (unsigned)nsamp + (unsigned)samp);
+    }
+    double up = 0.5, vp = 0.5;
+    if (S > 0) {
+      const int sr = samp / S, sc = samp - sr * S;
+      up = ((double)sc + pcg_float(pcg)) / (double)S;
+      vp = ((double)sr + pcg_float(pcg)) / (double)S;
+    }
+    ray = primary_ray(a, col, grow, up, vp);
+  };
+
+  // TILED: the generator a lane's next sample starts from, `samp` = vbase + jlane
+  auto seed_round = [&]() {
+    pt_kargs c = cold_args(a);
+    if (pcg_mode == PT_PCG_SAMPLE)
+      pcg_seed(pcg, c->s0, c->q0 + gpix * (unsigned)nsamp + (unsigned)samp);
+    else
+    {
+      // (sample vbase + i: what its upper neighbour vbase + i - period drew, if the pixel has got that far and that guess
+      //  has been the better one so far; else what the last validated sample drew)
+      const int period = hperiod;
+      unsigned ahead = (unsigned)jlane * ((unsigned)hist & 0xffu);
+      if (pscore > 0) {
+        ahead = 0;
+        for (int i = 0; i < jlane; ++i)
+          ahead += (unsigned)(hist >> (vbase + (i % period) >= period ? 8 * (period - 1 - (i % period)) : 0)) & 0xffu;
+      }
+      pcg.state = pcg_advance(vstate, pcg.inc, ahead);
+    }
+    pcg.n = 0;
+    st_start = pcg.state;
+    srays = 0;
+  };
+
+  // render.py:103-139 up to (not including) the recursion: sets `ret`, or pushes frame `sp` and asks
+  // for child 0 (`spawn`).  `ray` is the ray that was queried, at depth `sp`.
+  auto shade_hit = [&](auto rec, auto ax, double best_t) {
+    V3 hc, em;
+    double lum;
+    Hit h;
+    h.u = 0.0;
+    h.v = 0.0;
+    const bool uv = ax->needs_uv != 0;
+    bool details = false;
+    if (uv) {
+      if constexpr (INL)
+        hit_details<true>(rec, ax, ray, best_t, h, true);
+      else
+        hit_details_call(rec, ax, &ray, best_t, &h, true);
+      details = true;
+    }
+    hc = brdf_pigment(a, ax, h.u, h.v);
+    em = emitted_pigment(a, ax, h.u, h.v);
+    lum = max2(max2(hc.x, hc.y), hc.z);
+    if (sp >= rr) {  // render.py:116-123
+      const double q = max2(0.05, 1.0 - lum);
+      if (pcg_float(pcg) > q) {
+        const double k = 1.0 / (1.0 - q);
+        hc.x = hc.x * k;
+        hc.y = hc.y * k;
+        hc.z = hc.z * k;
+      } else {
+        ret = em;
+        return;
+      }
+    }
+    if (!(lum > 0.0)) {  // render.py:139 with cum_radiance = 0
+      ret.x = em.x + 0.0 * invN;
+      ret.y = em.y + 0.0 * invN;
+      ret.z = em.z + 0.0 * invN;
+      return;
+    }
+    if (sp + 1 > D) {
+      // Every child of this hit would be beyond max_depth: the reference still calls scatter_ray for each
+      // (consuming its draws: 2 for a diffuse BRDF, none for a mirror) and each child returns black at
+      // render.py:100-101 without a world query.  No ray, no frame, no geometry is needed: advance the
+      // generator and accumulate hit_color * 0 exactly as render.py:135-139 does.
+      const bool diffuse = ax->brdf_kind == PT_BRDF_DIFFUSE;
+      V3 fc = {0.0, 0.0, 0.0};
+      for (int i = 0; i < N; ++i) {
+        if (diffuse) {
+          pcg_next(pcg);
+          pcg_next(pcg);
+        }
+        fc.x = fc.x + hc.x * 0.0;
+        fc.y = fc.y + hc.y * 0.0;
+        fc.z = fc.z + hc.z * 0.0;
+      }
+      ret.x = em.x + fc.x * invN;
+      ret.y = em.y + fc.y * invN;
+      ret.z = em.z + fc.z * invN;
+      return;
+    }
+    // render.py:126-137: push the frame, child 0 is scattered at the next S-step
+    if (!details) {
+      if constexpr (INL)
+        hit_details<true>(rec, ax, ray, best_t, h, false);
+      else
+        hit_details_call(rec, ax, &ray, best_t, &h, false);
+    }
+    ws_put<LDSF>(w, sp, 0, hc.x);
+    ws_put<LDSF>(w, sp, 1, hc.y);
+    ws_put<LDSF>(w, sp, 2, hc.z);
+    ws_put<LDSF>(w, sp, 3, em.x);
+    ws_put<LDSF>(w, sp, 4, em.y);
+    ws_put<LDSF>(w, sp, 5, em.z);
+    if (N > 1) {
+      ws_put<LDSF>(w, sp, 6, 0.0);
+      ws_put<LDSF>(w, sp, 7, 0.0);
+      ws_put<LDSF>(w, sp, 8, 0.0);
+      ws_put<LDSF>(w, sp, 9, 0.0);
+      ws_put<LDSF>(w, sp, 10, h.wp.x);
+      ws_put<LDSF>(w, sp, 11, h.wp.y);
+      ws_put<LDSF>(w, sp, 12, h.wp.z);
+      ws_put<LDSF>(w, sp, 13, h.n.x);
+      ws_put<LDSF>(w, sp, 14, h.n.y);
+      ws_put<LDSF>(w, sp, 15, h.n.z);
+      ws_put<LDSF>(w, sp, 16, ray.d.x);
+      ws_put<LDSF>(w, sp, 17, ray.d.y);
+      ws_put<LDSF>(w, sp, 18, ray.d.z);
+      ws_put<LDSF>(w, sp, 19, (double)ax->brdf_kind);
+    }
+    f_wp = h.wp;
+    f_n = h.n;
+    f_in = ray.d;
+    f_brdf = ax->brdf_kind;
+    sp++;
+    spawn = true;
+  };
+  auto shade = [&](int hit, double best_t) {
+    spawn = false;
+    if (hit < 0) {  // render.py:103-105
+      pt_kargs c = cold_args(a);
+      ret.x = c->bg[0];
+      ret.y = c->bg[1];
+      ret.z = c->bg[2];
+      return;
+    }
+    if constexpr (SLDS)
+      shade_hit((pt_lds_rec)(const void *)(pt_lds_f64 + scene_lds) + hit,
+                (pt_lds_aux)(const void *)(pt_lds_f64 + scene_lds + a.n_shapes * 16) + hit, best_t);
+    else
+      shade_hit(a.recs + hit, cold_args(a)->aux + hit, best_t);
+  };
+
+  // the primary call returned `ret`: one sample done (imagetracer.py:94-104)
+  auto finish_sample = [&]() {
+    if (TILED) {  // the radiance stays in `ret` until the round is validated
+      mode = 3;
+      return;
+    }
+    if (S > 0) {
+      cum.x = cum.x + ret.x;
+      cum.y = cum.y + ret.y;
+      cum.z = cum.z + ret.z;
+    } else {
+      cum = ret;
+    }
+    mode = 0;
+    if (++samp == nsamp) {
+      if (S > 0) {
+        const double k = 1.0 / (double)(S * S);
+        cum.x = cum.x * k;
+        cum.y = cum.y * k;
+        cum.z = cum.z * k;
+      }
+      store_pixel(a, pix, cum);
+      cum.x = 0.0;
+      cum.y = 0.0;
+      cum.z = 0.0;
+      samp = 0;
+      mode = 2;
+    }
+  };
+
+#ifdef PT_DEBUG_TIME
+  // section sums for every wave, plus a step-by-step trace of the wave that drew the first (fullest) unit
+  unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
+  bool tracing = false;
+  int trace_n = 0;
+  int ulog_seq = -1, ulog_rounds = 0, ulog_iters = 0;
+  unsigned long long ulog_t[4] = {0, 0, 0, 0};
+  unsigned long long dbg_q[3] = {0, 0, 0};
+#define PT_STAMP(k)                                                                        \
+  do {                                                                                     \
+    const unsigned long long tn = __builtin_amdgcn_s_memtime();                            \
+    tsum[k] += tn - tprev;                                                                 \
+    const unsigned long long np_ = (unsigned long long)__popcll(__ballot(mode == 1));     \
+    if (tracing && lane == 0 && trace_n < PT_TRACE_LEN)                                    \
+      pt_trace[trace_n] = ((tn - tprev) << 16) | (np_ << 8) | (k);                         \
+    if (tracing) trace_n++;                                                                \
+    tprev = tn;                                                                            \
+  } while (0)
+#else
+#define PT_STAMP(k) do { } while (0)
+#endif
+  for (;;) {
+    PT_STAMP(7);
+    // (values that never flow from one iteration into the next: said explicitly, so that they hold no
+    //  registers across the queries)
+    spawn = false;
+    f_wp = {0.0, 0.0, 0.0};
+    f_n = {0.0, 0.0, 1.0};
+    f_in = {1.0, 0.0, 0.0};
+    f_brdf = 0;
+    // ---- work for idle lanes ----
+    if (TILED) {
+      if (!__any(mode == 0 || mode == 1)) {
+        if (__any(mode == 3)) {
+          // ---- end of a round: validate the pixel's samples in order, add them up in order ----
+          // (every lane of a pixel runs the same loop over the pixel's L lanes and ends with the same
+          //  vbase / vstate / hist; only the values in the leader are used for the pixel's result)
+          const bool fin = mode == 3;
+          bool chain = true;
+#ifdef PT_DEBUG_TIME
+          ulog_rounds++;
+          const int dbg_vbase0 = vbase;
+          int dbg_fin = 0;
+#endif
+          for (int jj = 0; jj < L; ++jj) {
+            const int src = (leader + jj) & 63;
+            uint64_t s_from = 0, s_to = 0;  // (PT_PCG_SAMPLE validates nothing: five cross-lane reads less per turn)
+            unsigned s_draws = 0;
+            if (pcg_mode != PT_PCG_SAMPLE) {
+              s_from = __shfl((unsigned long long)st_start, src, 64);
+              s_to = __shfl((unsigned long long)pcg.state, src, 64);
+              s_draws = (unsigned)__shfl((int)pcg.n, src, 64);
+            }
+            const int s_fin = __shfl((int)fin, src, 64);
+            const unsigned s_rays = (unsigned)__shfl((int)srays, src, 64);
+            const double rx_ = __shfl(ret.x, src, 64), ry_ = __shfl(ret.y, src, 64), rz_ = __shfl(ret.z, src, 64);
+            chain = chain && s_fin != 0 && (pcg_mode == PT_PCG_SAMPLE || s_from == vstate);
+#ifdef PT_DEBUG_TIME
+            dbg_fin += s_fin;
+#endif
+            if (chain) {
+              if (S > 0) {  // imagetracer.py:97
+                cum.x = cum.x + rx_;
+                cum.y = cum.y + ry_;
+                cum.z = cum.z + rz_;
+              } else {
+                cum.x = rx_;
+                cum.y = ry_;
+                cum.z = rz_;
+              }
+              vstate = s_to;
+              if (vbase >= hperiod)  // which guess would have been right for this sample: its upper neighbour's draws, or its predecessor's?
+                pscore += (int)(((unsigned)(hist >> (8 * (hperiod - 1))) & 0xffu) == (s_draws & 0xffu)) - (int)(((unsigned)hist & 0xffu) == (s_draws & 0xffu));
+              hist = (hist << 8) | (uint64_t)(s_draws & 0xffu);
+              prays += s_rays;
+              vbase++;
+#ifdef PT_DEBUG_TIME
+              if (tracing && in_unit && lane == leader && (leader / L) < 64 && vbase <= 80)
+                pt_trace[PT_TRACE_LEN + (leader / L) * 80 + (vbase - 1)] = ((unsigned long long)ulog_rounds << 32) | ((unsigned long long)s_draws << 16) | ((unsigned long long)(leader / L) << 8) | 0xEEULL;
+#endif
+            }
+          }
+          mode = 2;
+#ifdef PT_DEBUG_TIME
+          {  // speculation statistics: pixel-rounds, samples traced, samples kept
+            const bool lead = in_unit && lane == leader && pix >= 0;
+            unsigned long long r4 = lead ? 1ULL : 0ULL, r5 = lead ? (unsigned long long)dbg_fin : 0ULL,
+                               r6 = lead ? (unsigned long long)(vbase - dbg_vbase0) : 0ULL;
+            for (int off = 32; off > 0; off >>= 1) {
+              r4 += __shfl_down(r4, off, 64);
+              r5 += __shfl_down(r5, off, 64);
+              r6 += __shfl_down(r6, off, 64);
+            }
+            if (lane == 0) {
+              unsigned long long *wv = pt_dbg_wave + (size_t)((blockIdx.x * PT_BLOCK + threadIdx.x) >> 6) * 8;
+              wv[4] += r4;
+              wv[5] += r5;
+              wv[6] += r6;
+            }
+          }
+#endif
+          if (in_unit) {
+            if (vbase >= nsamp) {
+              if (lane == leader && pix >= 0) {  // imagetracer.py:99-104
+                if (S > 0) {
+                  const double k = 1.0 / (double)(S * S);
+                  cum.x = cum.x * k;
+                  cum.y = cum.y * k;
+                  cum.z = cum.z * k;
+                }
+                store_pixel(a, pix, cum);
+                nrays += prays;
+              }
+              pix = -1;  // this pixel is done (in every lane of it)
+            } else {
+              samp = vbase + jlane;
+              if (samp < nsamp) {
+                seed_round();
+                mode = 0;
+              }
+            }
+          }
+        }
+        PT_STAMP(3);
+        if (!__any(mode == 0)) {
+          // next unit for this wave, then its region's cone and survivor masks.  The sorted unit list is dealt out
+          // to PT_UNIT_SHARDS shards (unit u belongs to shard u % shards: every shard the same mix of sizes) and a
+          // workgroup pulls from shard blockIdx % shards only: a returning atomic on ONE head word saturates near 88
+          // dequeues/us -- with thousands of waves pulling, queueing at the head costs more than a unit's work.  A
+          // wave's first unit is its own rank in the shard (no atomic at all), later ones come from the shard's head,
+          // one atomic by lane 0.
+          unsigned uid = 0;
+          const unsigned nsh = gridDim.x < PT_UNIT_SHARDS ? gridDim.x : PT_UNIT_SHARDS;  // (every shard needs a puller)
+          const unsigned shard = blockIdx.x % nsh;
+          if (first_unit) {
+            uid = (blockIdx.x / nsh) * (PT_BLOCK / 64) + (threadIdx.x >> 6);
+            first_unit = false;
+          } else {
+            const unsigned pullers = (gridDim.x - shard + nsh - 1) / nsh * (PT_BLOCK / 64);
+#ifdef PT_DEBUG_TIME
+            PT_VM_DRAIN();
+            const unsigned long long lt0 = __builtin_amdgcn_s_memtime();
+#endif
+            if (lane == 0) uid = pullers + (unsigned)atomicAdd(pt_queue(a) + PT_QUEUE_HEADS + 32 * shard, 1ULL);
+#ifdef PT_DEBUG_TIME
+            asm volatile("s_waitcnt vmcnt(0)" : : "v"(uid) : "memory");
+            lat_note(2, __builtin_amdgcn_s_memtime() - lt0);
+#endif
+          }
+          uid = uid * nsh + shard;
+          const int seq = (int)__builtin_amdgcn_readfirstlane((int)uid);
+          PT_STAMP(6);
+#ifdef PT_DEBUG_TIME
+          tracing = seq == cold_args(a)->dbg_trace_unit;  // (or, below, the unit that starts at a given flagged pixel of a given region)
+          if (LAT && tracing && lane == 0) {
+            const unsigned long long *wv = pt_dbg_wave + (size_t)((blockIdx.x * PT_BLOCK + threadIdx.x) >> 6) * 8;
+            for (int q = 0; q < 3; ++q) dbg_q[q] = __hip_atomic_load(wv + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          if (lane == 0 && ulog_seq >= 0 && ulog_seq < PT_UNITLOG_LEN) {  // close the log entry of the unit just finished
+            pt_unitlog[ulog_seq * 8 + 1] = __builtin_amdgcn_s_memtime();
+            pt_unitlog[ulog_seq * 8 + 2] = (unsigned long long)ulog_rounds | ((unsigned long long)ulog_iters << 32);
+            pt_unitlog[ulog_seq * 8 + 4] = tsum[4] - ulog_t[0];
+            pt_unitlog[ulog_seq * 8 + 5] = tsum[5] - ulog_t[1];
+            pt_unitlog[ulog_seq * 8 + 6] = tsum[1] + tsum[2] - ulog_t[2];
+            pt_unitlog[ulog_seq * 8 + 7] = tsum[0] - ulog_t[3];
+          }
+          ulog_t[0] = tsum[4];
+          ulog_t[1] = tsum[5];
+          ulog_t[2] = tsum[1] + tsum[2];
+          ulog_t[3] = tsum[0];
+          ulog_seq = seq;
+          ulog_rounds = 0;
+          ulog_iters = 0;
+#endif
+          pt_kargs ca = cold_args(a);
+          if (seq >= n_units) break;
+#ifdef PT_DEBUG_TIME
+          if (lane == 0) pt_dbg_wave[(size_t)((blockIdx.x * PT_BLOCK + threadIdx.x) >> 6) * 8 + 7] += 1ULL;
+#endif
+#ifdef PT_DEBUG_TIME
+          const unsigned long long lt0 = __builtin_amdgcn_s_memtime();
+          PT_VM_DRAIN();
+          const unsigned long long lt1 = __builtin_amdgcn_s_memtime();
+          const int4 unit = ca->units[seq];
+          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : : "v"(unit.x) : "memory");
+          lat_note(0, __builtin_amdgcn_s_memtime() - lt1);
+          lat_note(1, lt1 - lt0);
+#else
+          const int4 unit = ca->units[seq];
+#endif
+          const int region = unit.x, first = unit.y & 0xff, count = (unit.y >> 8) & 0xff;
+#ifdef PT_DEBUG_TIME
+          if (cold_args(a)->dbg_trace_unit <= -2) tracing = (-2 - cold_args(a)->dbg_trace_unit) == region * 64 + first;  // (unit numbers vary from frame to frame)
+#endif
+          const unsigned long long todo = (unsigned long long)(unsigned)unit.z | ((unsigned long long)(unsigned)unit.w << 32);  // the region's flagged pixels
+          const int ry = region / regions_x, rx = region - ry * regions_x;
+          const int gr0 = global_row(a, ry * PT_REGION);
+          const int gr1 = global_row(a, (ry * PT_REGION + PT_REGION - 1 < rows_local) ? ry * PT_REGION + PT_REGION - 1 : rows_local - 1);
+          const TileCone tc = tile_cone(a, rx * PT_REGION, (rx * PT_REGION + PT_REGION < W) ? rx * PT_REGION + PT_REGION : W, gr0, gr1);
+          __builtin_amdgcn_wave_barrier();
+          for (int p = 0; p < npass; ++p) {
+            const int slot = p * 64 + lane;
+            bool keep = false;
+            if (slot < a.n_shapes) keep = slot >= a.n_spheres || cone_keeps(tc, a.bounds[slot]);  // planes: always
+            const unsigned long long m = __ballot(keep);
+            if (lane == 0) pt_lds_masks[mbase + p] = m;
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          // lanes [p * L, (p + 1) * L) take the unit's p-th pixel = flagged pixel `first + p` of the region
+          L = 64 / count;
+          if (L > nsamp) L = nsamp;
+#ifdef PT_DEBUG_TIME
+          if (lane == 0 && seq < PT_UNITLOG_LEN) {
+            pt_unitlog[seq * 8 + 0] = __builtin_amdgcn_s_memtime();
+            pt_unitlog[seq * 8 + 3] = (unsigned long long)count | ((unsigned long long)L << 8) | ((unsigned long long)(blockIdx.x & 0x3ff) << 16) |
+                                      ((unsigned long long)first << 26) | ((unsigned long long)region << 32);
+          }
+#endif
+          const int pidx = lane / L;
+          in_unit = pidx < count;
+          leader = in_unit ? pidx * L : lane;
+          jlane = lane - leader;
+          mode = 2;
+          pix = -1;
+          if (in_unit) {
+            const int bit = nth_set_bit(todo, first + pidx);
+            pix = (long long)(ry * PT_REGION + (bit >> 3)) * W + (rx * PT_REGION + (bit & 7));
+            pixel_coords(a, pix, col, grow);
+            gpix = (unsigned long long)grow * ca->W + col;
+            if (pcg_mode != PT_PCG_SAMPLE) {
+              pcg_seed(pcg, ca->s0, ca->q0 + gpix);
+              vstate = pcg.state;
+            }
+            hist = 0x0101010101010101ULL * (uint64_t)(ca->spec_draws & 0xff);
+            pscore = 0;
+            vbase = 0;
+            prays = 0;
+            cum.x = 0.0;
+            cum.y = 0.0;
+            cum.z = 0.0;
+            samp = jlane;
+            if (samp < nsamp) {
+              seed_round();
+              mode = 0;
+            }
+          }
+        }
+      }
+    } else {
+      const bool need = mode == 2 && !exhausted;
+      if (__any(need)) {
+        const long long np = next_pixel(a, need, a.npix);
+        if (need) {
+          if (np >= 0) {
+            pix = np;
+            mode = 0;
+          }
+        }
+        exhausted = __any(need && np < 0);
+      }
+      if (!__any(mode != 2)) break;
+    }
+
+    PT_STAMP(0);
+#ifdef PT_DEBUG_TIME
+    ulog_iters++;
+#endif
+    const int n_start = __popcll(__ballot(mode == 0));
+    const int n_path = __popcll(__ballot(mode == 1));
+    if (n_start == 0 && n_path == 0) continue;  // TILED: nothing in flight, the round / unit logic above decides
+    const bool do_p = n_start > 0 && n_path < cold_args(a)->p_max_path;
+    const bool do_s = n_path >= cold_args(a)->s_min_path || (n_path > 0 && !do_p);
+
+    // ---- queries: primary rays against the region's survivors, scattered rays against everything ----
+    const bool prim = do_p && mode == 0;
+    const bool scat = do_s && mode == 1;
+    double best_t = INFINITY;
+    int hit = -1;
+    if (do_p) {
+      if (prim) start_sample();
+      PT_STAMP(1);
+      double tp = INFINITY;
+      int hp;
+      if (TILED)
+        hp = ortho ? world_query_tile<false, false, false>(a, ray, mbase, npass, tp, prim)
+                   : world_query_tile<false, false, true>(a, ray, mbase, npass, tp, prim);
+      else
+        hp = world_query<false, false>(a, ray, INFINITY, tp, prim);
+      if (prim) {
+        hit = hp;
+        best_t = tp;
+      }
+      PT_STAMP(2);
+    }
+    if (do_s) {
+      double ts;
+      const int hs = LAT ? world_query_lanes<false, LEAN>(a, ray, INFINITY, ts, scat, diag_lds) : world_query<false, false>(a, ray, INFINITY, ts, scat);
+      if (scat) {
+        hit = hs;
+        best_t = ts;
+      }
+      PT_STAMP(4);
+#ifdef PT_DEBUG_TIME
+      if (LAT && tracing && lane == 0) {  // the traced unit: this query's prefilter cycles (8), walk cycles (9), walk turns (10)
+        const unsigned long long *wv = pt_dbg_wave + (size_t)((blockIdx.x * PT_BLOCK + threadIdx.x) >> 6) * 8;
+        for (int q = 0; q < 3; ++q) {
+          const unsigned long long now = __hip_atomic_load(wv + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (trace_n < PT_TRACE_LEN) pt_trace[trace_n] = ((now - dbg_q[q]) << 16) | (unsigned long long)(8 + q);
+          dbg_q[q] = now;
+          trace_n++;
+        }
+      } else if (LAT && tracing) {
+        trace_n += 3;
+      }
+#endif
+    }
+
+    // ---- shade the hit, then unwind: deliver radiance up the stack / scatter the next child, until
+    //      this lane has a ray that needs a query (mode 1) or its sample is complete (mode 0 / 2 / 3) ----
+    const bool work = prim || scat;
+    if (work) {
+      if (TILED)
+        srays++;
+      else
+        nrays++;
+      shade(hit, best_t);
+      mode = 1;
+    }
+    bool unwinding = work;
+    while (unwinding) {
+      if (spawn) {
+        // scatter_ray consumes its draws even when the child is beyond max_depth
+        if (INL)
+          ray = scatter_ray<true>(f_brdf, pcg, f_in, f_wp, f_n);
+        else
+          scatter_ray_call(f_brdf, &pcg, &f_in, &f_wp, &f_n, &ray);
+        spawn = false;
+        if (sp > D) {  // render.py:100-101: the child returns black without a world query
+          ret.x = 0.0;
+          ret.y = 0.0;
+          ret.z = 0.0;
+          continue;
+        }
+        break;  // mode 1: queried at the next S-step
+      }
+      if (sp == 0) {
+        finish_sample();  // mode 0 (next sample), 2 (pixel done) or 3 (TILED: wait for the round's end)
+        break;
+      }
+      // a child of frame sp-1 returned `ret` (render.py:135-137)
+      const int fs = sp - 1;
+      const V3 hc = {ws_get<LDSF>(w, fs, 0), ws_get<LDSF>(w, fs, 1), ws_get<LDSF>(w, fs, 2)};
+      V3 fc = {0.0, 0.0, 0.0};
+      int done = 0;
+      if (N > 1) {
+        fc.x = ws_get<LDSF>(w, fs, 6);
+        fc.y = ws_get<LDSF>(w, fs, 7);
+        fc.z = ws_get<LDSF>(w, fs, 8);
+        done = (int)ws_get<LDSF>(w, fs, 9);
+      }
+      fc.x = fc.x + hc.x * ret.x;
+      fc.y = fc.y + hc.y * ret.y;
+      fc.z = fc.z + hc.z * ret.z;
+      done++;
+      if (done < N) {
+        ws_put<LDSF>(w, fs, 6, fc.x);
+        ws_put<LDSF>(w, fs, 7, fc.y);
+        ws_put<LDSF>(w, fs, 8, fc.z);
+        ws_put<LDSF>(w, fs, 9, (double)done);
+        f_wp = {ws_get<LDSF>(w, fs, 10), ws_get<LDSF>(w, fs, 11), ws_get<LDSF>(w, fs, 12)};
+        f_n = {ws_get<LDSF>(w, fs, 13), ws_get<LDSF>(w, fs, 14), ws_get<LDSF>(w, fs, 15)};
+        f_in = {ws_get<LDSF>(w, fs, 16), ws_get<LDSF>(w, fs, 17), ws_get<LDSF>(w, fs, 18)};
+        f_brdf = (int)ws_get<LDSF>(w, fs, 19);
+        spawn = true;
+        continue;
+      }
+      // render.py:139
+      ret.x = ws_get<LDSF>(w, fs, 3) + fc.x * invN;
+      ret.y = ws_get<LDSF>(w, fs, 4) + fc.y * invN;
+      ret.z = ws_get<LDSF>(w, fs, 5) + fc.z * invN;
+      sp = fs;
+    }
+    PT_STAMP(5);
+  }
+#ifdef PT_DEBUG_TIME
+  if ((threadIdx.x & 63) == 0)
+    for (int q = 0; q < 8; ++q) atomicAdd(pt_queue(a) + 1 + q, tsum[q]);
+  pt_dbg_flush();
+#endif
+  add_ray_count(a, nrays);
+}
+
+// every pixel of the frame, pixels from one queue (orthogonal camera): throughput matters
+template <bool LDSF>
+__global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAVES_PATH, 8))) void pt_path_kernel(const PtKArgs a) {
+  path_trace<false, LDSF, false>(a);
+}
+// second pass behind pt_tile_kernel<PATHTRACER> (perspective camera): the flagged pixels, by region
+#ifndef PT_WAVES_REGIONS
+#define PT_WAVES_REGIONS 2
+#endif
+template <bool LDSF, bool SLDS = false, int LEAN = 0>
+__global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAVES_REGIONS, 8))) void pt_path_regions_kernel(const PtKArgs a) {
+  path_trace<true, LDSF, true, SLDS, LEAN>(a);
+}

@@ -1,0 +1,488 @@
+// pt_tree.h -- PathTracer with num_of_rays > 1: one pixel per wave (pt_path_tree_kernel).
+// A part of pt_kernels.h (which includes the parts in order: each relies on the ones before it); not a header of its own.
+// ---- PathTracer with num_of_rays > 1 (second pass behind pt_tile_kernel<PATHTRACER>): ONE pixel per wave, a node's children on lanes --
+// render.py:126-139 runs the N children of a hit one after the other, each with its whole subtree, all drawing from one
+// generator: where child k starts in the stream is known only when child k-1 has returned.  path_trace gives such a
+// pixel one lane, which walks the tree ray by ray: up to sum N^d dependent steps (1 111 for the CLI's N = 10, D = 3)
+// while a frame's worst pixel sets the launch time (profiles/r03_units_n10_before.log: 8.3 ms, 1 111 iterations).
+// Here a wave owns a pixel and works on one NODE at a time (explicit stack of nodes, depth first, so the order of
+// draws is the reference's): the node's next children are scattered and traced AT THE SAME TIME on different lanes, each
+// from a SPECULATED generator state, and then committed in child order by comparing states -- child k counts iff the
+// state it started from is the state child k-1 ended with, in which case everything it computed is what the sequential
+// program computes; the first child that started elsewhere (and everything behind it) is simply done again in the next
+// round from the right state.  Child 0 always starts right, so a round commits at least one child.
+//   * A child that needs children of its own (hit, lum > 0, survived roulette, depth < D) is committed by pushing its
+//     node; its later siblings wait for the state its subtree leaves behind.
+//   * Ordinary families speculate a chain: child r starts r * cpred draws ahead, cpred = what the last committed child
+//     without a subtree drew (initially: its scatter draws, plus the roulette draw where depth >= rr).
+//   * LEAF families (children at depth D: traced, but THEIR children are beyond max_depth and only consume draws,
+//     render.py:100-101) have few outcomes: c0 draws (hit and killed, black or specular surface) or c0 + 2N (a diffuse hit
+//     that survives).  So child r is traced for EVERY start state it can have, r * c0 + b * 2N for b = 0..r: 55 lanes
+//     settle ten leaves in one round whatever mix of outcomes they have.  (A miss draws c0 - 1: the chain then breaks
+//     there and resumes next round -- slower, never wrong.)
+// The sum a node keeps (cum_radiance += hit_color * child, render.py:137) is formed in child order, so the frame is
+// the sequential one bit for bit; rays are counted for committed children only.
+// LDS: per wave max(D, 1) node records of PT_TREE_FRAME doubles; of the innermost node hit_color, the running sum, the child
+// counter and the BRDF kind are also kept in registers (wave-uniform).
+#define PT_TREE_FRAME 20  // hc 0..2, em 3..5, cum 6..8, wp 9..11, n 12..14, in 15..17, brdf 18, next child 19
+PT_DEV double rl_f64(double v, int lane) {  // v_readlane of a double (lane wave-uniform)
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, lane);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), lane);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | (unsigned long long)lo);
+}
+PT_DEV unsigned long long rl_u64(unsigned long long u, int lane) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, lane);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), lane);
+  return ((unsigned long long)hi << 32) | (unsigned long long)lo;
+}
+PT_DEV V3 rl_v3(V3 v, int lane) {
+  V3 r = {rl_f64(v.x, lane), rl_f64(v.y, lane), rl_f64(v.z, lane)};
+  return r;
+}
+
+template <bool SMALL>
+PT_DEV void path_tree(const PtKArgs &a) {
+  int S, nsamp, N, W, rows_local, npass, D, rr, diag_lds, pcg_mode, frames_lds;
+  bool ortho;
+  {
+    pt_kargs c = cold_args(a);
+    ortho = c->cam_kind != PT_CAMERA_PERSPECTIVE;
+    diag_lds = c->diag_lds;
+    pcg_mode = c->pcg_mode;
+    S = c->S;
+    N = c->N;
+    W = c->W;
+    rows_local = c->rows_local;
+    npass = c->npass;
+    D = c->D;
+    rr = c->rr;
+    frames_lds = 4 * c->npass + (int)(threadIdx.x >> 6) * (c->D > 1 ? c->D : 1) * PT_TREE_FRAME;  // (doubles)
+  }
+  if (blockIdx.x == gridDim.x - 1) {  // the next frame's queue block (nothing of this frame reads it)
+    unsigned long long *qn = pt_queue_next(a);
+    for (int k = threadIdx.x; k < PT_QUEUE_WORDS; k += PT_BLOCK) qn[k] = 0ULL;
+  }
+  if (diag_lds >= 0) {  // scale+translate records into LDS: world_query_lanes fetches them by lane-private index
+    const unsigned long long *src = (const unsigned long long *)a.diag;
+    for (int k = threadIdx.x; k < a.n_diag * 8; k += PT_BLOCK) pt_lds_masks[diag_lds + k] = src[k];
+    __syncthreads();
+  }
+  {  // the grid's occupancy bits into LDS: the cell walk of world_query_lanes reads one per step
+    pt_kargs c = cold_args(a);
+    const int occ_lds = c->grid_occ_lds;
+    if (occ_lds >= 0) {
+      const int nwords = (c->grid_res[0] * c->grid_res[1] * c->grid_res[2] + 31) / 32;
+      unsigned *dst = (unsigned *)pt_lds_masks;
+      for (int k = threadIdx.x; k < nwords; k += PT_BLOCK) dst[occ_lds + k] = c->grid_occ[k];
+      __syncthreads();
+    }
+  }
+  nsamp = S > 0 ? S * S : 1;
+  const double invN = 1.0 / (double)N;
+  const int lane = threadIdx.x & 63;
+  const int mbase = (threadIdx.x >> 6) * npass;
+  const int regions_x = (W + PT_REGION - 1) / PT_REGION;
+  const int n_units = (int)pt_queue(a)[9];
+  bool first_unit = true;
+  unsigned long long nrays = 0;  // (wave-uniform: committed rays of this wave's pixels)
+  // small worlds: the wave-uniform loop over every shape (records through the scalar cache) has a shorter critical
+  // path than per-lane candidate lists -- and a round's latency, not its throughput, is what a pixel's tree waits for
+  const bool uniform_loop = a.n_shapes <= cold_args(a)->tree_uniform_max;
+  const bool fuse_on = cold_args(a)->tree_fuse != 0;
+  int b_last = N / 2;  // survivors of the last complete leaf family (wave-uniform): where the next one's guesses are centred
+  // lane r of a leaf round: row = child offset in the round, col = hypothesis b (0..row); rows with row(row+1)/2 + row < 64
+  int tri_row = 0;
+  while ((tri_row + 1) * (tri_row + 2) / 2 <= lane) ++tri_row;
+  const int tri_col = lane - tri_row * (tri_row + 1) / 2;
+  int tri_rows = 0;  // rows that fit the wave: 10
+  while ((tri_rows + 1) * (tri_rows + 2) / 2 <= 64) ++tri_rows;
+
+  // node records live in LDS (frame d = the node at depth d of the current path through the tree); a wave's DS
+  // operations execute in order, so a record written by one lane is what every lane reads afterwards
+  auto frame = [&](int d) -> double * { return pt_lds_f64 + frames_lds + d * PT_TREE_FRAME; };
+  auto rfl_f64 = [&](double v) -> double { return rl_f64(v, 0); };  // (a broadcast LDS read, made scalar)
+
+  // what a lane found out about the ray it traced (render.py:103-139 up to the recursion)
+  bool o_term = true;            // the call returns without children of its own
+  V3 o_ret = {0.0, 0.0, 0.0};    // ... this value
+  V3 o_hc = {0.0, 0.0, 0.0}, o_em = {0.0, 0.0, 0.0}, o_wp = {0.0, 0.0, 0.0}, o_n = {0.0, 0.0, 1.0};  // else: its node
+  int o_brdf = 0;
+  Pcg pcg;
+  pcg.state = 0;
+  pcg.inc = 1;
+  pcg.n = 0;
+  Ray ray;
+  ray.o = {0.0, 0.0, 0.0};
+  ray.d = {1.0, 0.0, 0.0};
+  ray.tmin = 1e-5;
+  auto shade_ray = [&](int hit, double best_t, int depth) {
+    o_term = true;
+    if (hit < 0) {  // render.py:103-105
+      pt_kargs c = cold_args(a);
+      o_ret = {c->bg[0], c->bg[1], c->bg[2]};
+      return;
+    }
+    const PtShapeRec *rec = a.recs + hit;
+    const PtShapeAux *ax = cold_args(a)->aux + hit;
+    Hit h;
+    h.u = 0.0;
+    h.v = 0.0;
+    bool details = false;
+    if (ax->needs_uv != 0) {
+      hit_details<true>(rec, ax, ray, best_t, h, true);
+      details = true;
+    }
+    V3 hc = brdf_pigment(a, ax, h.u, h.v);
+    const V3 em = emitted_pigment(a, ax, h.u, h.v);
+    const double lum = max2(max2(hc.x, hc.y), hc.z);
+    if (depth >= rr) {  // render.py:116-123
+      const double q = max2(0.05, 1.0 - lum);
+      if (pcg_float(pcg) > q) {
+        const double k = 1.0 / (1.0 - q);
+        hc.x = hc.x * k;
+        hc.y = hc.y * k;
+        hc.z = hc.z * k;
+      } else {
+        o_ret = em;
+        return;
+      }
+    }
+    if (!(lum > 0.0)) {  // render.py:139 with cum_radiance = 0
+      o_ret = {em.x + 0.0 * invN, em.y + 0.0 * invN, em.z + 0.0 * invN};
+      return;
+    }
+    if (depth + 1 > D) {  // every child is beyond max_depth: its scatter draws are consumed, it returns black (render.py:100-101)
+      const bool diffuse = ax->brdf_kind == PT_BRDF_DIFFUSE;
+      V3 fc = {0.0, 0.0, 0.0};
+      for (int i = 0; i < N; ++i) {
+        if (diffuse) {
+          pcg_next(pcg);
+          pcg_next(pcg);
+        }
+        fc.x = fc.x + hc.x * 0.0;
+        fc.y = fc.y + hc.y * 0.0;
+        fc.z = fc.z + hc.z * 0.0;
+      }
+      o_ret = {em.x + fc.x * invN, em.y + fc.y * invN, em.z + fc.z * invN};
+      return;
+    }
+    if (!details) hit_details<true>(rec, ax, ray, best_t, h, false);
+    o_term = false;
+    o_hc = hc;
+    o_em = em;
+    o_wp = h.wp;
+    o_n = h.n;
+    o_brdf = ax->brdf_kind;
+  };
+
+#ifdef PT_DEBUG_TIME
+  // cycles of this wave in: 0 fetch + cull, 1 primary ray, 2 state jump + scatter, 3 scattered-ray query, 4 shade,
+  // 5 commit, 6 node returns; 7: rounds
+  unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
+  unsigned long long dbg_leaf_rounds = 0, dbg_committed = 0, dbg_traced = 0, dbg_max_rounds = 0, dbg_fused = 0, dbg_fused_hit = 0;
+#define PT_TT(k) do { const unsigned long long tn = __builtin_amdgcn_s_memtime(); tsum[k] += tn - tprev; tprev = tn; } while (0)
+#else
+#define PT_TT(k) do { } while (0)
+#endif
+  for (;;) {
+    // ---- next pixel: the unit list, one pixel per unit (see path_trace for the sharded heads) ----
+    unsigned uid = 0;
+    const unsigned nsh = gridDim.x < PT_UNIT_SHARDS ? gridDim.x : PT_UNIT_SHARDS;
+    const unsigned shard = blockIdx.x % nsh;
+    if (first_unit) {
+      uid = (blockIdx.x / nsh) * (PT_BLOCK / 64) + (threadIdx.x >> 6);
+      first_unit = false;
+    } else {
+      const unsigned pullers = (gridDim.x - shard + nsh - 1) / nsh * (PT_BLOCK / 64);
+      if (lane == 0) uid = pullers + (unsigned)atomicAdd(pt_queue(a) + PT_QUEUE_HEADS + 32 * shard, 1ULL);
+    }
+    uid = uid * nsh + shard;
+    const int seq = (int)__builtin_amdgcn_readfirstlane((int)uid);
+    if (seq >= n_units) break;
+    pt_kargs ca = cold_args(a);
+    const int4 unit = ca->units[seq];
+    const int region = __builtin_amdgcn_readfirstlane(unit.x), first = __builtin_amdgcn_readfirstlane(unit.y) & 0xff;
+    const unsigned long long todo = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(unit.z) |
+                                    ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(unit.w) << 32);
+    const int ry = region / regions_x, rx = region - ry * regions_x;
+    {  // the region's cone and survivor masks, for the primary rays
+      const int gr0 = global_row(a, ry * PT_REGION);
+      const int gr1 = global_row(a, (ry * PT_REGION + PT_REGION - 1 < rows_local) ? ry * PT_REGION + PT_REGION - 1 : rows_local - 1);
+      const TileCone tc = tile_cone(a, rx * PT_REGION, (rx * PT_REGION + PT_REGION < W) ? rx * PT_REGION + PT_REGION : W, gr0, gr1);
+      __builtin_amdgcn_wave_barrier();
+      for (int p = 0; p < npass; ++p) {
+        const int slot = p * 64 + lane;
+        bool keep = false;
+        if (slot < a.n_shapes) keep = slot >= a.n_spheres || cone_keeps(tc, a.bounds[slot]);  // planes: always
+        const unsigned long long m = __ballot(keep);
+        if (lane == 0) pt_lds_masks[mbase + p] = m;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    const int bit = nth_set_bit(todo, first);
+    const long long pix = (long long)(ry * PT_REGION + (bit >> 3)) * W + (rx * PT_REGION + (bit & 7));
+    int col, grow;
+    pixel_coords(a, pix, col, grow);
+    const unsigned long long gpix = (unsigned long long)grow * ca->W + col;
+    // the pixel's generator (PT_PCG_PIXEL) -- wave-uniform: `gstate` is the state the sequential program is in
+    unsigned long long gstate = 0, ginc = 1;
+    if (pcg_mode != PT_PCG_SAMPLE) {
+      Pcg g;
+      pcg_seed(g, ca->s0, ca->q0 + gpix);
+      gstate = g.state;
+      ginc = g.inc;
+    }
+    V3 cum_pix = {0.0, 0.0, 0.0};
+    unsigned long long prays = 0;
+#ifdef PT_DEBUG_TIME
+    unsigned long long dbg_rounds_pix = 0;
+#endif
+    PT_TT(0);
+    for (int samp = 0; samp < nsamp; ++samp) {
+      if (pcg_mode == PT_PCG_SAMPLE) {
+        Pcg g;
+        pcg_seed(g, ca->s0, ca->q0 + gpix * (unsigned)nsamp + (unsigned)samp);
+        gstate = g.state;
+        ginc = g.inc;
+      }
+      // ---- the sample's primary ray (imagetracer.py:86-97): lane 0 ----
+      pcg.state = gstate;
+      pcg.inc = ginc;
+      pcg.n = 0;
+      double up = 0.5, vp = 0.5;
+      if (S > 0) {
+        const int sr = samp / S, sc = samp - sr * S;
+        up = ((double)sc + pcg_float(pcg)) / (double)S;
+        vp = ((double)sr + pcg_float(pcg)) / (double)S;
+      }
+      ray = primary_ray(a, col, grow, up, vp);
+      {
+        double tp = INFINITY;
+        // (an orthogonal camera's rays have no common origin: nothing is hoisted)
+        const int hp = ortho ? world_query_tile<false, false, false>(a, ray, mbase, npass, tp, lane == 0)
+                             : world_query_tile<false, false, true>(a, ray, mbase, npass, tp, lane == 0);
+        shade_ray(hp, tp, 0);
+      }
+      prays += 1ULL;
+      PT_TT(1);
+      V3 sample_ret = rl_v3(o_ret, 0);
+      gstate = rl_u64(pcg.state, 0);
+      int sp = 0;  // nodes on the stack; the innermost one (frame sp - 1) is the node whose children are being traced
+      // of that node, in registers (wave-uniform): hit_color, the sum of its children so far, how many are done, its BRDF
+      V3 t_hc = {0.0, 0.0, 0.0}, t_cum = {0.0, 0.0, 0.0};
+      int t_next = 0, t_brdf = 0;
+      unsigned cpred = 0;
+      // lane `src` traced a ray that needs children of its own: its node becomes frame sp (written by that lane itself)
+      auto push_node = [&](int src, V3 in_dir) {
+        if (sp > 0 && lane == 0) {  // the parent's running sum and child counter wait in its record
+          double *f = frame(sp - 1);
+          f[6] = t_cum.x; f[7] = t_cum.y; f[8] = t_cum.z;
+          f[19] = (double)t_next;
+        }
+        if (lane == src) {
+          double *f = frame(sp);
+          f[0] = o_hc.x; f[1] = o_hc.y; f[2] = o_hc.z; f[3] = o_em.x; f[4] = o_em.y; f[5] = o_em.z;
+          f[6] = 0.0; f[7] = 0.0; f[8] = 0.0; f[9] = o_wp.x; f[10] = o_wp.y; f[11] = o_wp.z;
+          f[12] = o_n.x; f[13] = o_n.y; f[14] = o_n.z; f[15] = in_dir.x; f[16] = in_dir.y; f[17] = in_dir.z;
+          f[18] = (double)o_brdf; f[19] = 0.0;
+        }
+        // (the record is read by every lane later on: the compiler may neither move those loads above this store nor
+        //  feed them from this lane's registers)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        t_hc = rl_v3(o_hc, src);
+        t_cum = {0.0, 0.0, 0.0};
+        t_next = 0;
+        t_brdf = __builtin_amdgcn_readlane(o_brdf, src);
+        sp++;
+      };
+      // render.py:139 for the innermost node, then render.py:137 in its parent, which becomes the innermost one
+      auto pop_node = [&]() -> V3 {
+        const double *f = frame(sp - 1);
+        const V3 val = {rfl_f64(f[3]) + t_cum.x * invN, rfl_f64(f[4]) + t_cum.y * invN, rfl_f64(f[5]) + t_cum.z * invN};
+        sp--;
+        if (sp > 0) {
+          const double *g = frame(sp - 1);
+          t_hc = {rfl_f64(g[0]), rfl_f64(g[1]), rfl_f64(g[2])};
+          t_cum = {rfl_f64(g[6]), rfl_f64(g[7]), rfl_f64(g[8])};
+          t_brdf = (int)rfl_f64(g[18]);
+          t_next = (int)rfl_f64(g[19]);
+          t_cum.x = t_cum.x + t_hc.x * val.x;
+          t_cum.y = t_cum.y + t_hc.y * val.y;
+          t_cum.z = t_cum.z + t_hc.z * val.z;
+        }
+        return val;
+      };
+      auto base_draws = [&]() -> unsigned {  // what a child of the innermost node draws when it needs no children: scatter + roulette
+        return (t_brdf == PT_BRDF_DIFFUSE ? 2u : 0u) + (sp >= rr ? 1u : 0u);
+      };
+      if (!__builtin_amdgcn_readfirstlane((int)o_term)) {
+        push_node(0, ray.d);
+        cpred = base_draws();
+      }
+      // ---- the tree under the primary hit ----
+      while (sp > 0) {
+        const int remaining = N - t_next;
+        if (remaining <= 0) {
+          const V3 val = pop_node();
+          if (sp == 0) {
+            sample_ret = val;
+            break;
+          }
+          cpred = base_draws();
+          PT_TT(6);
+          continue;
+        }
+        // ---- a round: children t_next .. of this node, depth sp, each from a speculated state ----
+        const unsigned c0 = base_draws();
+        const bool leaf = sp == D;  // (children of the children are beyond max_depth)
+        int row, nrows;
+        unsigned ahead;
+        if (leaf) {
+          nrows = remaining < tri_rows ? remaining : tri_rows;
+          row = tri_row;
+          ahead = (unsigned)tri_row * c0 + (unsigned)tri_col * 2u * (unsigned)N;
+        } else {
+          nrows = remaining < 64 ? remaining : 64;
+          row = lane;
+          ahead = (unsigned)lane * cpred;
+        }
+        bool act = row < nrows;
+        // A WHOLE leaf family leaves lanes over (ten leaves: 55 of 64).  Where the family ends is known up to the number
+        // b of its members that survive roulette on a diffuse surface -- N * c0 + 2N * b draws -- so the spare lanes
+        // trace the NEXT sibling of this node (a child of its parent, one level up) from those states in the same round:
+        // when the family commits in full and b is among the guesses, the sibling's ray is already traced when the node
+        // returns, and a parent whose children all branch costs one round per child instead of two.
+        const int leaf_lanes = nrows * (nrows + 1) / 2;
+        bool fused = leaf && sp >= 2 && t_next == 0 && nrows == N && leaf_lanes < 64 && fuse_on;
+        if (fused) fused = (int)rfl_f64(frame(sp - 2)[19]) < N;
+        // (the spare lanes cover nh consecutive values of b around what the last complete family had)
+        const int nh = (64 - leaf_lanes) < (N + 1) ? (64 - leaf_lanes) : (N + 1);
+        int bmin = b_last - nh / 2;
+        bmin = bmin < 0 ? 0 : (bmin > N + 1 - nh ? N + 1 - nh : bmin);
+        const bool sib = fused && lane >= leaf_lanes && lane - leaf_lanes < nh;  // hypothesis b = bmin + lane - leaf_lanes
+        if (sib) {
+          act = true;
+          row = -1;
+          ahead = (unsigned)N * c0 + 2u * (unsigned)N * (unsigned)(bmin + lane - leaf_lanes);
+        }
+        // (what the last round found out is dead: said explicitly, so that it holds no registers across the query)
+        o_term = true;
+        o_ret = o_hc = o_em = o_wp = {0.0, 0.0, 0.0};
+        o_n = {0.0, 0.0, 1.0};
+        o_brdf = 0;
+        pcg.state = act ? pcg_advance(gstate, ginc, ahead) : gstate;
+        pcg.inc = ginc;
+        pcg.n = 0;
+        const unsigned long long st_start = pcg.state;
+        {
+          const double *f = frame(sib ? sp - 2 : sp - 1);  // the node the ray leaves from
+          const V3 n_wp = {f[9], f[10], f[11]}, n_n = {f[12], f[13], f[14]}, n_in = {f[15], f[16], f[17]};
+          ray = scatter_ray<true>((int)f[18], pcg, n_in, n_wp, n_n);  // materials.py:132-152, 175-196
+        }
+        PT_TT(2);
+        double ts = INFINITY;
+        int hs;
+        if (uniform_loop)
+          hs = world_query<false, false>(a, ray, INFINITY, ts, act);
+        else
+          hs = world_query_lanes<false, SMALL ? 1 : 0>(a, ray, INFINITY, ts, act, diag_lds);
+        PT_TT(3);
+        if (act) shade_ray(hs, ts, sib ? sp - 1 : sp);
+        PT_TT(4);
+#ifdef PT_DEBUG_TIME
+        tsum[7] += 1;
+        dbg_rounds_pix += 1;
+        if (leaf) dbg_leaf_rounds += 1;
+        dbg_traced += (unsigned long long)__popcll(__ballot(act));
+#endif
+        // ---- commit in child order ----
+        unsigned long long expect = gstate;
+        bool pushed = false;
+        unsigned fam_draws = 0;
+        // child `src` of the innermost node counts: add its value up, or put its node on the stack
+        auto commit_child = [&](int src) {
+          prays += 1ULL;
+          t_next++;
+          expect = rl_u64(pcg.state, src);
+          if (__builtin_amdgcn_readlane((int)o_term, src)) {
+            const V3 val = rl_v3(o_ret, src);
+            t_cum.x = t_cum.x + t_hc.x * val.x;  // render.py:137
+            t_cum.y = t_cum.y + t_hc.y * val.y;
+            t_cum.z = t_cum.z + t_hc.z * val.z;
+            cpred = (unsigned)__builtin_amdgcn_readlane((int)pcg.n, src);
+            fam_draws += cpred;
+          } else {  // the child has children of its own: its node goes on the stack, the siblings wait
+            push_node(src, ray.d);
+            pushed = true;
+          }
+        };
+        for (int r = 0; r < nrows && !pushed; ++r) {
+          const unsigned long long m = __ballot(act && row == r && st_start == expect);
+          if (!m) break;  // nobody traced child r from the right state: next round
+          commit_child(__ffsll((long long)m) - 1);
+        }
+        if (leaf && t_next == N && nrows == N && fam_draws >= (unsigned)N * c0)
+          b_last = (int)((fam_draws - (unsigned)N * c0) / (2u * (unsigned)N));
+#ifdef PT_DEBUG_TIME
+        if (fused) dbg_fused += 1;
+#endif
+        if (fused && t_next == N) {
+          // the leaf family is complete: its node returns now, and its parent's next child may be there already
+          (void)pop_node();
+          cpred = base_draws();
+          const unsigned long long m = __ballot(sib && st_start == expect);
+          if (m) commit_child(__ffsll((long long)m) - 1);
+#ifdef PT_DEBUG_TIME
+          if (m) dbg_fused_hit += 1;
+#endif
+        }
+        gstate = expect;
+        if (pushed) cpred = base_draws();
+        PT_TT(5);
+      }
+      // imagetracer.py:94-97
+      if (S > 0) {
+        cum_pix.x = cum_pix.x + sample_ret.x;
+        cum_pix.y = cum_pix.y + sample_ret.y;
+        cum_pix.z = cum_pix.z + sample_ret.z;
+      } else {
+        cum_pix = sample_ret;
+      }
+    }
+    if (S > 0) {  // imagetracer.py:99-101
+      const double k = 1.0 / (double)(S * S);
+      cum_pix.x = cum_pix.x * k;
+      cum_pix.y = cum_pix.y * k;
+      cum_pix.z = cum_pix.z * k;
+    }
+    if (lane == 0) store_pixel(a, pix, cum_pix);
+    nrays += prays;
+#ifdef PT_DEBUG_TIME
+    dbg_committed += prays;
+    if (dbg_rounds_pix > dbg_max_rounds) dbg_max_rounds = dbg_rounds_pix;
+#endif
+  }
+#ifdef PT_DEBUG_TIME
+  if (lane == 0) {
+    for (int q = 0; q < 8; ++q) atomicAdd(pt_queue(a) + 1 + q, tsum[q]);
+    atomicAdd(pt_queue(a) + 12, dbg_leaf_rounds | (dbg_fused << 24) | (dbg_fused_hit << 44));
+    atomicAdd(pt_queue(a) + 13, dbg_committed);
+    atomicAdd(pt_queue(a) + 14, dbg_traced);
+    atomicMax(pt_queue(a) + 15, dbg_max_rounds);
+  }
+#endif
+  add_ray_count(a, lane == 0 ? nrays : 0ULL);
+}
+
+#ifndef PT_TREE_WAVES
+#define PT_TREE_WAVES 2
+#endif
+template <bool SMALL = false>
+__global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_TREE_WAVES, 8))) void pt_path_tree_kernel(const PtKArgs a) {
+  path_tree<SMALL>(a);
+}

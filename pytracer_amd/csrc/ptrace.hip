@@ -46,7 +46,7 @@ static int fail(int code, const char *fmt, ...) {
 
 // A ball of the scattered-ray filter as the kernels want it: r'^2 / (1 - 8e-6) rounded up; where there is no usable bound
 // (r' not finite or >= 1e17, a centre that is not finite or beyond 1e17) the centre 0 and r'^2 = 1e38, which the filter's
-// arithmetic never rejects and never overflows on (pt_kernels.h: world_query_lanes).
+// arithmetic never rejects and never overflows on (pt_query.h: world_query_lanes).
 static void pt_ball_square(float *x, float *y, float *z, float *r, bool *ordinary) {
   const bool ok = std::isfinite(*r) && *r >= 0.0f && *r < 1e17f && std::isfinite(*x) && std::isfinite(*y) && std::isfinite(*z) &&
                   std::fabs(*x) < 1e17f && std::fabs(*y) < 1e17f && std::fabs(*z) < 1e17f;
@@ -1078,7 +1078,7 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
     return PT_OK;
   }
   if (p->renderer == PT_RENDERER_PATHTRACER) {
-    // the queue block (head, unit counts, F; pt_kernels.h: pt_unit_scatter) starts every frame zeroed: by the path
+    // the queue block (head, unit counts, F; pt_path.h: pt_unit_scatter) starts every frame zeroed: by the path
     // kernel of the frame before (it clears the OTHER block), by a memset after anything went wrong in between
     a.qpar = s->queue_parity;
     s->queue_last = s->queue + (size_t)a.qpar * PT_QUEUE_WORDS;

@@ -13,7 +13,7 @@ PART 2 -- whole frames: spheres at tangency +- a few ulp of rays that run ON the
 boundary of a tile / strip / cell / pixel cone (perspective camera) or of a tile's beam (orthogonal camera).
 
 Every conservative cull of the kernels (`cone_keeps`, `pixel_cone`, the strip and cell pre-passes, the beam of an
-orthogonal camera; pt_kernels.h) works in fp32 with hand-derived slack.  Random scenes exercise the slack only
+orthogonal camera; csrc/pt_tile.h) works in fp32 with hand-derived slack.  Random scenes exercise the slack only
 statistically; here the geometry is built to sit on it:
 
 * the per-pixel random streams are searched (vectorised PCG, numpy) for a seed whose FIRST jitter number of a
