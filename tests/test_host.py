@@ -156,3 +156,15 @@ def test_fill_image_into_reference_style_hdrimage():
     _fill_image(img, arr)
     assert all(isinstance(c, RefColor) for c in img.pixels)
     assert (img.pixels[4].r, img.pixels[4].g, img.pixels[4].b) == (12.0, 13.0, 14.0)  # (x=1, y=1) -> 1*3+1
+
+
+def test_sparse_shard_sizes_agree_between_library_and_python():
+    """pt_image_sparse_fixed_bytes (no device needed) against pytracer_amd.dist.sparse_fixed_bytes: the two sides of the
+    gather must agree on what the fixed-size message weighs."""
+    from pytracer_amd import _lib, abi, dist as ptdist
+
+    L = _lib.lib()
+    for npx in (1, 2, 127, 128, 129, 255, 256, 257, 3840 * 270, 3840 * 1080, 10 ** 7 + 3):
+        assert L.pt_image_sparse_fixed_bytes(npx, abi.OUT_F32) == ptdist.sparse_fixed_bytes(npx, 4)
+        assert L.pt_image_sparse_fixed_bytes(npx, abi.OUT_F64) == ptdist.sparse_fixed_bytes(npx, 8)
+    assert L.pt_image_sparse_fixed_bytes(0, abi.OUT_F32) == -1 and L.pt_image_sparse_fixed_bytes(10, 7) == -1
