@@ -579,7 +579,8 @@ class SceneGroup:
     switches go to all of them, counters and times are summed, `stats()` is the first handle's last frame."""
 
     def __init__(self, flat, n, device):
-        self.scenes = [DeviceScene(flat, device=device) for _ in range(max(1, n))]
+        first = DeviceScene(flat, device=device)
+        self.scenes = [first] + [first.clone() for _ in range(max(1, n) - 1)]
 
     def set_count_rays(self, on):
         for d in self.scenes:

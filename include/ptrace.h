@@ -160,6 +160,13 @@ int pt_device_count(void);
 int pt_device_info(int device, int *compute_units, int *clock_khz);
 /* Copy the flattened scene to the HBM of `device` (packed into the kernel's record layout). */
 int pt_scene_upload(const pt_scene_desc *desc, int device, pt_scene **out);
+/* A further handle on an uploaded scene, for frames IN FLIGHT (the reference renders an animation one frame per process;
+ * here consecutive frames are independent launches, and a small frame leaves most of the chip idle): the new handle
+ * shares the tables pt_scene_upload made -- nothing is uploaded again -- and has its own per-camera constants, queues,
+ * counters and workspace.  One call at a time per HANDLE; frames rendered through different handles of a scene may run
+ * concurrently, each on its own stream (pt_render_device).  Free every handle with pt_scene_free, in any order: the
+ * last one frees the shared tables. */
+int pt_scene_clone(pt_scene *scene, pt_scene **out);
 void pt_scene_free(pt_scene *scene);
 /* Number of image rows rank `p->rank` owns under p's partition. */
 int pt_rows_for_rank(const pt_params *p);

@@ -11,7 +11,7 @@ _LIB_PATH = os.environ.get("PTRACE_LIB") or os.path.join(os.path.dirname(os.path
 _lib = None
 
 # every symbol include/ptrace.h declares
-EXPORTS = ("pt_device_count", "pt_scene_upload", "pt_scene_free", "pt_rows_for_rank", "pt_output_bytes",
+EXPORTS = ("pt_device_count", "pt_scene_upload", "pt_scene_clone", "pt_scene_free", "pt_rows_for_rank", "pt_output_bytes",
            "pt_render", "pt_render_device", "pt_get_stats", "pt_set_count_rays", "pt_sync", "pt_last_error",
            "pt_version", "pt_profile_begin", "pt_profile_end", "pt_set_timing", "pt_image_pack_pfm",
            "pt_image_average_luminosity", "pt_image_tonemap", "pt_host_alloc", "pt_host_free", "pt_set_dome_shortcut", "pt_device_info",
@@ -76,6 +76,8 @@ def lib():
         L.pt_device_info.argtypes = [C.c_int, P(C.c_int), P(C.c_int)]
         L.pt_scene_upload.restype = C.c_int
         L.pt_scene_upload.argtypes = [P(abi.SceneDesc), C.c_int, P(C.c_void_p)]
+        L.pt_scene_clone.restype = C.c_int
+        L.pt_scene_clone.argtypes = [C.c_void_p, P(C.c_void_p)]
         L.pt_scene_free.restype = None
         L.pt_scene_free.argtypes = [C.c_void_p]
         L.pt_rows_for_rank.restype = C.c_int

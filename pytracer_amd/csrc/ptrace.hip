@@ -7,6 +7,7 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -136,6 +137,9 @@ struct pt_scene {
   hipStream_t hoist_stream = nullptr;  // the stream the constants were produced on
   int n_cu = 256;
   pt_stats stats = {};
+  // handles made by pt_scene_clone share the scene's tables (everything pt_scene_upload wrote and no launch changes);
+  // the last handle of the family to be freed frees them
+  std::atomic<int> *family = nullptr;
 };
 
 extern "C" int pt_version(void) { return PT_VERSION; }
@@ -219,21 +223,27 @@ extern "C" void pt_scene_free(pt_scene *s) {
   if (!s) return;
   (void)hipSetDevice(s->device);
   if (s->stream) (void)hipStreamSynchronize(s->stream);
-  (void)hipFree(s->recs);
-  (void)hipFree(s->aux);
+  if (s->launched && s->last_stream) (void)hipStreamSynchronize(s->last_stream);
+  // the tables the family shares: freed by its last handle (a scene that was never cloned is a family of one)
+  const bool last = !s->family || s->family->fetch_sub(1) == 1;
+  if (last) {
+    (void)hipFree(s->recs);
+    (void)hipFree(s->aux);
+    (void)hipFree(s->diag);
+    (void)hipFree(s->bounds);
+    (void)hipFree(s->bsoa);
+    (void)hipFree(s->grid_cells);
+    (void)hipFree(s->grid_occ);
+    (void)hipFree(s->grid_balls);
+    (void)hipFree(s->grid_slots);
+    (void)hipFree(s->grid_always);
+    (void)hipFree(s->lights);
+    (void)hipFree(s->tex);
+    (void)hipFree(s->tex_data);
+    delete s->family;
+  }
   (void)hipFree(s->hoist);
-  (void)hipFree(s->diag);
   (void)hipFree(s->hoist_diag);
-  (void)hipFree(s->bounds);
-  (void)hipFree(s->bsoa);
-  (void)hipFree(s->grid_cells);
-  (void)hipFree(s->grid_occ);
-  (void)hipFree(s->grid_balls);
-  (void)hipFree(s->grid_slots);
-  (void)hipFree(s->grid_always);
-  (void)hipFree(s->lights);
-  (void)hipFree(s->tex);
-  (void)hipFree(s->tex_data);
   (void)hipFree(s->ws);
   (void)hipFree(s->out_dev);
   (void)hipFree(s->ray_counter);
@@ -260,6 +270,29 @@ static int upload(T **dst, const std::vector<T> &src) {
   const size_t bytes = std::max<size_t>(src.size(), 1) * sizeof(T);
   HIP_TRY(hipMalloc((void **)dst, bytes));
   if (!src.empty()) HIP_TRY(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+  return PT_OK;
+}
+
+// what every handle has of its own besides the per-camera constants: counters, queue blocks, the argument block, a stream
+// and events.  On failure the handle is freed.
+static int handle_state(pt_scene *s) {
+  auto hip_or_free = [&](hipError_t e, const char *what) -> int {
+    if (e == hipSuccess) return PT_OK;
+    int code = fail(PT_ERR_HIP, "%s failed: %s", what, hipGetErrorString(e));
+    pt_scene_free(s);
+    return code;
+  };
+  int rc;
+  if ((rc = hip_or_free(hipMalloc((void **)&s->ray_counter, 2 * sizeof(unsigned long long)), "hipMalloc(counter)"))) return rc;
+  if ((rc = hip_or_free(hipMalloc((void **)&s->queue, 2 * PT_QUEUE_WORDS * sizeof(unsigned long long)), "hipMalloc(queue)"))) return rc;
+  if ((rc = hip_or_free(hipMalloc((void **)&s->args_dev, sizeof(PtKArgs)), "hipMalloc(args)"))) return rc;
+  if ((rc = hip_or_free(hipHostMalloc((void **)&s->ray_counter_host, 2 * sizeof(unsigned long long)), "hipHostMalloc"))) return rc;
+  s->ray_counter_host[0] = s->ray_counter_host[1] = 0;
+  if ((rc = hip_or_free(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking), "hipStreamCreate"))) return rc;
+  if ((rc = hip_or_free(hipEventCreate(&s->ev0), "hipEventCreate"))) return rc;
+  if ((rc = hip_or_free(hipEventCreate(&s->ev1), "hipEventCreate"))) return rc;
+  if ((rc = hip_or_free(hipEventCreate(&s->ev2), "hipEventCreate"))) return rc;
+  if ((rc = hip_or_free(hipEventCreateWithFlags(&s->ev_count, hipEventDisableTiming), "hipEventCreate"))) return rc;
   return PT_OK;
 }
 
@@ -738,24 +771,49 @@ extern "C" int pt_scene_upload(const pt_scene_desc *d, int device, pt_scene **ou
     UP(upload(&s->hoist, h));
   }
 #undef UP
-  auto hip_or_free = [&](hipError_t e, const char *what) -> int {
-    if (e == hipSuccess) return PT_OK;
-    int code = fail(PT_ERR_HIP, "%s failed: %s", what, hipGetErrorString(e));
-    pt_scene_free(s);
-    return code;
-  };
-  if ((rc = hip_or_free(hipMalloc((void **)&s->ray_counter, 2 * sizeof(unsigned long long)), "hipMalloc(counter)"))) return rc;
-  if ((rc = hip_or_free(hipMalloc((void **)&s->queue, 2 * PT_QUEUE_WORDS * sizeof(unsigned long long)), "hipMalloc(queue)"))) return rc;
-  if ((rc = hip_or_free(hipMalloc((void **)&s->args_dev, sizeof(PtKArgs)), "hipMalloc(args)"))) return rc;
-  if ((rc = hip_or_free(hipHostMalloc((void **)&s->ray_counter_host, 2 * sizeof(unsigned long long)), "hipHostMalloc"))) return rc;
-  s->ray_counter_host[0] = s->ray_counter_host[1] = 0;
-  if ((rc = hip_or_free(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking), "hipStreamCreate"))) return rc;
-  if ((rc = hip_or_free(hipEventCreate(&s->ev0), "hipEventCreate"))) return rc;
-  if ((rc = hip_or_free(hipEventCreate(&s->ev1), "hipEventCreate"))) return rc;
-  if ((rc = hip_or_free(hipEventCreate(&s->ev2), "hipEventCreate"))) return rc;
-  if ((rc = hip_or_free(hipEventCreateWithFlags(&s->ev_count, hipEventDisableTiming), "hipEventCreate"))) return rc;
+  if ((rc = handle_state(s))) return rc;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) s->n_cu = prop.multiProcessorCount;
+  s->family = new std::atomic<int>(1);
+  *out = s;
+  return PT_OK;
+}
+
+// A second handle on the same scene: it shares the tables pt_scene_upload made (nothing a launch writes) and has its
+// own per-camera constants, queues, counters, workspace, stream and events -- so frames rendered through different
+// handles of a family may be in flight at the same time, each on its own stream (include/ptrace.h).
+extern "C" int pt_scene_clone(pt_scene *src, pt_scene **out) {
+  if (!src || !out) return fail(PT_ERR_INVALID, "null argument");
+  *out = nullptr;
+  HIP_TRY(hipSetDevice(src->device));
+  pt_scene *s = new pt_scene();
+  // what describes the scene
+  s->device = src->device;
+  s->n_shapes = src->n_shapes; s->n_spheres = src->n_spheres; s->n_lights = src->n_lights; s->n_textures = src->n_textures;
+  s->recs = src->recs; s->aux = src->aux; s->diag = src->diag; s->bounds = src->bounds;
+  s->grid_cells = src->grid_cells; s->grid_occ = src->grid_occ; s->grid_balls = src->grid_balls; s->grid_slots = src->grid_slots;
+  s->grid_always = src->grid_always; s->grid_n_always = src->grid_n_always; s->grid_n_cells = src->grid_n_cells;
+  s->grid_far_eo = src->grid_far_eo;
+  for (int q = 0; q < 3; ++q) {
+    s->grid_res[q] = src->grid_res[q]; s->grid_min[q] = src->grid_min[q]; s->grid_max[q] = src->grid_max[q];
+    s->grid_cell[q] = src->grid_cell[q]; s->grid_inv[q] = src->grid_inv[q]; s->bs_rmax[q] = src->bs_rmax[q];
+  }
+  s->bsoa = src->bsoa; s->bs_stride = src->bs_stride; s->gs_stride = src->gs_stride; s->cs_stride = src->cs_stride;
+  s->bs_levels = src->bs_levels; s->n_diag = src->n_diag;
+  s->lights = src->lights; s->tex = src->tex; s->tex_data = src->tex_data;
+  s->dome_cands = src->dome_cands;
+  s->n_cu = src->n_cu;
+  s->count_rays = src->count_rays; s->dome_shortcut = src->dome_shortcut; s->timing = src->timing;
+  s->family = src->family;
+  s->family->fetch_add(1);
+  // what is this handle's own
+  int rc = PT_OK;
+  const size_t nh = (size_t)std::max(s->n_shapes, 1), nd = (size_t)std::max(s->n_diag, 1);
+  if (hipMalloc((void **)&s->hoist, nh * sizeof(PtHoist)) != hipSuccess || hipMalloc((void **)&s->hoist_diag, nd * sizeof(PtHoistDiag)) != hipSuccess) {
+    pt_scene_free(s);
+    return fail(PT_ERR_NOMEM, "hipMalloc(per-camera constants) failed");
+  }
+  if ((rc = handle_state(s))) return rc;
   *out = s;
   return PT_OK;
 }

@@ -78,6 +78,17 @@ class DeviceScene:
         d = scene.desc()
         _lib.check(_lib.lib().pt_scene_upload(C.byref(d), int(device), C.byref(self._h)))
 
+    def clone(self) -> "DeviceScene":
+        """A further handle on the same scene (``pt_scene_clone``): shares the uploaded tables, has its own per-camera
+        constants, queues and workspace -- so that frames rendered through different handles may be in flight at once,
+        each on its own stream (``pytracer_amd.pipeline.FramePipeline``)."""
+        other = DeviceScene.__new__(DeviceScene)
+        other._h = C.c_void_p()
+        other.flat = self.flat
+        other.device = self.device
+        _lib.check(_lib.lib().pt_scene_clone(self._h, C.byref(other._h)))
+        return other
+
     def close(self) -> None:
         if getattr(self, "_h", None) is not None and self._h.value:
             _lib.lib().pt_scene_free(self._h)

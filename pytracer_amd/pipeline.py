@@ -3,9 +3,9 @@
 The reference renders an animation as one process per frame (``main.py:76-214`` called once per camera angle); here a
 frame is one kernel launch of ~10 us whose waves are bound by dependent fp64 latency, and a launch has a fixed cost of
 ~2-3 us (dispatch, ramp, drain: ``tools/micro/ramp.hip``) that nothing inside the frame can hide.  Consecutive frames
-are independent, so the next frame can: ``FramePipeline`` keeps ``n_in_flight`` scene handles (each with its own
-per-camera tables and counters: one handle must not render two frames at once) and as many HIP streams, and frame ``i``
-goes to slot ``i % n_in_flight``.  The frames are bit-identical to the ones a single stream renders.
+are independent, so the next frame can: ``FramePipeline`` keeps ``n_in_flight`` handles on ONE uploaded scene
+(``pt_scene_clone``: each with its own per-camera tables, queues and counters -- one handle must not render two frames at
+once) and as many HIP streams, and frame ``i`` goes to slot ``i % n_in_flight``.  The frames are bit-identical to the ones a single stream renders.
 """
 from typing import List, Optional
 
@@ -20,7 +20,8 @@ class FramePipeline:
         if n_in_flight < 1:
             raise ValueError("n_in_flight must be >= 1")
         self.device = torch.device("cuda", device)
-        self.scenes: List[DeviceScene] = [DeviceScene(flat, device=device) for _ in range(n_in_flight)]
+        first = DeviceScene(flat, device=device)  # uploaded once; the other slots are further handles on the same tables
+        self.scenes: List[DeviceScene] = [first] + [first.clone() for _ in range(n_in_flight - 1)]
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(n_in_flight)]
         self._busy: List[Optional[torch.Tensor]] = [None] * n_in_flight  # keeps a slot's output alive while it renders
         self._next = 0

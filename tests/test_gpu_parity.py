@@ -1160,3 +1160,31 @@ def test_frames_in_flight_are_the_frames_of_one_stream(dev):
                 ref = ds.render(cam, abi.copy_params(par, out_format=abi.OUT_F64)).astype(np.float32)
                 assert np.array_equal(outs[k].cpu().numpy().view(np.uint32), ref.view(np.uint32)), (renderer, k)
         assert not np.array_equal(outs[0].cpu().numpy(), outs[5].cpu().numpy())
+
+
+def test_cloned_handles_share_the_scene_and_outlive_the_first(dev):
+    """pt_scene_clone: further handles on one uploaded scene (own per-camera constants and queues, shared tables) render
+    the frames the first handle renders, for a world with a grid and cell lists as well, and keep working after the
+    handle they were cloned from has been freed (the last handle of the family frees the tables)."""
+    from pytracer_amd import flatten, hostmodel as hm, scenes
+
+    for n_spheres, W, H in ((32, 320, 176), (1500, 160, 96)):
+        flat = flatten.flatten_world(scenes.synthetic_world(n_spheres, with_plane=n_spheres < 100, wide=n_spheres > 100))
+        cams = [flatten.flatten_camera(hm.PerspectiveCamera(1.0, W / H, hm.rotation_z(9.0 * k) * hm.translation(hm.Vec(-1.0, 0.0, 1.0))))
+                for k in range(3)]
+        pars = [abi.make_params(W, H, abi.RENDERER_FLAT),
+                abi.make_params(W, H, abi.RENDERER_PATHTRACER, samples_per_side=2, num_of_rays=1, max_depth=3, rr_limit=2,
+                                path_state=45, path_seq=54)]
+        first = dev.DeviceScene(flat)
+        ref = [[first.render(cam, par) for cam in cams] for par in pars]
+        clones = [first.clone(), first.clone()]
+        grand = clones[0].clone()  # (a clone of a clone is a handle like the others)
+        first.close()
+        for h in clones + [grand]:
+            for pi, par in enumerate(pars):
+                for ci in (2, 0, 1):  # (another camera order than the first handle's: the per-camera constants are the handle's own)
+                    out = h.render(cams[ci], par)
+                    assert util.bits_equal(out, ref[pi][ci]), (n_spheres, pi, ci)
+            assert h.stats().n_rays > 0
+        for h in (clones[1], grand, clones[0]):
+            h.close()
