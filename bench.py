@@ -182,6 +182,35 @@ def kernel_row(ds, cam, par, out, reps, flat):
             "algorithmic_equivalent_TFLOP_s": st.n_rays * (n_sph * FLOP_PER_SPHERE_TEST + n_pl * FLOP_PER_PLANE_TEST) / t / 1e12}
 
 
+def in_flight_row(ds, cam, par, out, frames):
+    """The same frames with TWO in flight: a second handle on the uploaded scene (pt_scene_clone) and a stream each, frames
+    dealt alternately; wall clock between two device synchronisations -> ms per frame (a frame RATE: one frame still
+    takes what ms_per_frame says).  Checked: both handles' frames are the frame `out` holds."""
+    other = ds.clone()
+    outs = [out, torch.empty_like(out)]
+    handles, streams = [ds, other], [torch.cuda.Stream(), torch.cuda.Stream()]
+    nbytes = out.numel() * out.element_size()
+    for h in handles:
+        h.set_count_rays(False)
+        h.set_timing(False)
+    try:
+        for i in range(4):
+            handles[i & 1].render_into(cam, par, outs[i & 1].data_ptr(), nbytes, streams[i & 1].cuda_stream)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(frames):
+            handles[i & 1].render_into(cam, par, outs[i & 1].data_ptr(), nbytes, streams[i & 1].cuda_stream)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        same = bool(torch.equal(outs[0], outs[1]))
+    finally:
+        ds.set_count_rays(True)
+        ds.set_timing(True)
+        other.close()
+    return {"ms_per_frame": dt / frames * 1e3, "frames": frames, "frames_identical": same,
+            "note": "a frame rate (wall clock / frames), two frames in flight on two handles of the scene"}
+
+
 def extra_rows(device: int):
     """Secondary rows (not the headline): the other configurations of BASELINE.json on one GPU, kernel time from
     the library's events, median of a few frames.  The path-traced ones in both per-thread PCG modes."""
@@ -221,6 +250,7 @@ def extra_rows(device: int):
         par = abi.make_params(W, H, out_format=abi.OUT_F32, **kw)
         out = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")  # (a rank's share uses the top of it)
         rows[name] = kernel_row(ds, cam_for(W, H), par, out, reps, flat)
+        rows[name]["two_frames_in_flight"] = in_flight_row(ds, cam_for(W, H), par, out, 40 if W * H > 2_000_000 else 120)
     for ds_old in scene_cache.values():
         ds_old[1].close()
     # the path tracer's second pass on C3: executed VALU instructions (PMC medians committed under profiles/) against
