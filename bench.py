@@ -257,7 +257,8 @@ def extra_rows(device: int):
     # the SIMD-cycles of its launch -- the same fraction as roofline.frac, for the kernel VERDICT r1 named
     n_cu, clock_khz = device_info(device)
     for tag, fname in (("C3_pathtracer_1280x720_32sph_D3_spp16_N1", "pmc_c3_second_pass.json"),
-                       ("C3_same_PT_PCG_SAMPLE", "pmc_c3_second_pass_sample.json")):
+                       ("C3_same_PT_PCG_SAMPLE", "pmc_c3_second_pass_sample.json"),
+                       ("C4_same_PT_PCG_SAMPLE", "pmc_c4_second_pass_sample.json")):
         pmc = load_profile(fname)
         if pmc is not None and tag in rows:
             valu, dur = pmc["counters"]["SQ_INSTS_VALU"], pmc["dur_us"] * 1e-6
