@@ -1,0 +1,89 @@
+"""LazyPixels — what ``GpuImageTracer`` installs as ``image.pixels`` of a reference-style ``HdrImage``.
+
+The reference's ``HdrImage`` keeps a Python list of ``width * height`` ``Color`` objects (hdrimages.py:70) and reaches
+them through ``self.pixels[i]`` only: ``get_pixel`` / ``set_pixel`` (hdrimages.py:78-94), ``for pix in self.pixels`` and
+``len(self.pixels)`` in ``average_luminosity`` (:120-128), ``self.pixels[i] = self.pixels[i] * k`` in ``normalize_image``
+(:130-140) and ``self.pixels[i].r = ...`` in ``clamp_image`` (:142-147).  Building that list eagerly costs 0.49 s for a
+1280x720 frame whose kernel takes 0.014 ms (VERDICT r3 missing #4); most callers then read a handful of pixels or hand
+the image to ``write_pfm``.
+
+So the frame stays a numpy ``[H*W, 3]`` fp64 array and a ``Color`` is made when an index is first read.  The object is
+kept from then on: ``pixels[i]`` returns the SAME object every time, as a list would, so that ``pixels[i].r = x``
+(``clamp_image``) is not lost.  Assignment replaces the object.  Slices, ``pixels[:] = colors``, iteration, ``len``,
+``==`` against a list, ``reversed``, ``index`` / ``count`` (through ``collections.abc.Sequence``) behave like the list's.
+``as_array()`` gives the frame back as ``[H*W, 3]`` fp64 including whatever was assigned or mutated since.
+"""
+from __future__ import annotations
+
+from collections.abc import Sequence
+
+import numpy as np
+
+
+class LazyPixels(Sequence):
+    __slots__ = ("_arr", "_made", "color_cls")
+
+    def __init__(self, arr: np.ndarray, color_cls):
+        a = np.asarray(arr, dtype=np.float64)
+        self._arr = a.reshape(-1, 3)   # (a view: the caller hands the frame over)
+        self._made = {}                # index -> the Color handed out / assigned for it
+        self.color_cls = color_cls
+
+    def __len__(self) -> int:
+        return self._arr.shape[0]
+
+    def _index(self, i) -> int:
+        n = self._arr.shape[0]
+        j = i.__index__()
+        if j < 0:
+            j += n
+        if not 0 <= j < n:
+            raise IndexError("list index out of range")
+        return j
+
+    def _get(self, j: int):
+        c = self._made.get(j)
+        if c is None:
+            r, g, b = self._arr[j].tolist()
+            c = self._made[j] = self.color_cls(r, g, b)
+        return c
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self._get(j) for j in range(*i.indices(self._arr.shape[0]))]
+        return self._get(self._index(i))
+
+    def __setitem__(self, i, value) -> None:
+        if isinstance(i, slice):
+            idx = range(*i.indices(self._arr.shape[0]))
+            vals = list(value)
+            if len(vals) != len(idx):
+                raise ValueError("LazyPixels keeps its length: a slice can only be assigned as many colours as it holds")
+            for j, v in zip(idx, vals):
+                self._made[j] = v
+            return
+        self._made[self._index(i)] = value
+
+    def __iter__(self):
+        get = self._get
+        for j in range(self._arr.shape[0]):
+            yield get(j)
+
+    def __eq__(self, other):
+        if isinstance(other, (list, tuple, LazyPixels)):
+            return len(other) == len(self) and all(a == b for a, b in zip(self, other))
+        return NotImplemented
+
+    __hash__ = None
+
+    def __repr__(self) -> str:
+        return f"LazyPixels({self._arr.shape[0]} pixels, {len(self._made)} materialised)"
+
+    def as_array(self) -> np.ndarray:
+        """``[H*W, 3]`` fp64 with every assignment and mutation applied (a copy when there were any)."""
+        if not self._made:
+            return self._arr
+        out = self._arr.copy()
+        idx = np.fromiter(self._made.keys(), dtype=np.int64, count=len(self._made))
+        out[idx] = np.array([(c.r, c.g, c.b) for c in self._made.values()], dtype=np.float64).reshape(-1, 3)
+        return out

@@ -1,0 +1,187 @@
+"""GPU parity at BASELINE.json's FULL frame sizes: the HIP path through the C-ABI against the
+CPU oracle on the very frames `bench.py` times -- C2 (Flat and OnOff), C3 in both per-thread PCG modes, C5, a quarter-size
+C4 and a full-width band of the real 3840x2160 C4 frame -- and the path tracer with more samples per pixel than a wave
+has lanes (S = 9, 10, 16; imagetracer.py:80-104 loops over S x S strata whatever S is).
+
+The oracle runs on the box's host cores (OpenMP rows): C2 20 ms, C3 about a second, C5 and the C4 frames a few seconds.
+Bars as everywhere (BASELINE.json north_star): bit-exact where no libm transcendental is involved, else <= 1e-5 relative
+per channel with the outlier pixels counted (a last-ulp sin/cos difference can flip a silhouette or roulette decision after
+a bounce: SURVEY.md H3), and ray counts equal up to those flips.
+"""
+import numpy as np
+import pytest
+
+from pytracer_amd import abi
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    from pytracer_amd import device
+
+    assert device.device_count() >= 1, "no HIP device visible"
+    return device
+
+
+def _synthetic(n_spheres, with_plane, wide, w, h):
+    from pytracer_amd import flatten, scenes
+
+    world = scenes.synthetic_world(n_spheres, with_plane=with_plane, wide=wide)
+    return flatten.flatten_world(world), flatten.flatten_camera(scenes.synthetic_camera(w, h))
+
+
+def _oracle(oracle, scene, cam, par):
+    ora, n = oracle.render(scene, cam, par, sqr_mode=oracle.SQR_MUL)
+    oracle.set_sqr_mode(oracle.SQR_POW)
+    return ora, n
+
+
+def _path_check(tag, out, ora, n_dev, n_ora, max_outliers, pixels):
+    err = util.rel_err(out, ora)
+    bad = int((err > TOL).any(axis=-1).sum())
+    exact = int((np.ascontiguousarray(out, dtype=np.float64).view(np.uint64) ==
+                 np.ascontiguousarray(ora, dtype=np.float64).view(np.uint64)).all(axis=-1).sum())
+    print(f"{tag}: max rel {err.max():.3e}, outliers {bad}/{pixels}, bit-identical pixels {exact}/{pixels}, rays {n_dev} vs {n_ora}")
+    assert bad <= max_outliers, f"{tag}: {bad} pixels beyond {TOL}"
+    assert abs(int(n_dev) - int(n_ora)) <= max(8, n_ora // 100000), f"{tag}: rays {n_dev} vs {n_ora}"
+
+
+@pytest.mark.parametrize("renderer", [abi.RENDERER_FLAT, abi.RENDERER_ONOFF])
+@pytest.mark.parametrize("fmt", [abi.OUT_F64, abi.OUT_F32])
+def test_c2_full_frame_bit_exact_vs_oracle(dev, oracle, renderer, fmt):
+    """C2 as bench.py times it: 1280x720, 32 spheres + the checkered plane, pixel-centre rays; fp64 and the fp32 output
+    of the headline; with the dome shortcut on and off (bench.py's `dome_off` row)."""
+    W, H = 1280, 720
+    scene, cam = _synthetic(32, True, False, W, H)
+    par = abi.make_params(W, H, renderer, out_format=fmt)
+    ora, n = _oracle(oracle, scene, cam, par)
+    with dev.DeviceScene(scene) as ds:
+        for dome in (True, False):
+            ds.set_dome_shortcut(dome)
+            out = ds.render(cam, par)
+            st = ds.stats()
+            assert out.dtype == ora.dtype and out.tobytes() == ora.tobytes(), f"dome shortcut {dome}: device != oracle"
+            assert int(st.n_rays) == n == W * H
+            assert st.kernel == abi.KERNEL_TILE4 or __import__("os").environ.get("PTRACE_TILE4", "1") == "0"
+
+
+@pytest.mark.parametrize("mode", [abi.PCG_PIXEL, abi.PCG_SAMPLE])
+def test_c3_full_frame_vs_oracle(dev, oracle, mode):
+    """C3 as specified: 1280x720, 32 spheres, PathTracer N=1 D=3 rr=3, S=4 (spp 16), per-thread PCG in both alignments."""
+    W, H = 1280, 720
+    scene, cam = _synthetic(32, False, False, W, H)
+    par = abi.make_params(W, H, abi.RENDERER_PATHTRACER, samples_per_side=4, num_of_rays=1, max_depth=3, rr_limit=3,
+                          pcg_mode=mode, path_state=45, path_seq=54)
+    with dev.DeviceScene(scene) as ds:
+        out = ds.render(cam, par)
+        st = ds.stats()
+    ora, n = _oracle(oracle, scene, cam, par)
+    _path_check(f"C3 {W}x{H} mode={mode}", out, ora, st.n_rays, n, 6, W * H)
+    assert n >= W * H * 16
+
+
+def test_c3_cli_defaults_full_frame_vs_oracle(dev, oracle):
+    """The CLI's defaults (main.py:95-102: N=10, D=3, one jittered sample) on the C3 scene at 1280x720."""
+    W, H = 1280, 720
+    scene, cam = _synthetic(32, False, False, W, H)
+    par = abi.make_params(W, H, abi.RENDERER_PATHTRACER, samples_per_side=1, num_of_rays=10, max_depth=3, rr_limit=3,
+                          path_state=45, path_seq=54)
+    with dev.DeviceScene(scene) as ds:
+        out = ds.render(cam, par)
+        st = ds.stats()
+    ora, n = _oracle(oracle, scene, cam, par)
+    _path_check(f"C3 N=10 {W}x{H}", out, ora, st.n_rays, n, 6, W * H)
+
+
+def test_c5_full_frame_bit_exact_vs_oracle(dev, oracle):
+    """C5 as specified: 1280x720 over 10 000 spheres, Flat (9.2e9 ray-shape tests for the oracle: seconds on the box)."""
+    W, H = 1280, 720
+    scene, cam = _synthetic(10000, False, True, W, H)
+    par = abi.make_params(W, H, abi.RENDERER_FLAT, out_format=abi.OUT_F32)
+    with dev.DeviceScene(scene) as ds:
+        out = ds.render(cam, par)
+        st = ds.stats()
+    ora, n = _oracle(oracle, scene, cam, par)
+    assert out.tobytes() == ora.tobytes()
+    assert int(st.n_rays) == n == W * H
+
+
+@pytest.mark.parametrize("mode", [abi.PCG_PIXEL, abi.PCG_SAMPLE])
+def test_c4_quarter_frame_vs_oracle(dev, oracle, mode):
+    """C4's scene and renderer (256 wide spheres, N=1 D=5 rr=3, spp 64) at 960x540."""
+    W, H = 960, 540
+    scene, cam = _synthetic(256, False, True, W, H)
+    par = abi.make_params(W, H, abi.RENDERER_PATHTRACER, samples_per_side=8, num_of_rays=1, max_depth=5, rr_limit=3,
+                          pcg_mode=mode, path_state=45, path_seq=54, out_format=abi.OUT_F32)
+    with dev.DeviceScene(scene) as ds:
+        out = ds.render(cam, par)
+        st = ds.stats()
+    ora, n = _oracle(oracle, scene, cam, par)
+    _path_check(f"C4 {W}x{H} mode={mode}", out, ora, st.n_rays, n, 6, W * H)
+
+
+@pytest.mark.parametrize("mode", [abi.PCG_PIXEL, abi.PCG_SAMPLE])
+def test_c4_full_width_band_of_the_real_frame_vs_oracle(dev, oracle, mode):
+    """The REAL C4 frame (3840x2160, spp 64): the 128 rows [1024, 1152) -- where the spheres are -- as rank 8 of a
+    16-rank partition in 128-row blocks, device against oracle."""
+    W, H = 3840, 2160
+    scene, cam = _synthetic(256, False, True, W, H)
+    par = abi.make_params(W, H, abi.RENDERER_PATHTRACER, samples_per_side=8, num_of_rays=1, max_depth=5, rr_limit=3,
+                          pcg_mode=mode, path_state=45, path_seq=54, out_format=abi.OUT_F32, n_ranks=16, rank=8, row_block=128)
+    with dev.DeviceScene(scene) as ds:
+        out = ds.render(cam, par)
+        st = ds.stats()
+    assert out.shape == (128, W, 3)
+    ora, n = _oracle(oracle, scene, cam, par)
+    _path_check(f"C4 band 128x{W} mode={mode}", out, ora, st.n_rays, n, 6, 128 * W)
+
+
+@pytest.mark.parametrize("S", [9, 10, 16])
+@pytest.mark.parametrize("mode", [abi.PCG_PIXEL, abi.PCG_SAMPLE])
+@pytest.mark.parametrize("n_rays", [1, 3])
+def test_pathtracer_with_more_samples_than_lanes(dev, oracle, S, mode, n_rays):
+    """samples_per_side 9, 10, 16 (81, 100, 256 samples per pixel: more than the 64 lanes a pixel's samples are spread
+    over), N = 1 (pt_path_regions_kernel) and N = 3 (pt_path_tree_kernel), both PCG alignments."""
+    W, H = 48, 27
+    scene, cam = _synthetic(32, False, False, W, H)
+    par = abi.make_params(W, H, abi.RENDERER_PATHTRACER, samples_per_side=S, num_of_rays=n_rays, max_depth=3, rr_limit=2,
+                          pcg_mode=mode, path_state=45, path_seq=54)
+    with dev.DeviceScene(scene) as ds:
+        out = ds.render(cam, par)
+        st = ds.stats()
+        # ... and the same frame as three ranks' shards (per-pixel / per-sample seeds: the same bits)
+        got = np.zeros_like(out)
+        for rank in range(3):
+            p = abi.copy_params(par, n_ranks=3, rank=rank, row_block=4)
+            got[abi.rows_for_rank(H, 4, 3, rank)] = ds.render(cam, p)
+    ora, n = _oracle(oracle, scene, cam, par)
+    _path_check(f"S={S} mode={mode} N={n_rays}", out, ora, st.n_rays, n, 3, W * H)
+    assert util.bits_equal(got, out)
+
+
+@pytest.mark.parametrize("renderer", [abi.RENDERER_FLAT, abi.RENDERER_ONOFF, abi.RENDERER_POINTLIGHT])
+def test_jittered_primary_renderers_with_more_samples_than_lanes(dev, oracle, renderer):
+    """S = 9 and 12 for the renderers without a scattering stream (the jitter alone draws), both alignments."""
+    from pytracer_amd import flatten, hostmodel as hm, scenes
+
+    W, H = 64, 36
+    world = scenes.synthetic_world(32, with_plane=True)
+    world.add_light(hm.PointLight(hm.Vec(-3.0, 6.0, 8.0), hm.Color(1.0, 0.9, 0.8), 0.0))
+    scene = flatten.flatten_world(world)
+    cam = flatten.flatten_camera(scenes.synthetic_camera(W, H))
+    for S in (9, 12):
+        for mode in (abi.PCG_PIXEL, abi.PCG_SAMPLE):
+            par = abi.make_params(W, H, renderer, samples_per_side=S, pcg_mode=mode, path_state=45, path_seq=54)
+            with dev.DeviceScene(scene) as ds:
+                out = ds.render(cam, par)
+                st = ds.stats()
+            ora, n = _oracle(oracle, scene, cam, par)
+            if renderer == abi.RENDERER_POINTLIGHT:  # (specular BRDF eval: acos)
+                assert util.rel_err(out, ora).max() <= TOL
+            else:
+                assert util.bits_equal(out, ora), (S, mode)
+            assert int(st.n_rays) == n
