@@ -41,8 +41,13 @@ extern "C" {
 #define PT_RENDERER_POINTLIGHT 3 /* render.py:142 */
 
 /* PCG stream assignment ("seed alignment").
- * SEQ    : the reference's two global sequential streams (jitter + scattering), row-major
- *          pixel order.  Inherently serial: accepted by the CPU oracle only.
+ * SEQ    : the reference's own two global sequential streams (ImageTracer.pcg for the jitter, imagetracer.py:84-101;
+ *          PathTracer.pcg for the scattering, render.py:118,128), row-major pixel order.  For OnOff / Flat / PointLight
+ *          only the jitter stream exists and every sample draws exactly two numbers from it, so sample k of pixel i
+ *          starts 2 (i S^2 + k) draws into PCG(jitter_state, jitter_seq): the device enters the stream there by
+ *          jump-ahead and renders the frame the reference's `ImageTracer(pcg=PCG(jitter_state, jitter_seq))` renders,
+ *          bit for bit.  With the path tracer the scattering stream is serial by construction: PT_ERR_UNSUPPORTED on
+ *          the device (the CPU oracle accepts it).
  * PIXEL  : pixel i = row*W+col owns PCG(path_state, path_seq + i) for jitter and scattering,
  *          consumed in program order.  Depends only on the global pixel index.
  * SAMPLE : sample k = sub_row*S+sub_col of pixel i owns PCG(path_state, path_seq + i*S*S + k).
@@ -121,7 +126,7 @@ typedef struct pt_params {
   int32_t max_depth;        /* PathTracer.max_depth (render.py:96)                       */
   int32_t rr_limit;         /* PathTracer.russian_roulette_limit (render.py:97)          */
   int32_t pcg_mode;         /* PT_PCG_*                                                  */
-  uint64_t jitter_state, jitter_seq; /* ImageTracer.pcg seeds (SEQ mode only)            */
+  uint64_t jitter_state, jitter_seq; /* ImageTracer.pcg seeds (SEQ mode only; < 2^63)    */
   uint64_t path_state, path_seq;     /* PathTracer.pcg seeds (SEQ) / S0,Q0 (PIXEL, SAMPLE) */
   /* Pixel partition for multi-GPU: rows are cut in blocks of `row_block` rows, block b belongs
    * to rank b % n_ranks; a rank's output holds its rows compactly in ascending global order.
@@ -249,7 +254,10 @@ int pt_image_sparse_decode_many(int device, int n_shards, const void *const *fix
                                 int row_block, int n_ranks, void *stream);
 /* Copy the last error message of the calling thread (NUL-terminated) into buf; returns its length. */
 int pt_last_error(char *buf, size_t n);
-/* Library/ABI version: (major<<16)|minor. */
+/* Library/ABI version: (major<<16)|minor; this header describes 1.3.  The minor grows whenever a struct here grows or an
+ * entry point is added (1.2: pt_stats gained `kernel` and `_reserved` -- 56 bytes, which pt_get_stats writes in full --,
+ * pt_scene_clone, pt_image_sparse_*; 1.3: PT_PCG_SEQ on the device for OnOff / Flat / PointLight): a caller built
+ * against an older header must check pt_version() before it hands pt_get_stats its smaller struct. */
 int pt_version(void);
 
 #ifdef __cplusplus

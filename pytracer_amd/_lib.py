@@ -23,6 +23,11 @@ DEBUG_EXPORTS = ("pt_debug_probe", "pt_debug_cull_probe", "pt_debug_hit_probe", 
                  "pt_debug_camera_probe", "pt_debug_scatter_probe", "pt_debug_read_queue")
 
 
+# include/ptrace.h: pt_version() = major << 16 | minor; abi.Stats mirrors the 56-byte pt_stats of minor >= 2, the tracer's
+# default alignment needs the PT_PCG_SEQ of minor >= 3
+ABI_MAJOR, ABI_MINOR_NEEDED = 1, 3
+
+
 class PtraceError(RuntimeError):
     def __init__(self, code: int, message: str):
         super().__init__(f"{abi.ERROR_NAMES.get(code, code)}: {message}")
@@ -100,6 +105,10 @@ def lib():
         L.pt_last_error.restype = C.c_int
         L.pt_last_error.argtypes = [C.c_char_p, C.c_size_t]
         L.pt_version.restype = C.c_int
+        ver = int(L.pt_version())
+        if ver >> 16 != ABI_MAJOR or (ver & 0xFFFF) < ABI_MINOR_NEEDED:
+            raise ImportError(f"{_LIB_PATH} implements ABI {ver >> 16}.{ver & 0xFFFF}; this package needs {ABI_MAJOR}.>={ABI_MINOR_NEEDED} "
+                              "(pt_stats layout, PT_PCG_SEQ): rebuild with `python -m pytracer_amd.build --force`")
         L.pt_set_timing.restype = C.c_int
         L.pt_set_timing.argtypes = [C.c_void_p, C.c_int]
         L.pt_profile_begin.restype = C.c_int

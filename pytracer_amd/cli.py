@@ -131,16 +131,23 @@ def cli():
 @click.option("--samples-per-pixel", type=int, default=1, help="Samples per pixel (a perfect square, e.g. 16).")
 @click.option("--declare-float", "-d", type=str, multiple=True, help="Declare a variable: --declare-float=VAR:VALUE")
 @click.option("--device", type=int, default=0, help="GPU to render on")
-@click.option("--pcg-mode", type=click.Choice(["pixel", "sample"]), default="pixel",
-              help="Random streams: one generator per pixel (default: the alignment the reference's CLI frames are pinned "
-                   "in) or one per sample (equally pinned, samples of a pixel independent: several times faster with "
-                   "--samples-per-pixel > 1).")
+@click.option("--pcg-mode", type=click.Choice(["auto", "seq", "pixel", "sample"]), default="auto",
+              help="Random streams.  auto (default): onoff / flat / pointlight draw their jitter from the reference's own "
+                   "sequential stream PCG(42, 54) -- the frame `python -m pytracer render` writes with the same flags, bit "
+                   "for bit -- and pathtracing uses one generator per pixel (its scattering stream is serial in the "
+                   "reference; the per-pixel alignment is what its CLI frames are pinned in).  seq: the reference's stream "
+                   "(refused for pathtracing).  pixel / sample: one generator per pixel / per sample (samples of a pixel "
+                   "independent: several times faster with --samples-per-pixel > 1).")
 @click.option("--host-postprocess", is_flag=True, default=False,
               help="Copy the fp64 frame to the host first and post-process there (the round-2 behaviour; same bytes).")
 @click.argument("input_scene_name", type=str)
 def render(width, height, algorithm, pfm_output, png_output, num_of_rays, max_depth, init_state, init_seq,
            samples_per_pixel, declare_float, device, pcg_mode, host_postprocess, input_scene_name):
     try:
+        if pcg_mode == "seq" and algorithm == "pathtracing":
+            raise UsageError("--pcg-mode seq with --algorithm pathtracing: the reference's scattering stream is one generator "
+                             "consumed in the order the paths of all pixels end in (render.py:118,128) -- serial by "
+                             "construction; use pixel (default) or sample")
         job = plan_render(width, height, algorithm, num_of_rays, max_depth, init_state, init_seq, samples_per_pixel,
                           declare_float, input_scene_name)
     except UsageError as e:

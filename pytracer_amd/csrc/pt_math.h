@@ -36,6 +36,34 @@ PT_DEV uint64_t pcg_advance(uint64_t state, uint64_t inc, unsigned delta) {
   }
   return acc_mul * state + acc_add;
 }
+// ... with a 64-bit distance: where sample k of pixel i starts in ONE sequential stream that every sample draws the same
+// count from (PT_PCG_SEQ: ImageTracer.pcg, two jitter numbers per sample, imagetracer.py:84-101) -- a 4K frame at 256
+// samples per pixel is 4.2e9 draws in.
+PT_DEV uint64_t pcg_advance64(uint64_t state, uint64_t inc, uint64_t delta) {
+  uint64_t acc_mul = 1ULL, acc_add = 0ULL, cur_mul = 6364136223846793005ULL, cur_add = inc;
+  while (delta) {
+    if (delta & 1ULL) {
+      acc_mul *= cur_mul;
+      acc_add = acc_add * cur_mul + cur_add;
+    }
+    cur_add = (cur_mul + 1ULL) * cur_add;
+    cur_mul *= cur_mul;
+    delta >>= 1;
+  }
+  return acc_mul * state + acc_add;
+}
+// The generator of pixel `gpix` before its first sample (S > 0), by alignment (a.s0 / a.q0 are the
+// path seeds, or under PT_PCG_SEQ the jitter seeds): PIXEL -- PCG(S0, Q0 + i); SEQ -- the ONE generator PCG(S0, Q0) of
+// the reference's ImageTracer, 2 * S^2 * i draws in (renderers without a scattering stream: every sample before this
+// pixel drew exactly its two jitter numbers); SAMPLE seeds per sample instead.
+PT_DEV void pcg_seed_pixel(Pcg &p, int pcg_mode, uint64_t s0, uint64_t q0, unsigned long long gpix, int nsamp) {
+  if (pcg_mode == PT_PCG_PIXEL) {
+    pcg_seed(p, s0, q0 + gpix);
+  } else if (pcg_mode == PT_PCG_SEQ) {
+    pcg_seed(p, s0, q0);
+    p.state = pcg_advance64(p.state, p.inc, 2ULL * (unsigned long long)nsamp * gpix);
+  }
+}
 // pcg.py:60-62: random() / 0xFFFFFFFF, an fp64 division (inclusive 1.0)
 PT_DEV double pcg_float(Pcg &p) { return (double)pcg_next(p) / 4294967295.0; }
 

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(PT_BLOCK)
     if (S > 0) {
       pt_kargs c = cold_args(a);
       gpix = (unsigned long long)grow * c->W + col;
-      if (c->pcg_mode == PT_PCG_PIXEL) pcg_seed(pcg, c->s0, c->q0 + gpix);
+      pcg_seed_pixel(pcg, c->pcg_mode, c->s0, c->q0, gpix, nsamp);
     }
     V3 cum = {0.0, 0.0, 0.0};
     for (int s = 0; s < nsamp; ++s) {

@@ -828,7 +828,7 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
     if (S > 0) {
       pt_kargs c = cold_args(a);
       gpix = (unsigned long long)grow * c->W + pcol;
-      if (c->pcg_mode == PT_PCG_PIXEL) pcg_seed(pcg, c->s0, c->q0 + gpix);
+      pcg_seed_pixel(pcg, c->pcg_mode, c->s0, c->q0, gpix, nsamp);
     }
     V3 cum = {0.0, 0.0, 0.0};
     bool alive = active;  // PATHTRACER: still a pixel this pass can finish

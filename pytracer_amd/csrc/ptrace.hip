@@ -25,7 +25,10 @@
 #ifndef PT_TILE4_NPX_SMALL
 #define PT_TILE4_NPX_SMALL 4  // pixels per lane of pt_tile4_kernel on frames with few 16x16 tiles (2: measured slower)
 #endif
-#define PT_VERSION ((1 << 16) | 1)
+// major << 16 | minor.  The minor grows whenever a struct of include/ptrace.h grows or an entry point is added (minor 2:
+// pt_stats gained `kernel` + `_reserved`, pt_scene_clone / pt_image_sparse_* arrived; minor 3: PT_PCG_SEQ accepted for
+// OnOff / Flat / PointLight at any samples_per_side); a caller built against an older header checks pt_version() first.
+#define PT_VERSION ((1 << 16) | 3)
 
 static thread_local char g_err[512] = "";
 
@@ -843,10 +846,18 @@ static int check_params(const pt_scene *s, const pt_camera *cam, const pt_params
     return fail(PT_ERR_INVALID, "unknown output format %d", p->out_format);
   const int nr = p->n_ranks > 0 ? p->n_ranks : 1;
   if (p->rank < 0 || p->rank >= nr) return fail(PT_ERR_INVALID, "rank %d outside [0,%d)", p->rank, nr);
-  if (p->pcg_mode == PT_PCG_SEQ && (p->samples_per_side > 0 || p->renderer == PT_RENDERER_PATHTRACER))
+  // PT_PCG_SEQ, the reference's own streams: the JITTER stream is one sequential generator from which every sample draws
+  // exactly two numbers (imagetracer.py:84-101), so sample k of pixel i starts 2 (i S^2 + k) draws in -- parallel by
+  // jump-ahead, and exact.  The path tracer's SCATTERING stream (render.py:118,128) is consumed in the order the paths of
+  // ALL pixels end in, each taking a number of draws only known once it has been traced: serial by construction.
+  if (p->pcg_mode == PT_PCG_SEQ && p->renderer == PT_RENDERER_PATHTRACER)
     return fail(PT_ERR_UNSUPPORTED,
-                "PT_PCG_SEQ (two global sequential streams) is inherently serial; the device path "
-                "implements PT_PCG_PIXEL and PT_PCG_SAMPLE");
+                "PT_PCG_SEQ with the path tracer: its scattering stream is ONE generator consumed in the order the paths "
+                "of all pixels end in (render.py:118,128), which only a serial program reproduces; the device path "
+                "implements PT_PCG_PIXEL and PT_PCG_SAMPLE for it (PT_PCG_SEQ is exact for OnOff, Flat and PointLight)");
+  if (p->pcg_mode == PT_PCG_SEQ && p->samples_per_side > 0 &&
+      (unsigned long long)p->width * p->height > (~0ULL >> 2) / ((unsigned long long)p->samples_per_side * p->samples_per_side))
+    return fail(PT_ERR_INVALID, "PT_PCG_SEQ: the frame draws more than 2^63 jitter numbers");
   if (p->pcg_mode < PT_PCG_SEQ || p->pcg_mode > PT_PCG_SAMPLE)
     return fail(PT_ERR_INVALID, "unknown pcg_mode %d", p->pcg_mode);
   if (p->renderer == PT_RENDERER_PATHTRACER) {
@@ -957,9 +968,17 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
   a.N = p->num_of_rays;
   a.D = p->max_depth;
   a.rr = p->rr_limit;
-  a.pcg_mode = p->pcg_mode == PT_PCG_SEQ ? PT_PCG_PIXEL : p->pcg_mode;
+  a.pcg_mode = p->pcg_mode;
   a.s0 = p->path_state;
   a.q0 = p->path_seq;
+  if (p->pcg_mode == PT_PCG_SEQ) {  // (OnOff / Flat / PointLight only: check_params)
+    if (p->samples_per_side > 0) {  // the jitter stream of the reference's ImageTracer, entered by jump-ahead per pixel
+      a.s0 = p->jitter_state;
+      a.q0 = p->jitter_seq;
+    } else {
+      a.pcg_mode = PT_PCG_PIXEL;  // pixel-centre rays: no random number is drawn, the alignments coincide
+    }
+  }
   a.row_block = p->row_block > 0 ? p->row_block : 1;
   a.n_ranks = p->n_ranks > 0 ? p->n_ranks : 1;
   a.rank = p->rank;

@@ -66,43 +66,33 @@ _transport = {}  # process group (None = the default one) -> P2P | PADDED, agree
 
 def choose_transport(group=None, force: Optional[str] = None) -> str:
     """Agree, once per process group, on how shards travel: batched point-to-point transfers (one per remote rank),
-    or -- for a backend that refuses those -- one ``gather`` of shards padded to a common size.
+    or -- for a backend without them -- one ``gather`` of shards padded to a common size.
 
-    A collective: EVERY rank of the group must call it (``gather_image`` does, on first use), whether or not it owns
-    rows.  The probe is a one-element send from every rank to the last one's neighbour ring; the ranks' verdicts
-    meet in an all-reduce, so either all ranks use point-to-point transfers or none does.  ``force`` (or the
-    environment variable ``PT_GATHER``) pins the choice without a probe -- it must then be the same on every rank."""
+    Decided from CAPABILITY, not from a trial transfer (a probe that one rank is refused while its neighbours
+    have already posted theirs leaves those waiting for ever): ``nccl`` (= RCCL) and ``gloo`` both implement
+    ``batch_isend_irecv``, anything else takes the padded ``gather``; ``force`` (or the environment variable
+    ``PT_GATHER``) pins the choice.  A collective all the same: EVERY rank of the group calls it (``gather_image`` does,
+    on first use), whether or not it owns rows, and the ranks' choices meet in ONE all-reduce -- if they differ (one rank
+    started with another ``PT_GATHER``) every rank raises instead of entering different collectives later."""
     import os
 
     if group in _transport and force is None:
         return _transport[group]
     force = force or os.environ.get("PT_GATHER")
     if force in (P2P, PADDED):
-        _transport[group] = force
-        return force
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
+        choice = force
+    else:
+        choice = P2P if dist.get_backend(group) in ("nccl", "gloo") else PADDED
     dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
-    ok = 1
-    try:
-        nxt = (rank + 1) % world
-        prv = (rank - 1) % world
-        if group is not None:
-            nxt, prv = dist.get_global_rank(group, nxt), dist.get_global_rank(group, prv)
-        a = torch.full((1,), float(rank), device=dev)
-        b = torch.empty((1,), device=dev)
-        for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, a, nxt, group), dist.P2POp(dist.irecv, b, prv, group)]):
-            req.wait()
-        if dev.type == "cuda":
-            torch.cuda.synchronize()
-        if int(b.item()) != (rank - 1) % world:
-            ok = 0
-    except (RuntimeError, ValueError, NotImplementedError):
-        ok = 0  # refused before anything was sent; the all-reduce below is still entered by this rank
-    flag = torch.tensor([ok], dtype=torch.int32, device=dev)
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-    _transport[group] = P2P if int(flag.item()) == 1 else PADDED
-    return _transport[group]
+    code = 1 if choice == P2P else 0
+    lo = torch.tensor([code], dtype=torch.int32, device=dev)
+    hi = lo.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+    if int(lo.item()) != int(hi.item()):
+        raise RuntimeError("the ranks chose different gather transports (PT_GATHER differs between ranks?)")
+    _transport[group] = choice
+    return choice
 
 
 def gather_plan(height: int, width: int, row_block: int, world: int, itemsize: int = 4, transport: str = P2P) -> dict:
@@ -134,9 +124,46 @@ def place_shard(out: torch.Tensor, shard: torch.Tensor, height: int, row_block: 
         out[g0:g0 + n].copy_(shard[ng * rb: ng * rb + n], non_blocking=True)
 
 
+class PhaseClock:
+    """Wall time per phase of ONE gather, for the bench's per-phase breakdown (``ShardedFrameLoop.phase_probe``): ``mark``
+    drains the device and books the time since the previous mark under a name.  Every mark is a host-device
+    synchronisation, so a clocked gather runs its phases one after the other -- a measurement mode; the frame loops
+    pass no clock and synchronise nowhere."""
+
+    def __init__(self):
+        from time import perf_counter
+
+        self._now = perf_counter
+        self.ms = {}
+        self.restart()
+
+    def restart(self) -> None:
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        self._last = self._now()
+
+    def mark(self, name: str) -> None:
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        t = self._now()
+        self.ms[name] = self.ms.get(name, 0.0) + (t - self._last) * 1e3
+        self._last = t
+
+
+def _mark(clock: Optional["PhaseClock"], name: str) -> None:
+    if clock is not None:
+        clock.mark(name)
+
+
 SPARSE_TILE = 128  # pixels per run (csrc/pt_post.h: PT_SPARSE_RUN)
 last_gather = {}   # on dst, after a gather: {"bytes": what the remote ranks sent for that frame, "sparse": bool}
-_sparse_scratch = {}  # (device, dtype, runs) -> payload buffer at full capacity: reused frame after frame
+_sparse_scratch = {}  # (device, dtype, runs, stream) -> payload buffer at full capacity: reused frame after frame on THAT stream
+
+
+def release_sparse_scratch(stream=None) -> None:
+    """Drop the encoder's payload buffers -- of ``stream`` (a ``torch.cuda.Stream``), or all of them."""
+    for key in [k for k in _sparse_scratch if stream is None or k[3] == stream.cuda_stream]:
+        del _sparse_scratch[key]
 
 
 def sparse_default() -> bool:
@@ -173,7 +200,9 @@ def encode_sparse(shard: torch.Tensor, tile: int = SPARSE_TILE) -> Tuple[torch.T
 
         dev = shard.device
         fixed = torch.empty((sparse_fixed_bytes(npx, shard.element_size()),), dtype=torch.uint8, device=dev)
-        key = (dev, shard.dtype, nt)
+        # one buffer per STREAM: two loops encoding same-sized shards on different streams must not share a payload that
+        # RCCL may still be sending
+        key = (dev, shard.dtype, nt, torch.cuda.current_stream(dev).cuda_stream)
         if key not in _sparse_scratch:
             _sparse_scratch[key] = torch.empty((nt, tile, 3), dtype=shard.dtype, device=dev)
         payload = _sparse_scratch[key]
@@ -272,7 +301,7 @@ def _gather_padded(local, height, row_block, world, rank, group, dst, out):
         dist.gather(shard, None, dst=dst, group=group)
 
 
-def _gather_sparse(local, height, row_block, world, rank, group, dst, out, nrows):
+def _gather_sparse(local, height, row_block, world, rank, group, dst, out, nrows, clock=None):
     """Point-to-point gather of sparse shards: the fixed parts first (sizes known from the partition), then -- once
     ``dst`` has read the counts -- the runs that are not constant."""
     W = local.shape[1]
@@ -291,28 +320,33 @@ def _gather_sparse(local, height, row_block, world, rank, group, dst, out, nrows
         if remote:
             heads = torch.stack([fixed[r][:8] for r in remote]).view(torch.int64).reshape(-1).cpu()  # (one synchronisation)
             counts = {r: int(heads[k]) for k, r in enumerate(remote)}
+        _mark(clock, "transfer_ms")  # (fixed parts in, counts read back: includes waiting for the remote ranks' encode)
         payload = {r: torch.empty((counts[r], SPARSE_TILE, 3), dtype=local.dtype, device=local.device) for r in remote}
         ops = [dist.P2POp(dist.irecv, payload[r], peer_of(r), group) for r in remote if counts[r] > 0]
         if ops:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
+        _mark(clock, "transfer_ms")
         if nrows[dst] > 0:
             place_shard(out, local, height, row_block, world, dst)
         if remote:
             decode_sparse_many([fixed[r] for r in remote], [payload[r] for r in remote], remote, out, row_block, world)
+        _mark(clock, "decode_ms")
         last_gather.update(bytes=sum(fixed[r].numel() + payload[r].numel() * esize for r in remote), sparse=True)
     elif nrows[rank] > 0:
         fixed, payload = encode_sparse(local[: nrows[rank]].contiguous())
+        _mark(clock, "encode_ms")  # (classify + scan + pack, and the count's read-back)
         for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, fixed, peer_of(dst), group)]):
             req.wait()
         if payload.shape[0] > 0:
             for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, payload, peer_of(dst), group)]):
                 req.wait()
+        _mark(clock, "transfer_ms")
 
 
 def gather_image(local: torch.Tensor, height: int, row_block: int, group=None, dst: int = 0,
                  out: Optional[torch.Tensor] = None, staging: Optional[torch.Tensor] = None,
-                 sparse: Optional[bool] = None) -> Optional[torch.Tensor]:
+                 sparse: Optional[bool] = None, clock: Optional[PhaseClock] = None) -> Optional[torch.Tensor]:
     """Assemble the frame on ``dst`` from the ranks' compact row shards.
 
     ``local`` is this rank's ``[>= rows_of_this_rank, W, 3]`` shard (rows beyond its own are ignored).
@@ -338,8 +372,9 @@ def gather_image(local: torch.Tensor, height: int, row_block: int, group=None, d
         sparse = sparse_default()  # (the same on every rank: an argument or the environment of the job)
     if transport == PADDED:
         _gather_padded(local, height, row_block, world, rank, group, dst, out)
+        _mark(clock, "transfer_ms")
     elif sparse:
-        _gather_sparse(local, height, row_block, world, rank, group, dst, out, nrows)
+        _gather_sparse(local, height, row_block, world, rank, group, dst, out, nrows, clock)
     elif rank == dst:
         if staging is None:
             staging = torch.empty((world, max(nrows)) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
@@ -351,14 +386,17 @@ def gather_image(local: torch.Tensor, height: int, row_block: int, group=None, d
         if ops:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()  # (RCCL: returns once the group is enqueued on the current stream)
+        _mark(clock, "transfer_ms")
         for r in range(world):
             if nrows[r] > 0:
                 place_shard(out, local if r == dst else staging[r], height, row_block, world, r)
+        _mark(clock, "decode_ms")
         last_gather.update(bytes=sum(nrows[r] for r in range(world) if r != dst) * local[0].numel() * local.element_size(), sparse=False)
     elif nrows[rank] > 0:
         peer = dist.get_global_rank(group, dst) if group is not None else dst
         for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, local[: nrows[rank]], peer, group)]):
             req.wait()
+        _mark(clock, "transfer_ms")
     if staged and rank == dst:
         if dev_out is None:
             dev_out = torch.empty(out.shape, dtype=out.dtype, device=dev_local.device)
@@ -427,7 +465,9 @@ class ShardedFrameLoop:
         if self.world > 1:
             choose_transport(group)  # collective, before the first frame
         self._free = [None] * nb      # event: the gather that last read buffer b is done
-        self._rendered = [None] * nb
+        self._rendered = [None] * nb  # event: the render that last wrote buffer b is done ...
+        self._rendered_on = [0] * nb  # ... and the stream slot it ran on
+        self._assembled = self.world == 1  # image(): the last frame rendered has been gathered
         self._pending = []            # buffers whose frames are rendered (or being rendered) and not gathered yet, oldest first
         self.sparse = sparse_default() if sparse is None else bool(sparse)
         self.gather_bytes = None      # rank 0: what the remote ranks sent for the last gathered frame
@@ -446,12 +486,19 @@ class ShardedFrameLoop:
         st = self.streams[slot]
         if self._free[b] is not None:
             st.wait_event(self._free[b])
+            self._free[b] = None
+        # the frame that last wrote this buffer ran on another stream when buffers and streams do not divide evenly
+        # (three in flight: five buffers): it must have finished
+        if self._rendered[b] is not None and self._rendered_on[b] != slot:
+            st.wait_event(self._rendered[b])
         self.scenes[slot].render_into(self.cam, self.params, self.bufs[b].data_ptr(), self.nbytes, st.cuda_stream)
         self.last = b
-        if self.world > 1 and gather:
+        if self.world > 1 or len(self.streams) > 1:
             rendered = torch.cuda.Event()
             rendered.record(st)
-            self._rendered[b] = rendered
+            self._rendered[b], self._rendered_on[b] = rendered, slot
+        self._assembled = self.world == 1
+        if self.world > 1 and gather:
             self._pending.append(b)
             if len(self._pending) > self.lag:
                 self._gather(self._pending.pop(0))
@@ -471,13 +518,56 @@ class ShardedFrameLoop:
             done = torch.cuda.Event()
             done.record(self.comm)
             self._free[b] = done
+        if not self._pending:
+            self._assembled = True
 
     def finish(self) -> None:
         self._drain()
         torch.cuda.synchronize()
 
+    PHASES = ("render_ms", "encode_ms", "transfer_ms", "decode_ms")
+
+    def phase_probe(self, frames: int = 4) -> dict:
+        """Where a sharded frame's time goes ON THIS RANK, phases run one after the other (``PhaseClock``: a measurement
+        mode, nothing overlaps): ``render_ms`` this rank's rows; then -- behind a barrier, so that no rank's transfer
+        waits for another's render -- ``encode_ms`` (remote ranks: the sparse encode with its count read-back),
+        ``transfer_ms`` (remote: the sends; rank 0: until every shard is in, i.e. the slowest remote rank's encode plus
+        the wire) and ``decode_ms`` (rank 0: its own placement and the one-launch decode of the remote shards).
+        -> mean ms per frame and phase.  Collective: every rank of the group calls it."""
+        self.finish()
+        total = {k: 0.0 for k in self.PHASES}
+        st = self.streams[0]
+        for _ in range(max(1, frames)):
+            if self.world > 1:
+                dist.barrier(self.group)
+            clock = PhaseClock()
+            self.scenes[0].render_into(self.cam, self.params, self.bufs[0].data_ptr(), self.nbytes, st.cuda_stream)
+            clock.mark("render_ms")
+            if self.world > 1:
+                dist.barrier(self.group)
+                clock.restart()
+                with torch.cuda.stream(self.comm):
+                    gather_image(self.bufs[0], self.height, self.row_block, group=self.group, dst=0,
+                                 out=self.full[0] if self.rank == 0 else None,
+                                 staging=self.staging if self.rank == 0 else None, sparse=self.sparse, clock=clock)
+                torch.cuda.synchronize()
+            for k in self.PHASES:
+                total[k] += clock.ms.get(k, 0.0)
+        self.last = 0
+        return {k: v / max(1, frames) for k, v in total.items()}
+
     def image(self) -> Optional[torch.Tensor]:
-        """The last assembled frame (rank 0; ``[H, W, 3]`` in HBM)."""
+        """The last frame, assembled (rank 0; ``[H, W, 3]`` in HBM; ``None`` on the other ranks).  Raises when the last
+        frame was rendered without a gather (``step(gather=False)`` in a process group): there is no assembled frame
+        then, and handing out an older buffer would be a stale image."""
         if self.world == 1:
             return self.bufs[self.last][: self.rows]
+        if not self._assembled:
+            raise RuntimeError("ShardedFrameLoop.image(): the last frame was not gathered (step(gather=False), or finish() not called)")
         return self.full[self.last] if self.rank == 0 else None
+
+    def close(self) -> None:
+        """Drain the streams and release the sparse encoder's payload buffers of this loop's comm stream."""
+        self.finish()
+        if self.comm is not None:
+            release_sparse_scratch(self.comm)

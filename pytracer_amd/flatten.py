@@ -149,13 +149,13 @@ _M64 = (1 << 64) - 1
 
 
 def recover_seeds(pcg) -> Tuple[int, int]:
-    """(init_state, init_seq) of a PCG that has not been drawn from since construction.
+    """(init_state, init_seq) such that ``PCG(init_state, init_seq)`` is in the state ``pcg`` is in NOW: the seeds it was
+    built with if it has not been drawn from since, otherwise the seeds of the generator that starts where this one has
+    got to (a tracer whose ``pcg`` an earlier frame already drew from continues its stream, as the reference does).
 
     The reference's PCG keeps only (state, inc) (pcg.py:25-41).  For a fresh generator
     state = ((inc + init_state) * MULT + inc) mod 2^64 and inc = (init_seq << 1) | 1, so both
     seeds can be solved for exactly (seeds < 2^63)."""
-    if hasattr(pcg, "init_state") and hasattr(pcg, "init_seq"):
-        return int(pcg.init_state), int(pcg.init_seq)
     inc = int(pcg.inc) & _M64
     state = int(pcg.state) & _M64
     init_state = ((((state - inc) & _M64) * _MULT_INV) - inc) & _M64
@@ -174,6 +174,11 @@ def is_device_renderer(func) -> bool:
     """True for the reference's renderer objects (by class name, render.py:42-193): what the device path
     renders.  Anything else handed to ``fire_all_rays`` is an opaque callable."""
     return _cls(func) in RENDERER_KINDS and hasattr(func, "world") and hasattr(func, "background_color")
+
+
+def renderer_kind(renderer) -> int:
+    """``PT_RENDERER_*`` of a renderer object (by class name)."""
+    return RENDERER_KINDS[_cls(renderer)]
 
 
 def renderer_params(renderer, width: int, height: int, samples_per_side: int = 0,

@@ -261,6 +261,20 @@ class PCG:
         return self.random() / 0xFFFFFFFF
 
 
+def pcg_advance(state: int, inc: int, delta: int) -> int:
+    """The state ``delta`` draws after ``state`` (the generator is a linear congruential one: jump by repeated squaring;
+    identical to ``delta`` calls of ``random()``; csrc/pt_math.h: pcg_advance64)."""
+    acc_mul, acc_add, cur_mul, cur_add = 1, 0, 6364136223846793005, inc & _M64
+    while delta > 0:
+        if delta & 1:
+            acc_mul = (acc_mul * cur_mul) & _M64
+            acc_add = (acc_add * cur_mul + cur_add) & _M64
+        cur_add = ((cur_mul + 1) * cur_add) & _M64
+        cur_mul = (cur_mul * cur_mul) & _M64
+        delta >>= 1
+    return (acc_mul * state + acc_add) & _M64
+
+
 # ---- image container ---------------------------------------------------------------------------
 class HdrImage:
     """Row-major RGB image, row 0 at the top (hdrimages.py:59-94).

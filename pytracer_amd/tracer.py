@@ -17,13 +17,22 @@ What ``func`` may be:
   in this class (``_host_loop``), drawing the jitter numbers from ``self.pcg`` exactly as
   imagetracer.py:80-104 does.
 
-Random streams on the device: the reference draws jitter and scattering numbers from two global
-sequential generators in row-major pixel order (imagetracer.py:89-92, render.py:118,128), which is
-inherently serial.  The device uses the per-pixel alignment of SURVEY.md §8c: pixel
-``i = row*W + col`` owns ``PCG(S0, Q0 + i)`` (``pcg_mode="pixel"``) or each sample owns
-``PCG(S0, Q0 + i*S² + k)`` (``"sample"``), where (S0, Q0) are the seeds of ``PathTracer.pcg``
-(or of the tracer's ``pcg`` for the other renderers).  Images are deterministic and independent
-of grid, tile or rank layout.
+Random streams on the device (``pcg_mode``).  The reference draws jitter and scattering numbers from two global
+sequential generators in row-major pixel order (imagetracer.py:89-92, render.py:118,128).
+
+* ``"seq"`` -- the reference's own streams.  For ``OnOffRenderer`` / ``FlatRenderer`` / ``PointLightRenderer`` only the
+  jitter stream exists and every sample draws exactly two numbers from it, so sample ``k`` of pixel ``i`` starts
+  ``2 (i S² + k)`` draws into the tracer's ``pcg``: the device enters the stream there by jump-ahead and the frame is
+  the one ``ImageTracer(image, camera, S, pcg).fire_all_rays(renderer)`` computes, bit for bit; afterwards
+  ``tracer.pcg`` has advanced by the ``2 W H S²`` draws the reference would have made.  Refused for ``PathTracer``
+  (its scattering stream is serial by construction).
+* ``"pixel"`` -- pixel ``i = row*W + col`` owns ``PCG(S0, Q0 + i)`` for jitter and scattering in program order;
+  ``"sample"`` -- each sample owns ``PCG(S0, Q0 + i*S² + k)``, where (S0, Q0) are the seeds of
+  ``PathTracer.pcg`` (or of the tracer's ``pcg`` for the other renderers).
+* ``"auto"`` (default) -- ``"seq"`` where it is exact (the three renderers without a scattering stream), ``"pixel"`` for
+  the path tracer.
+
+Images are deterministic and independent of grid, tile or rank layout in every mode.
 
 ``callback(col=, row=, **kw)`` is invoked once before rendering and then whenever more than
 ``callback_time_s`` have passed since the last call (imagetracer.py:76-78, 106-110), with the last
@@ -61,10 +70,10 @@ import numpy as np
 
 from . import abi, flatten
 from .device import DeviceScene
-from .hostmodel import PCG, Color
+from .hostmodel import PCG, Color, pcg_advance
 from .pixels import LazyPixels
 
-_PCG_MODES = {"pixel": abi.PCG_PIXEL, "sample": abi.PCG_SAMPLE}
+_PCG_MODES = {"auto": None, "seq": abi.PCG_SEQ, "pixel": abi.PCG_PIXEL, "sample": abi.PCG_SAMPLE}
 
 
 class _RayView:
@@ -89,7 +98,7 @@ class _RayView:
 
 class GpuImageTracer:
     def __init__(self, image, camera, samples_per_side: int = 0, pcg=None, device: int = 0,
-                 pcg_mode: str = "pixel", resident: bool = False, fallback: Optional[str] = None,
+                 pcg_mode: str = "auto", resident: bool = False, fallback: Optional[str] = None,
                  eager_fill: bool = False):
         if fallback not in (None, "host"):
             raise ValueError('fallback must be None or "host"')
@@ -188,8 +197,11 @@ class GpuImageTracer:
         if callback:
             callback(col=0, row=0, **callback_kwargs)
         w, h = int(self.image.width), int(self.image.height)
+        mode = _PCG_MODES[self.pcg_mode]
+        if mode is None:  # "auto": the reference's own stream where the device can enter it anywhere
+            mode = abi.PCG_PIXEL if flatten.renderer_kind(func) == abi.RENDERER_PATHTRACER else abi.PCG_SEQ
         params = flatten.renderer_params(func, w, h, samples_per_side=int(self.samples_per_side),
-                                         tracer_pcg=self.pcg, pcg_mode=_PCG_MODES[self.pcg_mode])
+                                         tracer_pcg=self.pcg, pcg_mode=mode)
         cam = flatten.flatten_camera(self.camera)
         scene = self._device_scene(func.world)
         dev_t = None
@@ -247,6 +259,9 @@ class GpuImageTracer:
                     band //= 2
             st.n_rays, st.n_rays_resolved, st.kernel_ms, st.total_ms, st.n_pixels = n_rays, n_res, kernel_ms, total_ms, w * h
             self.last_stats = st
+        if mode == abi.PCG_SEQ and int(self.samples_per_side) > 0 and hasattr(self.pcg, "state") and hasattr(self.pcg, "inc"):
+            # the reference's loop leaves ImageTracer.pcg 2 W H S^2 draws further on (imagetracer.py:84-101)
+            self.pcg.state = pcg_advance(int(self.pcg.state), int(self.pcg.inc), 2 * w * h * int(self.samples_per_side) ** 2)
         if dev_t is not None:
             from .postprocess import DeviceImage
 

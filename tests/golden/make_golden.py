@@ -465,6 +465,44 @@ def g5_cli():
                   mode=abi.PCG_PIXEL, s0=45, q0=54)
 
 
+def g5_seq():
+    """The reference's OWN random streams (Mode SEQ), no Seeder: the verbatim ``ImageTracer(image, camera, S,
+    pcg=PCG(...)).fire_all_rays(renderer)`` for the three renderers without a scattering stream -- whose jitter stream
+    the device enters by jump-ahead -- including what ``python -m pytracer render --algorithm
+    flat|onoff|pointlight examples/demo.txt`` computes with its defaults (main.py:76-129, 168-170: S = 1, ImageTracer's
+    default PCG(42, 54))."""
+    with open("/root/reference/examples/demo.txt", "rt") as f:
+        scene = parse_scene(InputStream(f), {})
+    world, cam = scene.world, scene.camera
+    frame_fixture("g5_seq_cli_demo_flat_s1_64x48", world, cam, lambda: FlatRenderer(world), 64, 48, S=1, mode=abi.PCG_SEQ)
+    frame_fixture("g5_seq_cli_demo_onoff_s1_48x36", world, cam, lambda: OnOffRenderer(world), 48, 36, S=1, mode=abi.PCG_SEQ)
+    frame_fixture("g5_seq_cli_demo_pointlight_s1_48x36", world, cam, lambda: PointLightRenderer(world), 48, 36, S=1,
+                  mode=abi.PCG_SEQ)
+    frame_fixture("g5_seq_demo_onoff_s3_40x30", world, cam, lambda: OnOffRenderer(world), 40, 30, S=3, mode=abi.PCG_SEQ,
+                  jitter=(7, 11))
+    frame_fixture("g5_seq_demo_pointlight_s2_40x30", world, cam, lambda: PointLightRenderer(world), 40, 30, S=2,
+                  mode=abi.PCG_SEQ, jitter=(123456789, 2 ** 40 + 3))
+    w2 = ref_synthetic_world(32, with_plane=True)
+    frame_fixture("g5_seq_c2_flat_s3_48x27", w2, ref_synthetic_camera(48, 27), lambda: FlatRenderer(w2), 48, 27, S=3,
+                  mode=abi.PCG_SEQ, jitter=(45, 54))
+    # orthogonal camera, textures, point lights
+    g = PCG(99, 1)
+    r = g.random_float
+    tex = HdrImage(8, 4)
+    for i in range(32):
+        tex.pixels[i] = Color(r(), r(), r())
+    wt = World()
+    wt.add_shape(Sphere(translation(Vec(1.0, 0.3, 0.2)) * rotation_y(25.0) * scaling(Vec(0.7, 0.5, 0.6)),
+                        Material(DiffuseBRDF(ImagePigment(tex)), UniformPigment(Color(0.05, 0.0, 0.1)))))
+    wt.add_shape(Plane(translation(Vec(0.0, 0.0, -0.6)),
+                       Material(DiffuseBRDF(ImagePigment(tex)), CheckeredPigment(BLACK, Color(0.2, 0.2, 0.2), 3))))
+    wt.add_light(PointLight(Point(-3.0, 4.0, 5.0), Color(1.0, 0.9, 0.8), 0.0))
+    ocam = OrthogonalCamera(aspect_ratio=4 / 3, transformation=translation(Vec(-1.0, 0.0, 0.0)))
+    frame_fixture("g5_seq_tex_pointlight_s2_32x24_ortho", wt, ocam,
+                  lambda: PointLightRenderer(wt, background_color=Color(0.1, 0.2, 0.3), ambient_color=Color(0.05, 0.05, 0.1)),
+                  32, 24, S=2, mode=abi.PCG_SEQ)
+
+
 def g9_furnace():
     """test_all.py:1015-1051: closed diffuse unit sphere, N=1, D=100, rr_limit=101."""
     pcg = PCG()
@@ -529,16 +567,16 @@ if __name__ == "__main__":
         del argv[at:at + 2]
     table = {"g1": g1_pcg, "g2": g2_xform, "g3": g3_shapes, "g4": g4_camera, "g6": g6_g7_scatter_onb,
              "g8": g8_pigments, "g9": g9_furnace, "g5": g5_frames, "g10": g10_postprocess, "g5c4": g5_c4,
-             "g5cli": g5_cli}
+             "g5cli": g5_cli, "g5seq": g5_seq}
     if argv:
-        parses = sum(1 for k in argv if k in ("g5", "g5cli"))
+        parses = sum(1 for k in argv if k in ("g5", "g5cli", "g5seq"))
         if parses > 1:
-            raise SystemExit("g5 and g5cli both parse examples/demo.txt: run them in separate processes (SURVEY.md H5)")
+            raise SystemExit("g5, g5cli and g5seq all parse examples/demo.txt: run them in separate processes (SURVEY.md H5)")
         for k in argv:
             table[k]()
     else:
         import subprocess
 
-        for k in ["g1", "g2", "g3", "g4", "g6", "g8", "g9", "g5", "g10", "g5cli", "g5c4"]:  # (g10 reads g5's frames)
+        for k in ["g1", "g2", "g3", "g4", "g6", "g8", "g9", "g5", "g10", "g5cli", "g5c4", "g5seq"]:  # (g10 reads g5's frames)
             subprocess.run([sys.executable, os.path.abspath(__file__), "--out", OUT_DIR, k], check=True,
                            env=dict(os.environ, PYTHONDONTWRITEBYTECODE="1"))

@@ -36,6 +36,7 @@ def test_cli_rejects_bad_values_before_touching_a_gpu():
                          (["-d", "a:b:c", "builtin:demo"], "NAME:VALUE"),
                          (["-d", "clock:fast", "builtin:demo"], "not a floating-point"),
                          (["builtin:nosuch"], "no built-in scene"),
+                         (["--pcg-mode", "seq", "builtin:demo"], "serial by"),  # (pathtracing is the default algorithm)
                          (["/nonexistent/scene.txt"], "")):
         r = CliRunner().invoke(cli, ["render"] + args)
         assert r.exit_code == 2, (args, r.output)
@@ -114,22 +115,31 @@ def _read_pfm(path, w, h):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("algo,fixture,w,h", [("flat", "g5_cli_demo_flat_s1_64x48", 64, 48),
-                                              ("pathtracing", "g5_cli_demo_path_s1_32x24_n10d3", 32, 24)])
-def test_cli_frame_equals_reference_cli_frame(tmp_path, algo, fixture, w, h):
+@pytest.mark.parametrize("algo,fixture,w,h,extra", [
+    # the reference CLI's own frames: jitter from ImageTracer's default PCG(42, 54), ONE sequential stream (main.py:168-170;
+    # tests/golden/make_golden.py g5_seq: the verbatim reference, no re-seeding) -- the default of `render` since round 4
+    ("flat", "g5_seq_cli_demo_flat_s1_64x48", 64, 48, []),
+    ("onoff", "g5_seq_cli_demo_onoff_s1_48x36", 48, 36, []),
+    ("pointlight", "g5_seq_cli_demo_pointlight_s1_48x36", 48, 36, []),
+    ("flat", "g5_seq_cli_demo_flat_s1_64x48", 64, 48, ["--pcg-mode", "seq"]),
+    # one generator per pixel (the reference driven through a re-seeding proxy: g5_cli)
+    ("flat", "g5_cli_demo_flat_s1_64x48", 64, 48, ["--pcg-mode", "pixel"]),
+    ("pathtracing", "g5_cli_demo_path_s1_32x24_n10d3", 32, 24, []),
+    ("pathtracing", "g5_cli_demo_path_s1_32x24_n10d3", 32, 24, ["--pcg-mode", "pixel"])])
+def test_cli_frame_equals_reference_cli_frame(tmp_path, algo, fixture, w, h, extra):
     """The PFM the CLI writes == the reference's frame for the same command line, rounded to the PFM's fp32
-    (hdrimages.py:35-43): exactly for Flat (no libm on the path: checkered planes and a uniform mirror), within 1e-5
-    for the path tracer (sin/cos of ocml vs glibc)."""
+    (hdrimages.py:35-43): exactly for OnOff and Flat (no libm on the path: checkered planes and a uniform mirror), within
+    1e-5 for PointLight and the path tracer (acos / sin / cos of ocml vs glibc)."""
     from pytracer_amd.cli import cli
 
     pfm, png = str(tmp_path / "o.pfm"), str(tmp_path / "o.png")
     r = CliRunner().invoke(cli, ["render", "--width", str(w), "--height", str(h), "--algorithm", algo,
-                                 "--pfm-output", pfm, "--png-output", png, "-d", "clock:150", "builtin:demo"])
+                                 "--pfm-output", pfm, "--png-output", png, "-d", "clock:150"] + extra + ["builtin:demo"])
     assert r.exit_code == 0, r.output
     assert os.path.getsize(png) > 100
     img = _read_pfm(pfm, w, h)
     gold = util.load(fixture)["pixels"]
-    if algo == "flat":
+    if algo in ("flat", "onoff"):
         assert np.array_equal(img, gold.astype(np.float32))
     else:
         err = util.rel_err(img, gold.astype(np.float32))
@@ -188,4 +198,4 @@ def test_cli_scene_file_on_the_gpu(tmp_path, reference_importable):
     r = CliRunner().invoke(cli, ["render", "--width", "64", "--height", "48", "--algorithm", "flat",
                                  "--pfm-output", pfm, "--png-output", png, REF_DEMO])
     assert r.exit_code == 0, r.output
-    assert np.array_equal(_read_pfm(pfm, 64, 48), util.load("g5_cli_demo_flat_s1_64x48")["pixels"].astype(np.float32))
+    assert np.array_equal(_read_pfm(pfm, 64, 48), util.load("g5_seq_cli_demo_flat_s1_64x48")["pixels"].astype(np.float32))

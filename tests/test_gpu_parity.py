@@ -37,8 +37,9 @@ def dev():
 
 
 def _device_ok(par: abi.Params) -> bool:
-    """SEQ fixtures that draw no random number are mode-independent and run on the device."""
-    return not (par.pcg_mode == abi.PCG_SEQ and (par.samples_per_side > 0 or par.renderer == abi.RENDERER_PATHTRACER))
+    """SEQ fixtures (the reference's own streams) run on the device unless they are path-traced: the jitter stream is
+    entered by jump-ahead (two draws per sample), the path tracer's scattering stream is serial by construction."""
+    return not (par.pcg_mode == abi.PCG_SEQ and par.renderer == abi.RENDERER_PATHTRACER)
 
 
 def _uses_libm(scene: abi.FlatScene, par: abi.Params) -> bool:
@@ -122,14 +123,13 @@ def test_pcg_known_answers_and_jump_ahead_on_the_device(dev):
 def test_frame_vs_reference_golden(dev, oracle, name):
     scene, cam, par, pixels = util.load_frame(name)
     if not _device_ok(par):
-        pytest.skip("fixture uses the reference's two global sequential PCG streams (serial by construction)")
+        pytest.skip("path tracer under the reference's global sequential scattering stream (serial by construction)")
     with dev.DeviceScene(scene) as ds:
         out = ds.render(cam, par)
         st = ds.stats()
     assert out.shape == pixels.shape
     # (1) against the oracle in the device's own arithmetic (x*x): exact unless libm is involved
-    par_o = abi.copy_params(par, pcg_mode=abi.PCG_PIXEL if par.pcg_mode == abi.PCG_SEQ else par.pcg_mode)
-    ora, n_rays = oracle.render(scene, cam, par_o, sqr_mode=oracle.SQR_MUL)
+    ora, n_rays = oracle.render(scene, cam, par, sqr_mode=oracle.SQR_MUL)  # (PT_PCG_SEQ: the oracle's serial loop)
     oracle.set_sqr_mode(oracle.SQR_POW)
     if not _uses_libm(scene, par):
         assert util.bits_equal(out, ora), f"device != oracle(x*x): max rel {util.rel_err(out, ora).max()}"
