@@ -737,6 +737,160 @@ class Agreement:
         return self.error is None
 
 
+C3 = dict(n_spheres=32, wide=False, W=1280, H=720,
+          kw=dict(renderer=abi.RENDERER_PATHTRACER, samples_per_side=4, num_of_rays=1, max_depth=3, rr_limit=3,
+                  path_state=45, path_seq=54))
+
+
+def rank_spread(dist, values, world_size):
+    """One number per rank and key -> {key: {min, median, max, per_rank}} (all-gathered; collective)."""
+    keys = sorted(values)
+    mine = torch.tensor([float(values[k]) for k in keys], dtype=torch.float64, device="cuda")
+    every = [torch.empty_like(mine) for _ in range(world_size)]
+    dist.all_gather(every, mine)
+    table = torch.stack(every).cpu().numpy()  # [rank, key]
+    return {k: {"min": float(table[:, i].min()), "median": float(np.median(table[:, i])), "max": float(table[:, i].max()),
+                "per_rank": [float(v) for v in table[:, i]]} for i, k in enumerate(keys)}
+
+
+def sharded_workload(args, cfg, modes, ds, cam, rank, world_size, dist, agree, gather_sparse, steps):
+    """One frame of `cfg` strong-scaled over the ranks, per PCG mode: warm-up and ray count, the timed loop with and
+    without the gather, the per-phase probe, the dome-off side row, the gather check against rank 0 alone and the
+    same loop on ONE GPU by the same clock.  -> {mode: row dict} on rank 0 (None elsewhere)."""
+    W, H = cfg["W"], cfg["H"]
+    rows, rays_frame, resolved_frame = {}, {}, {}
+    for mode in modes:
+        if agree.error is not None:
+            break
+        par = abi.make_params(W, H, out_format=abi.OUT_F32, pcg_mode=mode, **cfg["kw"])
+        loop = [None]
+        tag = f"{cfg['name']} {PCG_NAMES[mode]}"
+
+        def warm():
+            loop[0] = ShardedFrameLoop(ds.scenes, cam, par, row_block=8, sparse=gather_sparse)
+            ds.set_count_rays(True)
+            ds.set_timing(True)
+            for i in range(max(2, args.warmup)):
+                loop[0].step(i, gather=True)
+            loop[0].finish()
+            fence(dist)
+            ds.sync()
+            st = ds.stats()
+            r = torch.tensor([int(st.n_rays), int(st.n_rays_resolved)], dtype=torch.int64, device="cuda")
+            dist.all_reduce(r, op=dist.ReduceOp.SUM)
+            rays_frame[mode], resolved_frame[mode] = int(r[0].item()), int(r[1].item())
+
+        if not agree.run(f"warm-up {tag}", warm):
+            break
+        for gather in (True, False):
+            def timed():
+                elapsed, _, _ = timed_loop(ds, loop[0], steps, dist, gather, events=False)
+                _, kernel_ms, launches = timed_loop(ds, loop[0], max(2, steps // 2), dist, gather, events=True)
+                t = torch.tensor([elapsed, kernel_ms / max(1, launches)], dtype=torch.float64, device="cuda")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                rows[(mode, gather)] = (float(t[0].item()), float(t[1].item()))
+
+            if not agree.run(f"timed loop {tag} gather={gather}", timed):
+                break
+        if agree.error is not None:
+            break
+
+        def phases():  # where a frame's time goes on every rank, phases one after the other (a measurement mode)
+            ds.set_count_rays(False)
+            ds.set_timing(False)
+            mine = loop[0].phase_probe(frames=4)
+            ds.set_timing(True)
+            rows[(mode, "phases")] = rank_spread(dist, mine, world_size)
+
+        if not agree.run(f"phase probe {tag}", phases):
+            break
+
+        def dome_off():  # the same frames with every primary ray generated and traced (no gather: a side row)
+            ds.set_dome_shortcut(False)
+            try:
+                elapsed, _, _ = timed_loop(ds, loop[0], max(2, steps // 4), dist, False, events=False)
+            finally:
+                ds.set_dome_shortcut(True)
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            rows[(mode, "dome_off")] = (float(t[0].item()), max(2, steps // 4))
+
+        if not agree.run(f"dome-off loop {tag}", dome_off):
+            break
+
+        def check_and_solo():
+            # the frame assembled on rank 0 must be bit-identical to the same frame rendered by one rank ...
+            loop[0].step(0, gather=True)
+            loop[0].finish()
+            fence(dist)
+            if rank == 0:
+                rows[(mode, "gather_bytes")] = loop[0].gather_bytes
+                # ... and the SAME workload on ONE GPU, by the same wall clock as `value` (rank 0 alone, the others wait)
+                solo = ShardedFrameLoop(ds.scenes[:1], cam, par, row_block=8, solo=True)
+                el1, _, _ = timed_loop(ds, solo, steps, None, False, events=False)
+                if len(ds.scenes) > 1:  # ... with as many frames in flight as the ranks have, if that is faster on one GPU
+                    many = ShardedFrameLoop(ds.scenes, cam, par, row_block=8, solo=True)
+                    el_many, _, _ = timed_loop(ds, many, steps, None, False, events=False)
+                    rows[(mode, "n1_in_flight")] = (el1, el_many)
+                    el1 = min(el1, el_many)
+                _, k1, n1 = timed_loop(ds, solo, max(2, steps // 2), None, False, events=True)
+                rows[(mode, "check")] = "ok" if torch.equal(solo.image(), loop[0].image()) else "MISMATCH"
+                rows[(mode, "n1")] = (el1, k1 / max(1, n1))
+            fence(dist)
+            loop[0].close()
+            if rank == 0 and rows[(mode, "check")] != "ok":  # (raised behind the fence: every rank has left its collectives)
+                raise RuntimeError(f"{tag}: the gathered frame differs from the frame rank 0 renders alone")
+
+        if not agree.run(f"gather check + one-GPU loop {tag}", check_and_solo):
+            break
+
+    if rank != 0:
+        return None
+
+    def line(mode, gather):
+        el, k = rows[(mode, gather)]
+        traced = rays_frame[mode] - resolved_frame[mode]
+        return {"value": rays_frame[mode] * steps / el / 1e6, "unit": "Mray/s", "ms_per_step": el / steps * 1e3,
+                "traced_Mray_s": traced * steps / el / 1e6,
+                "avg_render_kernels_ms_max_over_ranks": k}
+
+    def mode_rows(mode):
+        out = dict(line(mode, True), without_gather=line(mode, False), gather_check=rows.get((mode, "check")),
+                   gather_bytes_per_frame_sent=rows.get((mode, "gather_bytes")),
+                   rays_per_frame=rays_frame[mode], steps=steps,
+                   traced_ray_fraction=1.0 - resolved_frame[mode] / max(1, rays_frame[mode]))
+        if (mode, "phases") in rows:
+            ph = rows[(mode, "phases")]
+            out["phases_ms"] = dict(ph, note="per rank, mean of 4 frames, phases run ONE AFTER THE OTHER with a device "
+                                             "synchronisation between them (pytracer_amd/dist.py: phase_probe) and a barrier behind "
+                                             "the render: render = the rank's rows; encode = the sparse encode incl. its count "
+                                             "read-back (remote ranks); transfer = sends (remote) / until every shard is in (rank 0: "
+                                             "the slowest remote encode + the wire); decode = placement + one-launch decode (rank 0). "
+                                             "The frame loops overlap these; min / median / max are over the ranks")
+            r = ph["render_ms"]["per_rank"]
+            out["rank_share_imbalance"] = max(r) / max(1e-12, sum(r) / len(r))
+        if (mode, "dome_off") in rows:
+            el, k = rows[(mode, "dome_off")]
+            out["dome_off"] = {"value": rays_frame[mode] * k / el / 1e6, "unit": "Mray/s", "ms_per_step": el / k * 1e3, "steps": k,
+                               "note": "same frames, no gather, pt_set_dome_shortcut(0): every primary ray generated and traced"}
+        if (mode, "n1") in rows:
+            el1, k1 = rows[(mode, "n1")]
+            n1 = {"value": rays_frame[mode] * steps / el1 / 1e6, "unit": "Mray/s", "ms_per_step": el1 / steps * 1e3,
+                  "avg_render_kernels_ms": k1,
+                  "note": "the same frame loop on rank 0 alone (no partition, no gather), same wall clock as `value`; the "
+                          "faster of one frame after the other and as many frames in flight as the ranks have"}
+            if (mode, "n1_in_flight") in rows:
+                a1, am = rows[(mode, "n1_in_flight")]
+                n1["ms_per_step_one_after_the_other"] = a1 / steps * 1e3
+                n1["ms_per_step_frames_in_flight"] = am / steps * 1e3
+            out["n1_same_workload"] = n1
+            out["speedup"] = out["value"] / n1["value"]
+            out["parallel_efficiency"] = out["speedup"] / world_size
+        return out
+
+    return {mode: mode_rows(mode) for mode in modes if (mode, True) in rows and (mode, False) in rows}
+
+
 def run_multi(args, rank, local_rank, world_size, dist, backend):
     from pytracer_amd import dist as ptdist
 
@@ -749,8 +903,6 @@ def run_multi(args, rank, local_rank, world_size, dist, backend):
     n_in_flight = max(1, int(os.environ.get("PT_FRAMES_IN_FLIGHT", "2")))
     ds = SceneGroup(flat, n_in_flight, local_rank)
     agree = Agreement(dist)
-    rows = {}
-    rays_frame, resolved_frame = {}, {}
     seen = [0]
 
     def count_ranks():
@@ -788,6 +940,7 @@ def run_multi(args, rank, local_rank, world_size, dist, backend):
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             gather_choice["probe_ms_per_frame"][name] = float(t.item()) / n * 1e3
             images[name] = lp.image().clone() if rank == 0 else None
+            lp.close()
         if rank == 0 and not torch.equal(images["sparse"], images["whole"]):
             raise RuntimeError("the sparse gather assembled a different frame")
 
@@ -798,115 +951,30 @@ def run_multi(args, rank, local_rank, world_size, dist, backend):
         else:
             gather_choice["sparse"] = False
             gather_choice["probe_error"] = agree.soft.get("gather probe")
-    for mode in (abi.PCG_SAMPLE, abi.PCG_PIXEL):
-        if agree.error is not None:
-            break
-        par = abi.make_params(W, H, out_format=abi.OUT_F32, pcg_mode=mode, **C4["kw"])
-        loop = [None]
 
-        def warm():
-            loop[0] = ShardedFrameLoop(ds.scenes, cam, par, row_block=8, sparse=gather_choice["sparse"])
-            ds.set_count_rays(True)
-            ds.set_timing(True)
-            for i in range(max(2, args.warmup)):
-                loop[0].step(i, gather=True)
-            loop[0].finish()
-            fence(dist)
-            ds.sync()
-            st = ds.stats()
-            r = torch.tensor([int(st.n_rays), int(st.n_rays_resolved)], dtype=torch.int64, device="cuda")
-            dist.all_reduce(r, op=dist.ReduceOp.SUM)
-            rays_frame[mode], resolved_frame[mode] = int(r[0].item()), int(r[1].item())
+    c4_rows = sharded_workload(args, dict(C4, name="C4"), (abi.PCG_SAMPLE, abi.PCG_PIXEL), ds, cam, rank, world_size, dist, agree,
+                               gather_choice["sparse"], args.steps)
+    ds.close()
 
-        if not agree.run(f"warm-up {PCG_NAMES[mode]}", warm):
-            break
-        for gather in (True, False):
-            def timed():
-                elapsed, _, _ = timed_loop(ds, loop[0], args.steps, dist, gather, events=False)
-                _, kernel_ms, launches = timed_loop(ds, loop[0], max(2, args.steps // 2), dist, gather, events=True)
-                t = torch.tensor([elapsed, kernel_ms / max(1, launches)], dtype=torch.float64, device="cuda")
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                rows[(mode, gather)] = (float(t[0].item()), float(t[1].item()))
-
-            if not agree.run(f"timed loop {PCG_NAMES[mode]} gather={gather}", timed):
-                break
-        if agree.error is not None:
-            break
-
-        def dome_off():  # the same frames with every primary ray generated and traced (no gather: a side row)
-            ds.set_dome_shortcut(False)
-            try:
-                elapsed, _, _ = timed_loop(ds, loop[0], max(2, args.steps // 4), dist, False, events=False)
-            finally:
-                ds.set_dome_shortcut(True)
-            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            rows[(mode, "dome_off")] = (float(t[0].item()), max(2, args.steps // 4))
-
-        if not agree.run(f"dome-off loop {PCG_NAMES[mode]}", dome_off):
-            break
-
-        def check_and_solo():
-            # the frame assembled on rank 0 must be bit-identical to the same frame rendered by one rank ...
-            loop[0].step(0, gather=True)
-            loop[0].finish()
-            fence(dist)
-            if rank == 0:
-                rows[(mode, "gather_bytes")] = loop[0].gather_bytes
-                # ... and the SAME workload on ONE GPU, by the same wall clock as `value` (rank 0 alone, the others wait)
-                solo = ShardedFrameLoop(ds.scenes[:1], cam, par, row_block=8, solo=True)
-                el1, _, _ = timed_loop(ds, solo, args.steps, None, False, events=False)
-                if len(ds.scenes) > 1:  # ... with as many frames in flight as the ranks have, if that is faster on one GPU
-                    many = ShardedFrameLoop(ds.scenes, cam, par, row_block=8, solo=True)
-                    el_many, _, _ = timed_loop(ds, many, args.steps, None, False, events=False)
-                    rows[(mode, "n1_in_flight")] = (el1, el_many)
-                    el1 = min(el1, el_many)
-                _, k1, n1 = timed_loop(ds, solo, max(2, args.steps // 2), None, False, events=True)
-                rows[(mode, "check")] = "ok" if torch.equal(solo.image(), loop[0].image()) else "MISMATCH"
-                rows[(mode, "n1")] = (el1, k1 / max(1, n1))
-            fence(dist)
-
-        if not agree.run(f"gather check + one-GPU loop {PCG_NAMES[mode]}", check_and_solo):
-            break
+    # BASELINE.json's metric is quoted "at 1280x720, 1/2/4/8 MI355X" (VERDICT r3 row e'): C3 -- 1280x720, 32 spheres,
+    # PathTracer D = 3, spp 16, per-thread PCG -- through the same sharded loop.  A frame of 0.12 ms cut in N: the
+    # launch and the gather are most of what is left, so more steps per timed loop than the 4K frame gets.
+    c3_rows = None
+    flat3 = flatten.flatten_world(scenes.synthetic_world(C3["n_spheres"], wide=C3["wide"]))
+    ds3 = SceneGroup(flat3, n_in_flight, local_rank)
+    if agree.error is None:
+        c3_rows = sharded_workload(args, dict(C3, name="C3"), (abi.PCG_SAMPLE,), ds3, cam_for(C3["W"], C3["H"]), rank, world_size,
+                                   dist, agree, gather_choice["sparse"], max(args.steps, 5 * args.steps))
+    ds3.close()
 
     if rank == 0:
-        def line(mode, gather):
-            el, k = rows[(mode, gather)]
-            traced = rays_frame[mode] - resolved_frame[mode]
-            return {"value": rays_frame[mode] * args.steps / el / 1e6, "unit": "Mray/s", "ms_per_step": el / args.steps * 1e3,
-                    "traced_Mray_s": traced * args.steps / el / 1e6,
-                    "avg_render_kernels_ms_max_over_ranks": k}
-
-        def mode_rows(mode):
-            out = dict(line(mode, True), without_gather=line(mode, False), gather_check=rows.get((mode, "check")),
-                       gather_bytes_per_frame_sent=rows.get((mode, "gather_bytes")),
-                       rays_per_frame=rays_frame[mode],
-                       traced_ray_fraction=1.0 - resolved_frame[mode] / max(1, rays_frame[mode]))
-            if (mode, "dome_off") in rows:
-                el, k = rows[(mode, "dome_off")]
-                out["dome_off"] = {"value": rays_frame[mode] * k / el / 1e6, "unit": "Mray/s", "ms_per_step": el / k * 1e3, "steps": k,
-                                   "note": "same frames, no gather, pt_set_dome_shortcut(0): every primary ray generated and traced"}
-            if (mode, "n1") in rows:
-                el1, k1 = rows[(mode, "n1")]
-                n1 = {"value": rays_frame[mode] * args.steps / el1 / 1e6, "unit": "Mray/s", "ms_per_step": el1 / args.steps * 1e3,
-                      "avg_render_kernels_ms": k1,
-                      "note": "the same C4 frame loop on rank 0 alone (no partition, no gather), same wall clock as `value`; the "
-                              "faster of one frame after the other and as many frames in flight as the ranks have"}
-                if (mode, "n1_in_flight") in rows:
-                    a1, am = rows[(mode, "n1_in_flight")]
-                    n1["ms_per_step_one_after_the_other"] = a1 / args.steps * 1e3
-                    n1["ms_per_step_frames_in_flight"] = am / args.steps * 1e3
-                out["n1_same_workload"] = n1
-                out["speedup"] = out["value"] / n1["value"]
-                out["parallel_efficiency"] = out["speedup"] / world_size
-            return out
-
         plan = ptdist.gather_plan(H, W, 8, world_size, itemsize=4, transport=ptdist.choose_transport() if agree.error is None else ptdist.P2P)
         result = {
             "metric": "Mray/s (primary+shadow), C4: ONE 3840x2160 frame, 256 spheres, PathTracer depth 5, 64 spp, strong-scaled "
                       f"over {world_size} MI355X with the RCCL gather of the HdrImage inside the timed region "
                       "(NOT the N=1 line's workload: `python bench.py` measures C2, 1280x720 Flat; the one-GPU figure for THIS "
-                      "workload is n1_same_workload, and speedup / parallel_efficiency are computed against it)",
+                      "workload is n1_same_workload, and speedup / parallel_efficiency are computed against it; the 1280x720 "
+                      "figure on N ranks is the row at_1280x720)",
             "value": None, "unit": "Mray/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": None, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic", "ranks_seen": seen[0], "backend": backend,
@@ -930,29 +998,62 @@ def run_multi(args, rank, local_rank, world_size, dist, backend):
                           "world query, dome_off is the same loop with the shortcut switched off",
         }
         HEAD, SIDE = abi.PCG_SAMPLE, abi.PCG_PIXEL
-        if (HEAD, True) in rows and (HEAD, False) in rows:
-            result.update(mode_rows(HEAD))
-            if (SIDE, True) in rows and (SIDE, False) in rows:
-                result["pcg_pixel"] = dict(mode_rows(SIDE),
+        if c4_rows and HEAD in c4_rows:
+            result.update(c4_rows[HEAD])
+            result["steps"] = args.steps
+            if SIDE in c4_rows:
+                result["pcg_pixel"] = dict(c4_rows[SIDE],
                                            note="the same frame with one generator per PIXEL (SURVEY.md 8c Mode PIXEL): a pixel's 64 "
                                                 "samples consume ONE stream in order, so the lanes of a pixel speculate on where each "
                                                 "sample starts (DESIGN.md 4 item 10) and a rank's share of the frame is bounded by its "
                                                 "slowest pixel's rounds, not by its share of the work")
+        if c3_rows and HEAD in c3_rows:
+            result["at_1280x720"] = dict(c3_rows[HEAD],
+                                         workload="C3 path tracer 1280x720, 32 spheres, N=1, D=3, rr=3, S=4 (16 spp), PT_PCG_SAMPLE, fp32 RGB "
+                                                  f"assembled on rank 0: ONE frame strong-scaled over {world_size} ranks (interleaved 8-row "
+                                                  "blocks), same ShardedFrameLoop, gather inside the timed region",
+                                         note="BASELINE.json quotes its metric 'at 1280x720, 1/2/4/8 MI355X'; C2 (14 us per frame) cannot "
+                                              "shard, C3 (0.12 ms) can: n1_same_workload is this frame on rank 0 alone by the same clock")
         if agree.error is not None:
             result["error"] = agree.error
         print(json.dumps(result), flush=True)
-    ds.close()
     return 0 if agree.error is None else 1
+
+
+def visible_gpus():
+    """GPUs this job can see, counted WITHOUT the HIP runtime (torch.cuda.device_count() may fall through to
+    hipGetDeviceCount and bring the runtime up in the parent): the KFD topology's nodes with SIMDs, cut by
+    HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES when set.  -> int, or None when the topology cannot be read."""
+    import glob
+
+    n = 0
+    try:
+        for path in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+            for line in open(path):
+                if line.startswith("simd_count") and int(line.split()[1]) > 0:
+                    n += 1
+    except (OSError, ValueError, IndexError):
+        return None
+    if n == 0:
+        return None
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
 
 
 def launch_ranks(args, argv):
     """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves
-    (`python -m torch.distributed.run`, one per GPU), relay rank 0's JSON line and exit with the job's status.
-    Runs BEFORE this process touches the GPU (no exec of a process that has initialised HIP)."""
+    (`python -m torch.distributed.run`, one per GPU) as a CHILD process (never an exec), relay rank 0's JSON line and
+    exit with the job's status.  This parent does not touch the GPU: the devices are counted from the KFD topology in
+    sysfs; where that cannot be read the count is left to the ranks (a rank without a device reports it)."""
     import socket
     import subprocess
 
-    n_dev = torch.cuda.device_count()  # (counting devices does not initialise the GPU)
+    n_dev = visible_gpus()
+    if n_dev is None:
+        n_dev = args.gpus  # unknown here: the child ranks find out
     env = dict(os.environ)
     if n_dev < args.gpus and env.get("PT_DIST_BACKEND", "nccl") == "nccl":
         print(json.dumps({"metric": "Mray/s", "value": None, "unit": "Mray/s", "n_gpus": args.gpus,

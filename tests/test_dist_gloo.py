@@ -109,6 +109,13 @@ def _gather_worker(rank, world, port, transport, H, ret, sparse=None, W=5, kind=
         out = ptdist.gather_image(shard + 1.0, H, 8, sparse=sparse)
         if rank == 0:
             ret["ok2"] = bool(torch.equal(out, full + 1.0))
+        # a clocked gather (bench.py's per-phase breakdown): the same frame, and every rank books the phases it took part in
+        clock = ptdist.PhaseClock()
+        out = ptdist.gather_image(shard + 2.0, H, 8, sparse=sparse, clock=clock)
+        if rank == 0:
+            ret["ok3"] = bool(torch.equal(out, full + 2.0))
+        ret[f"phases{rank}"] = sorted(clock.ms)
+        assert all(v >= 0.0 for v in clock.ms.values())
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -128,8 +135,11 @@ def test_gather_one_transfer_per_rank_and_the_padded_transport(world, transport,
     port = _free_port()
     ret = mp.Manager().dict()
     mp.spawn(_gather_worker, args=(world, port, transport, H, ret), nprocs=world, join=True)
-    assert ret["ok"] is True and ret["ok2"] is True
+    assert ret["ok"] is True and ret["ok2"] is True and ret["ok3"] is True
     assert ret["transport"] == (transport or "p2p")
+    assert "transfer_ms" in ret["phases0"]
+    if (transport or "p2p") == "p2p":
+        assert "decode_ms" in ret["phases0"] and "transfer_ms" in ret["phases1"]
 
 
 @pytest.mark.parametrize("world,H,W,kind,sparse", [
