@@ -78,6 +78,12 @@ PT_DEV pt_kargs cold_args(const PtKArgs &a) {
 #define PT_QUEUE_WORDS 512
 #endif
 #define PT_QUEUE_HEADS 256
+// num_of_rays > 1 on a perspective camera: BOTH second-pass kernels are enqueued behind the first pass and this word of the
+// frame's queue block, written by pt_unit_scatter from F (the flagged pixels the first pass counted), says which of
+// them works -- 0: pt_path_tree_kernel (one pixel per wave: few flagged pixels, the frame waits for its deepest tree),
+// 1: pt_path_kernel<., true> (a lane per flagged pixel, refilled from one queue: frames full of flagged pixels are
+// throughput-bound).  The other one returns at once.
+#define PT_Q_CHOICE 200
 #ifndef PT_UNIT_SHARDS
 #define PT_UNIT_SHARDS 8
 #endif

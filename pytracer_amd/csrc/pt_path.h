@@ -41,7 +41,7 @@ PT_DEV int unit_ppu(const unsigned long long *queue, long long lanes_cap, int ns
 #define PT_SCATTER_BLOCK 256
 #endif
 __global__ void pt_unit_scatter(const unsigned char *keys, const unsigned long long *masks, int n, int4 *units, int units_cap,
-                                unsigned long long *queue, long long lanes_cap, int nsamp, int min_rounds) {
+                                unsigned long long *queue, long long lanes_cap, int nsamp, int min_rounds, long long q_min_flagged = -1) {
   __shared__ int cnt[65], offs[65];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int k = i < n ? keys[i] : 0;
@@ -72,6 +72,8 @@ __global__ void pt_unit_scatter(const unsigned char *keys, const unsigned long l
     if (threadIdx.x == 63 && blockIdx.x == 0) {
       queue[9] = (unsigned long long)(upto < units_cap ? upto : units_cap);
       queue[10] = (unsigned long long)ppu;
+      // num_of_rays > 1: which second-pass kernel works on this frame (PT_Q_CHOICE); < 0: the tree kernel, always
+      queue[PT_Q_CHOICE] = (q_min_flagged >= 0 && (long long)queue[11] >= q_min_flagged) ? 1ULL : 0ULL;
     }
   }
   __syncthreads();
@@ -212,10 +214,13 @@ PT_DEV long long next_pixel(const PtKArgs &a, bool need, long long npix) {
 #ifndef PT_REGIONS_INLINE
 #define PT_REGIONS_INLINE 1  // second pass: HitRecord / scatter / transcendental code inline (1) or behind calls (0)
 #endif
-template <bool TILED, bool LDSF, bool LAT, bool SLDS = false, int LEAN = 0>
+// FLAGGED (!TILED only): the kernel runs BEHIND the first pass, as the alternative to pt_path_tree_kernel (PT_Q_CHOICE): it
+// returns at once unless the device chose it, and a lane keeps only pixels the first pass flagged (the others are settled).
+template <bool TILED, bool LDSF, bool LAT, bool SLDS = false, int LEAN = 0, bool FLAGGED = false>
 PT_DEV void path_trace(const PtKArgs &a) {
   constexpr bool INL = LAT && PT_REGIONS_INLINE;
   static_assert(!SLDS || INL, "the scene is staged in LDS for the second pass only");
+  static_assert(!FLAGGED || !TILED, "the flagged-pixel filter belongs to the one-queue kernel");
   PathCtx w;
   int S, nsamp, N, W = 0, rows_local = 0, npass = 0, D = 0, rr = 0, diag_lds = -1, pcg_mode = PT_PCG_PIXEL;
   bool ortho = false;
@@ -241,6 +246,10 @@ PT_DEV void path_trace(const PtKArgs &a) {
   if (blockIdx.x == gridDim.x - 1) {  // the next frame's queue block (nothing of this frame reads it)
     unsigned long long *qn = pt_queue_next(a);
     for (int k = threadIdx.x; k < PT_QUEUE_WORDS; k += PT_BLOCK) qn[k] = 0ULL;
+  }
+  if (FLAGGED && pt_queue(a)[PT_Q_CHOICE] != 1ULL) {  // (uniform over the grid: the tree kernel renders this frame)
+    add_ray_count(a, 0ULL, cold_args(a)->count_base);
+    return;
   }
   if (LAT && diag_lds >= 0) {
     // scale+translate records into LDS: world_query_lanes fetches them by lane-private index
@@ -312,6 +321,12 @@ PT_DEV void path_trace(const PtKArgs &a) {
   uint64_t hist = 0;
   int pscore = 0;                   // ... how much more often the upper neighbour was the better guess than the predecessor (per pixel)
   const int hperiod = (S >= 1 && S <= 8) ? S : 1;
+  // PT_PCG_PIXEL, pixels NEITHER guess works for (paths that bounce between spheres draw five or six different counts, none
+  // of them more than a third of the time: profiles/r03_c3_pixel_tail_units.txt): where a pixel has lanes to spare they
+  // trace the next samples from EVERY start state its recent counts allow -- sample vbase + d from vstate advanced by each
+  // integer in [d lo, d hi], lo / hi the smallest / largest count among its last eight samples -- and the round commits,
+  // level by level, whichever lane started from the state the level before it ended in (seed_round: "window").
+  int level = 0;                    // this lane's sample of the round is vbase + level
   uint64_t st_start = 0;            // state this lane's sample started from
   unsigned srays = 0, prays = 0;    // rays of the current sample; of the pixel's validated samples
   unsigned long long gpix = 0;      // global pixel index (seeds)
@@ -336,13 +351,15 @@ PT_DEV void path_trace(const PtKArgs &a) {
     ray = primary_ray(a, col, grow, up, vp);
   };
 
-  // TILED: the generator a lane's next sample starts from, `samp` = vbase + jlane
-  auto seed_round = [&]() {
+  // TILED: the sample of the round this lane traces (`level`: vbase + level) and the generator state it starts from.
+  // -> whether that sample exists (vbase + level < nsamp)
+  auto seed_round = [&]() -> bool {
     pt_kargs c = cold_args(a);
-    if (pcg_mode == PT_PCG_SAMPLE)
-      pcg_seed(pcg, c->s0, c->q0 + gpix * (unsigned)nsamp + (unsigned)samp);
-    else
-    {
+    level = jlane;
+    if (pcg_mode == PT_PCG_SAMPLE) {
+      samp = vbase + level;
+      if (samp < nsamp) pcg_seed(pcg, c->s0, c->q0 + gpix * (unsigned)nsamp + (unsigned)samp);
+    } else {
       // (sample vbase + i: what its upper neighbour vbase + i - period drew, if the pixel has got that far and that guess
       //  has been the better one so far; else what the last validated sample drew)
       const int period = hperiod;
@@ -351,12 +368,59 @@ PT_DEV void path_trace(const PtKArgs &a) {
         ahead = 0;
         for (int i = 0; i < jlane; ++i)
           ahead += (unsigned)(hist >> (vbase + (i % period) >= period ? 8 * (period - 1 - (i % period)) : 0)) & 0xffu;
+      } else if (L >= c->spec_win_lanes) {
+        // smallest and largest count of the last eight samples; how many of the seven neighbouring pairs drew alike
+        // (bytes of x that are zero: exact per-byte test, no borrow between bytes)
+        unsigned lo = (unsigned)hist & 0xffu, hi = lo;
+#pragma unroll
+        for (int k = 1; k < 8; ++k) {
+          const unsigned v = (unsigned)(hist >> (8 * k)) & 0xffu;
+          lo = v < lo ? v : lo;
+          hi = v > hi ? v : hi;
+        }
+        if (hi > lo) {
+          const uint64_t x = (hist ^ (hist >> 8)) & 0x00ffffffffffffffULL;
+          const uint64_t z = ~(((x & 0x7f7f7f7f7f7f7f7fULL) + 0x7f7f7f7f7f7f7f7fULL) | x | 0x7f7f7f7f7f7f7f7fULL) & 0x0080808080808080ULL;
+          // samples a round is expected to commit: the chain, 1 + p + p^2 + ... over L lanes with p the share of pairs that
+          // drew alike -- against the window, one level per d w + 1 lanes (w = hi - lo), each level reached with
+          // probability `cover` (the next count lies in [lo, hi])
+          const float pr = ((float)__popcll(z) + 0.5f) * (1.0f / 7.5f), cover = (float)c->spec_win_cover * (1.0f / 16.0f);
+          float e_chain = 0.0f, t = 1.0f;
+          for (int k = 0; k < L && k < 16; ++k) {
+            e_chain += t;
+            t *= pr;
+          }
+          const int w = (int)(hi - lo);
+          float e_win = 0.0f;
+          t = 1.0f;
+          for (int d = 0, n = 0; d < 16; ++d) {
+            const int width = d * w + 1;
+            if (n + width > L) {
+              e_win += t * (float)(L - n) / (float)width;
+              break;
+            }
+            n += width;
+            e_win += t;
+            t *= cover;
+          }
+          if (e_win > e_chain) {
+            int d = 0, r = jlane;
+            while (r >= d * w + 1) {
+              r -= d * w + 1;
+              ++d;
+            }
+            level = d;
+            ahead = (unsigned)d * lo + (unsigned)r;
+          }
+        }
       }
+      samp = vbase + level;
       pcg.state = pcg_advance(vstate, pcg.inc, ahead);
     }
     pcg.n = 0;
     st_start = pcg.state;
     srays = 0;
+    return samp < nsamp;
   };
 
   // render.py:103-139 up to (not including) the recursion: sets `ret`, or pushes frame `sp` and asks
@@ -556,7 +620,15 @@ PT_DEV void path_trace(const PtKArgs &a) {
             const int s_fin = __shfl((int)fin, src, 64);
             const unsigned s_rays = (unsigned)__shfl((int)srays, src, 64);
             const double rx_ = __shfl(ret.x, src, 64), ry_ = __shfl(ret.y, src, 64), rz_ = __shfl(ret.z, src, 64);
-            chain = chain && s_fin != 0 && (pcg_mode == PT_PCG_SAMPLE || s_from == vstate);
+            if (pcg_mode == PT_PCG_SAMPLE) {
+              chain = chain && s_fin != 0;
+            } else {
+              // the lane's sample counts iff it is the NEXT one (its level = the samples committed so far this round) and it
+              // started from the state the sequential program is in; lanes come level by level, so a hypothesis that was
+              // wrong (or a level already settled by an earlier lane) is passed over and the walk goes on
+              const int s_samp = __shfl(samp, src, 64);
+              chain = s_fin != 0 && s_samp == vbase && s_from == vstate;
+            }
 #ifdef PT_DEBUG_TIME
             dbg_fin += s_fin;
 #endif
@@ -614,12 +686,8 @@ PT_DEV void path_trace(const PtKArgs &a) {
                 nrays += prays;
               }
               pix = -1;  // this pixel is done (in every lane of it)
-            } else {
-              samp = vbase + jlane;
-              if (samp < nsamp) {
-                seed_round();
-                mode = 0;
-              }
+            } else if (seed_round()) {
+              mode = 0;
             }
           }
         }
@@ -742,25 +810,29 @@ PT_DEV void path_trace(const PtKArgs &a) {
             cum.x = 0.0;
             cum.y = 0.0;
             cum.z = 0.0;
-            samp = jlane;
-            if (samp < nsamp) {
-              seed_round();
-              mode = 0;
-            }
+            if (seed_round()) mode = 0;
           }
         }
       }
     } else {
-      const bool need = mode == 2 && !exhausted;
-      if (__any(need)) {
+      for (;;) {
+        const bool need = mode == 2 && !exhausted;
+        if (!__any(need)) break;
         const long long np = next_pixel(a, need, a.npix);
-        if (need) {
-          if (np >= 0) {
+        if (need && np >= 0) {
+          bool take = true;
+          if (FLAGGED) {  // pixels the first pass settled are not this kernel's (pt_tile_kernel: rmask)
+            const int lr = (int)(np / W), c0 = (int)(np - (long long)lr * W);
+            const unsigned long long m = cold_args(a)->region_mask[(lr / PT_REGION) * regions_x + c0 / PT_REGION];
+            take = ((m >> ((lr % PT_REGION) * PT_REGION + (c0 % PT_REGION))) & 1ULL) != 0ULL;
+          }
+          if (take) {
             pix = np;
             mode = 0;
           }
         }
         exhausted = __any(need && np < 0);
+        if (!FLAGGED) break;  // (FLAGGED: lanes that drew a settled pixel draw again)
       }
       if (!__any(mode != 2)) break;
     }
@@ -891,13 +963,14 @@ PT_DEV void path_trace(const PtKArgs &a) {
     for (int q = 0; q < 8; ++q) atomicAdd(pt_queue(a) + 1 + q, tsum[q]);
   pt_dbg_flush();
 #endif
-  add_ray_count(a, nrays);
+  add_ray_count(a, nrays, TILED ? 0 : cold_args(a)->count_base);
 }
 
-// every pixel of the frame, pixels from one queue (orthogonal camera): throughput matters
-template <bool LDSF>
+// every pixel of the frame, pixels from one queue (orthogonal camera; FLAGGED: the flagged pixels of a perspective frame
+// of num_of_rays > 1 when the device chose this kernel, PT_Q_CHOICE): throughput matters
+template <bool LDSF, bool FLAGGED = false>
 __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAVES_PATH, 8))) void pt_path_kernel(const PtKArgs a) {
-  path_trace<false, LDSF, false>(a);
+  path_trace<false, LDSF, false, false, 0, FLAGGED>(a);
 }
 // second pass behind pt_tile_kernel<PATHTRACER> (perspective camera): the flagged pixels, by region
 #ifndef PT_WAVES_REGIONS

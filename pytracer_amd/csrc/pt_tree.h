@@ -63,6 +63,10 @@ PT_DEV void path_tree(const PtKArgs &a) {
     unsigned long long *qn = pt_queue_next(a);
     for (int k = threadIdx.x; k < PT_QUEUE_WORDS; k += PT_BLOCK) qn[k] = 0ULL;
   }
+  if (pt_queue(a)[PT_Q_CHOICE] != 0ULL) {  // (uniform over the grid) a frame full of flagged pixels: pt_path_kernel<., true> renders it
+    add_ray_count(a, 0ULL);
+    return;
+  }
   if (diag_lds >= 0) {  // scale+translate records into LDS: world_query_lanes fetches them by lane-private index
     const unsigned long long *src = (const unsigned long long *)a.diag;
     for (int k = threadIdx.x; k < a.n_diag * 8; k += PT_BLOCK) pt_lds_masks[diag_lds + k] = src[k];

@@ -101,6 +101,11 @@ struct pt_scene {
   int queue_parity = 0;
   bool queue_clean = false;
   PtKArgs *args_dev = nullptr;          // device copy of the argument block (cold fields)
+  PtKArgs *args_dev2 = nullptr;         // ... of pt_path_kernel<., true>'s, when a frame enqueues both second-pass kernels (PT_Q_CHOICE)
+  PtKArgs args2_last;
+  bool args2_valid = false;
+  hipStream_t args2_stream = nullptr;
+  bool choice_pending = false;          // ray_counter_host[2] will hold the frame's PT_Q_CHOICE word once ev_count has passed
   unsigned char *region_keys = nullptr;  // path tracer region ordering
   struct DomeCand {
     int slot;
@@ -253,6 +258,7 @@ extern "C" void pt_scene_free(pt_scene *s) {
   (void)hipFree(s->ray_partials);
   (void)hipFree(s->queue);
   (void)hipFree(s->args_dev);
+  (void)hipFree(s->args_dev2);
   (void)hipFree(s->region_keys);
   (void)hipFree(s->units);
   (void)hipFree(s->region_mask);
@@ -289,8 +295,9 @@ static int handle_state(pt_scene *s) {
   if ((rc = hip_or_free(hipMalloc((void **)&s->ray_counter, 2 * sizeof(unsigned long long)), "hipMalloc(counter)"))) return rc;
   if ((rc = hip_or_free(hipMalloc((void **)&s->queue, 2 * PT_QUEUE_WORDS * sizeof(unsigned long long)), "hipMalloc(queue)"))) return rc;
   if ((rc = hip_or_free(hipMalloc((void **)&s->args_dev, sizeof(PtKArgs)), "hipMalloc(args)"))) return rc;
-  if ((rc = hip_or_free(hipHostMalloc((void **)&s->ray_counter_host, 2 * sizeof(unsigned long long)), "hipHostMalloc"))) return rc;
-  s->ray_counter_host[0] = s->ray_counter_host[1] = 0;
+  if ((rc = hip_or_free(hipMalloc((void **)&s->args_dev2, sizeof(PtKArgs)), "hipMalloc(args)"))) return rc;
+  if ((rc = hip_or_free(hipHostMalloc((void **)&s->ray_counter_host, 3 * sizeof(unsigned long long)), "hipHostMalloc"))) return rc;
+  s->ray_counter_host[0] = s->ray_counter_host[1] = s->ray_counter_host[2] = 0;
   if ((rc = hip_or_free(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking), "hipStreamCreate"))) return rc;
   if ((rc = hip_or_free(hipEventCreate(&s->ev0), "hipEventCreate"))) return rc;
   if ((rc = hip_or_free(hipEventCreate(&s->ev1), "hipEventCreate"))) return rc;
@@ -997,6 +1004,7 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
   s->last_stream = st;
   s->launched = true;
   s->count_pending = false;
+  s->choice_pending = false;
   const int rows = pt_rows_for_rank(p);
   a.rows_local = rows;
   a.npass = (s->n_shapes + 63) / 64;
@@ -1102,6 +1110,19 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
     grid4 = dim3((unsigned)(((p->width + 15) / 16 + 1) / 2), (unsigned)(((rows + th - 1) / th + 1) / 2), 1);
     grid = (int)(grid4.x * grid4.y);
   }
+  // num_of_rays > 1: the tree kernel (one pixel per wave) is latency-bound and wins while flagged pixels are few; a frame
+  // FULL of them is throughput-bound and a lane per pixel, refilled from one queue, wins (profiles/r03_tree_dense_frames.txt:
+  // the reference's demo scene at 1280x960, 16.3 against 10.6 ms).  Which of the two a frame is only the first pass knows
+  // (F, on the device): both kernels are enqueued and pt_unit_scatter writes which one works (PT_Q_CHOICE).  The one-queue
+  // kernel takes part only where its per-lane frame stack fits the LDS (N > 1: 20 doubles per depth and lane; D <= 3).
+  static const int env_qchoice = getenv("PTRACE_QCHOICE") ? atoi(getenv("PTRACE_QCHOICE")) : 1;  // 0: never, 2: always (measurement)
+  const size_t q_frame_lds = (size_t)std::max(p->max_depth, 1) * 20 * PT_BLOCK * sizeof(double);
+  const bool q_alt = tree && env_qchoice != 0 && q_frame_lds <= PT_LDS_BUDGET;
+  int grid_q = 0;
+  if (q_alt) {
+    const int wgq = std::min<int>(3, (int)(PT_LDS_BUDGET / q_frame_lds));
+    grid_q = (int)std::max<long long>(1, std::min<long long>(want, (long long)s->n_cu * wgq));
+  }
   int grid_first = 0;  // path tracer, first pass (pt_tile_kernel<PATHTRACER>): one wave per 8x8 region
   if (path_tiled) {
     const long long regions = (long long)((p->width + PT_REGION - 1) / PT_REGION) * ((rows + PT_REGION - 1) / PT_REGION);
@@ -1115,13 +1136,13 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
   s->stats.kernel = PT_KERNEL_NONE;
 
   if (s->count_rays) {
-    if (grid + grid_first > s->ray_partials_n) {
+    if (grid + grid_first + grid_q > s->ray_partials_n) {
       HIP_TRY(hipStreamSynchronize(st));
       if (s->ray_partials) HIP_TRY(hipFree(s->ray_partials));
       s->ray_partials = nullptr;
       s->ray_partials_n = 0;
-      HIP_TRY(hipMalloc((void **)&s->ray_partials, (size_t)(grid + grid_first) * 2 * sizeof(unsigned long long)));
-      s->ray_partials_n = grid + grid_first;
+      HIP_TRY(hipMalloc((void **)&s->ray_partials, (size_t)(grid + grid_first + grid_q) * 2 * sizeof(unsigned long long)));
+      s->ray_partials_n = grid + grid_first + grid_q;
     }
     a.ray_counter = s->ray_partials;
   }
@@ -1213,6 +1234,10 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
     // numbers and one diffuse bounce (a guess only costs a round when it is wrong, never a bit of the image)
     static const int env_spec = getenv("PTRACE_SPEC_DRAWS") ? atoi(getenv("PTRACE_SPEC_DRAWS")) : -1;
     a.spec_draws = env_spec >= 0 ? env_spec : (p->samples_per_side > 0 ? 4 : 2);
+    static const int env_wl = getenv("PTRACE_SPEC_WIN_LANES") ? atoi(getenv("PTRACE_SPEC_WIN_LANES")) : 8;
+    static const int env_wc = getenv("PTRACE_SPEC_WIN_COVER") ? atoi(getenv("PTRACE_SPEC_WIN_COVER")) : 13;
+    a.spec_win_lanes = env_wl;
+    a.spec_win_cover = env_wc;
     // The sphere the camera is deepest inside (object-space |o'|^2 - 1 most negative, and below -0.5): the
     // first pass settles, per pixel, what can only hit that sphere (pt_tile_kernel re-checks every condition
     // from the exact hoisted constants; this only names the candidate).
@@ -1379,9 +1404,31 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
       const int nsamp = p->samples_per_side > 0 ? p->samples_per_side * p->samples_per_side : 1;
       static const int env_minr = getenv("PTRACE_UNIT_MIN_ROUNDS") ? atoi(getenv("PTRACE_UNIT_MIN_ROUNDS")) : 0;
       const int min_rounds = env_minr != 0 ? env_minr : (a.pcg_mode == PT_PCG_SAMPLE ? -2 : 16);  // (< 0: see unit_ppu)
+      // The flagged pixels from which the one-queue kernel takes the frame (q_alt): where its estimate falls below the tree
+      // kernel's.  Both fitted to measurements on the MI355X (tools/tree_vs_queue.py, profiles/r04_tree_vs_queue.txt: 17
+      // frames of three scenes, N = 2 ... 20, D = 2 ... 3; ns per flagged pixel and sample):
+      //   tree kernel       F x tT,  tT = 4.5 + 0.045 min(R, 500)   (R = sum of N^d, the rays of a full tree: one pixel at a
+      //                     time on each of the 8 n_cu resident waves, a handful of rounds per family of children)
+      //   one-queue kernel  R x step + F x tQ,  step = 7 + 0.16 n_shapes us (its deepest lane: R dependent steps of a wave-
+      //                     uniform loop over every shape),  tQ = (0.6 + 0.012 n_shapes)(1 + R / 400)
+      long long q_min = -1;
+      if (q_alt) {
+        static const long long env_qmin = getenv("PTRACE_Q_MIN_FLAGGED") ? atoll(getenv("PTRACE_Q_MIN_FLAGGED")) : -1;
+        double tree_rays = 1.0, pw = 1.0;
+        for (int d = 1; d <= std::max(p->max_depth, 0); ++d) {
+          pw *= (double)p->num_of_rays;
+          tree_rays += pw;
+        }
+        const double step_ns = (7.0 + 0.16 * s->n_shapes) * 1e3;
+        const double t_tree = (4.5 + 0.045 * std::min(tree_rays, 500.0)) * (2048.0 / (8.0 * s->n_cu));
+        const double t_queue = (0.6 + 0.012 * s->n_shapes) * (1.0 + tree_rays / 400.0);
+        if (t_tree > t_queue) q_min = (long long)std::min(1e15, 1.1 * tree_rays * step_ns / (t_tree - t_queue));
+        if (env_qmin >= 0) q_min = env_qmin;
+        if (env_qchoice == 2) q_min = 0;
+      }
       if (tree)  // one pixel per unit: "64 lanes per pixel, whatever the number of flagged pixels"
         hipLaunchKernelGGL(pt_unit_scatter, dim3((nregions + PT_SCATTER_BLOCK - 1) / PT_SCATTER_BLOCK), dim3(PT_SCATTER_BLOCK), 0, st, s->region_keys, s->region_mask, nregions, s->units, s->units_cap,
-                           s->queue_last, (long long)1 << 60, 64, 1);
+                           s->queue_last, (long long)1 << 60, 64, 1, q_min);
       else
       hipLaunchKernelGGL(pt_unit_scatter, dim3((nregions + PT_SCATTER_BLOCK - 1) / PT_SCATTER_BLOCK), dim3(PT_SCATTER_BLOCK), 0, st, s->region_keys, s->region_mask, nregions, s->units, s->units_cap,
                          s->queue_last, lanes_cap, nsamp, min_rounds);
@@ -1391,11 +1438,11 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
       if (tree && small_world) {
         s->stats.kernel = PT_KERNEL_PATH_TREE;
         HIP_TRY(path_lds_limit((const void *)pt_path_tree_kernel<true>, lds + frame_lds + diag_lds_bytes));
-        PT_LAUNCH((pt_path_tree_kernel<true>), grid, lds + frame_lds + diag_lds_bytes, true, a);
+        PT_LAUNCH((pt_path_tree_kernel<true>), grid, lds + frame_lds + diag_lds_bytes, !q_alt, a);
       } else if (tree) {
         s->stats.kernel = PT_KERNEL_PATH_TREE;
         HIP_TRY(path_lds_limit((const void *)pt_path_tree_kernel<false>, lds + frame_lds + diag_lds_bytes));
-        PT_LAUNCH((pt_path_tree_kernel<false>), grid, lds + frame_lds + diag_lds_bytes, true, a);
+        PT_LAUNCH((pt_path_tree_kernel<false>), grid, lds + frame_lds + diag_lds_bytes, !q_alt, a);
       } else if (lds_frames && a.scene_lds >= 0 && small_world) {
         HIP_TRY(path_lds_limit((const void *)pt_path_regions_kernel<true, true, 1>, lds + frame_lds + diag_lds_bytes));
         PT_LAUNCH((pt_path_regions_kernel<true, true, 1>), grid, lds + frame_lds + diag_lds_bytes, true, a);
@@ -1411,6 +1458,35 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
       } else {
         HIP_TRY(path_lds_limit((const void *)pt_path_regions_kernel<false>, lds + diag_lds_bytes));
         PT_LAUNCH((pt_path_regions_kernel<false>), grid, lds + diag_lds_bytes, true, a);
+      }
+      if (q_alt) {
+        // ... and the one-queue kernel behind it, with an argument block of its own (a lane per pixel: 20 doubles per depth
+        // and lane in LDS, its own grid, its own slots for the ray counts); it returns at once unless PT_Q_CHOICE says 1
+        PtKArgs aq = a;
+        aq.cold = s->args_dev2;
+        aq.nthreads = grid_q * PT_BLOCK;
+        aq.frame_doubles = 20;
+        aq.p_max_path = 48;
+        aq.s_min_path = 16;
+        aq.count_base = grid + grid_first;
+        aq.diag_lds = -1;
+        aq.scene_lds = -1;
+        aq.grid_occ_lds = -1;
+        PtKArgs cold2 = aq;
+        cold2.out = nullptr;
+        cold2.qpar = 0;
+        if (!(s->args2_valid && s->args2_stream == st && memcmp(&s->args2_last, &cold2, sizeof cold2) == 0)) {
+          HIP_TRY(hipMemcpyAsync(s->args_dev2, &cold2, sizeof cold2, hipMemcpyHostToDevice, st));
+          s->args2_last = cold2;
+          s->args2_valid = true;
+          s->args2_stream = st;
+        }
+        HIP_TRY(path_lds_limit((const void *)pt_path_kernel<true, true>, q_frame_lds));
+        const void *tree_fn = main_fn;
+        PT_LAUNCH((pt_path_kernel<true, true>), grid_q, q_frame_lds, true, aq);
+        main_fn = tree_fn;  // (pt_stats.vgprs: the tree kernel's; pt_stats.kernel follows the device's choice, see fold_stats)
+        HIP_TRY(hipMemcpyAsync(s->ray_counter_host + 2, s->queue_last + PT_Q_CHOICE, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        s->choice_pending = true;
       }
     }
   } else {
@@ -1472,12 +1548,14 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
     s->stats_valid = false;
   }
   if (s->count_rays) {
-    hipLaunchKernelGGL(pt_sum_counts, dim3(1), dim3(256), 0, st, s->ray_partials, grid + grid_first, s->ray_counter);
+    hipLaunchKernelGGL(pt_sum_counts, dim3(1), dim3(256), 0, st, s->ray_partials, grid + grid_first + grid_q, s->ray_counter);
     HIP_TRY(hipMemcpyAsync(s->ray_counter_host, s->ray_counter, 2 * sizeof(unsigned long long),
                            hipMemcpyDeviceToHost, st));
     // ev1 was recorded BEFORE the count left the device: whoever reads ray_counter_host waits for this one
     HIP_TRY(hipEventRecord(s->ev_count, st));
     s->count_pending = true;
+  } else if (s->choice_pending) {
+    HIP_TRY(hipEventRecord(s->ev_count, st));
   }
   return PT_OK;
 }
@@ -1499,13 +1577,17 @@ static int fold_stats(pt_scene *s) {
   } else {
     s->stats.kernel_ms = s->stats.total_ms = 0.0;
   }
+  if (s->count_pending || s->choice_pending) HIP_TRY(hipEventSynchronize(s->ev_count));
   if (s->count_pending) {
-    HIP_TRY(hipEventSynchronize(s->ev_count));
     s->count_pending = false;
     s->stats.n_rays = s->ray_counter_host[0];
     s->stats.n_rays_resolved = s->ray_counter_host[1];
   } else {
     s->stats.n_rays = s->stats.n_rays_resolved = 0;  // (no pixels, or counting off)
+  }
+  if (s->choice_pending) {  // which of the two enqueued second-pass kernels the device let work (PT_Q_CHOICE)
+    s->choice_pending = false;
+    s->stats.kernel = s->ray_counter_host[2] ? PT_KERNEL_PATH : PT_KERNEL_PATH_TREE;
   }
   s->pending = false;
   s->pending_copy = false;

@@ -185,3 +185,32 @@ def test_jittered_primary_renderers_with_more_samples_than_lanes(dev, oracle, re
             else:
                 assert util.bits_equal(out, ora), (S, mode)
             assert int(st.n_rays) == n
+
+
+def test_num_of_rays_above_one_the_device_picks_the_second_pass_by_the_flagged_pixels(dev, oracle):
+    """num_of_rays > 1 (main.py:95-102): both second-pass kernels are enqueued and the device lets ONE work, chosen from F,
+    the flagged pixels the first pass counted (PT_Q_CHOICE) -- the tree kernel (one pixel per wave) where they are few, the
+    one-queue kernel (a lane per flagged pixel) where the frame is full of them.  Same frame either way: against the oracle,
+    and the dense frame cut over three ranks (each shard decides for itself) equals the whole."""
+    W, H = 640, 360
+    kw = dict(samples_per_side=1, num_of_rays=3, max_depth=2, rr_limit=3, path_state=45, path_seq=54)
+    dense, cam = _synthetic(32, True, False, W, H)    # a ground plane: every pixel below the horizon is flagged
+    sparse, _ = _synthetic(32, False, False, W, H)    # spheres in front of a sky: 3 % of the pixels
+    if __import__("os").environ.get("PTRACE_QCHOICE", "1") != "1":
+        pytest.skip("the choice is forced by PTRACE_QCHOICE")
+    for scene, want_kernel in ((dense, abi.KERNEL_PATH), (sparse, abi.KERNEL_PATH_TREE)):
+        par = abi.make_params(W, H, abi.RENDERER_PATHTRACER, **kw)
+        with dev.DeviceScene(scene) as ds:
+            out = ds.render(cam, par)
+            st = ds.stats()
+            assert st.kernel == want_kernel, (st.kernel, want_kernel)
+            if scene is dense:
+                got = np.zeros_like(out)
+                n_sum = 0
+                for rank in range(3):
+                    p = abi.copy_params(par, n_ranks=3, rank=rank, row_block=8)
+                    got[abi.rows_for_rank(H, 8, 3, rank)] = ds.render(cam, p)
+                    n_sum += int(ds.stats().n_rays)
+                assert util.bits_equal(got, out) and n_sum == int(st.n_rays)
+        ora, n = _oracle(oracle, scene, cam, par)
+        _path_check(f"N=3 D=2 {'dense' if scene is dense else 'sparse'}", out, ora, st.n_rays, n, 3, W * H)
