@@ -33,6 +33,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# (importing pytracer_amd does this too; said here because it must precede the process's first HIP call: kernel arguments in
+#  device memory, profiles/r04_dev_kernarg.txt)
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402

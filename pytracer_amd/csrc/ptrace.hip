@@ -30,6 +30,12 @@
 // OnOff / Flat / PointLight at any samples_per_side); a caller built against an older header checks pt_version() first.
 #define PT_VERSION ((1 << 16) | 3)
 
+// Kernel arguments in DEVICE memory: by default the HIP runtime keeps the kernarg segment in host memory, and the first
+// scalar load of every wave of a launch then crosses the host link (~1.5 us of a 14-us frame: profiles/r04_dev_kernarg.txt).
+// The runtime reads the variable when it initialises, so this runs when the library is loaded -- a caller that links
+// libptrace.so (or dlopens it before its first HIP call) gets it; one that has set the variable itself keeps its choice.
+__attribute__((constructor)) static void pt_prefer_device_kernargs() { setenv("HIP_FORCE_DEV_KERNARG", "1", 0); }
+
 static thread_local char g_err[512] = "";
 
 static int fail(int code, const char *fmt, ...) {
@@ -909,6 +915,9 @@ static void fill_cone_model(PtKArgs &a, const pt_camera *cam, int width, int hei
 // frame's first launch carries the start event and its last one the stop event IN the dispatch itself
 // (hipExtLaunchKernelGGL: the events take the kernel's own begin / end timestamps), so a timed frame costs no
 // barrier packet on the stream and the interval holds the frame's kernels, not the launch gaps around them.
+#ifndef PT_WAVES_POINTLIGHT
+#define PT_WAVES_POINTLIGHT 3  // waves per SIMD pt_tile_kernel<POINTLIGHT> is compiled for (register budget 512 / that)
+#endif
 #define PT_LAUNCH(KERNEL, GRID, LDS, LAST, ...)                                                              \
   do {                                                                                                       \
     main_fn = (const void *)(KERNEL);                                                                        \
@@ -1374,7 +1383,7 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
       else if (p->renderer == PT_RENDERER_FLAT)
         PT_LAUNCH((pt_tile_kernel<PT_RENDERER_FLAT, 4, true>), tgrid, lds, !path_tiled, a, 0);
       else if (p->renderer == PT_RENDERER_POINTLIGHT)
-        PT_LAUNCH((pt_tile_kernel<PT_RENDERER_POINTLIGHT, 3, true>), tgrid, lds, !path_tiled, a, 0);
+        PT_LAUNCH((pt_tile_kernel<PT_RENDERER_POINTLIGHT, PT_WAVES_POINTLIGHT, true>), tgrid, lds, !path_tiled, a, 0);
       else
         PT_LAUNCH((pt_tile_kernel<PT_RENDERER_PATHTRACER, 4, true>), tgrid, lds, !path_tiled, a, grid);
     } else if (ortho) {
@@ -1383,7 +1392,7 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
       else if (p->renderer == PT_RENDERER_FLAT)
         PT_LAUNCH((pt_tile_kernel<PT_RENDERER_FLAT, 4, false, true>), tgrid, lds, !path_tiled, a, 0);
       else if (p->renderer == PT_RENDERER_POINTLIGHT)
-        PT_LAUNCH((pt_tile_kernel<PT_RENDERER_POINTLIGHT, 3, false, true>), tgrid, lds, !path_tiled, a, 0);
+        PT_LAUNCH((pt_tile_kernel<PT_RENDERER_POINTLIGHT, PT_WAVES_POINTLIGHT, false, true>), tgrid, lds, !path_tiled, a, 0);
       else
         PT_LAUNCH((pt_tile_kernel<PT_RENDERER_PATHTRACER, 4, false, true>), tgrid, lds, !path_tiled, a, grid);
     } else if (p->renderer == PT_RENDERER_ONOFF)
@@ -1391,7 +1400,7 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
     else if (p->renderer == PT_RENDERER_FLAT)
       PT_LAUNCH((pt_tile_kernel<PT_RENDERER_FLAT, 4, false>), tgrid, lds, !path_tiled, a, 0);
     else if (p->renderer == PT_RENDERER_POINTLIGHT)
-      PT_LAUNCH((pt_tile_kernel<PT_RENDERER_POINTLIGHT, 3, false>), tgrid, lds, !path_tiled, a, 0);
+      PT_LAUNCH((pt_tile_kernel<PT_RENDERER_POINTLIGHT, PT_WAVES_POINTLIGHT, false>), tgrid, lds, !path_tiled, a, 0);
     else
     {
       if (a.npass >= 2 && s->dome_shortcut && a.block_h > 1)  // (big frames: blocks of strips, see a.block_h above)
@@ -1409,8 +1418,8 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
       // frames of three scenes, N = 2 ... 20, D = 2 ... 3; ns per flagged pixel and sample):
       //   tree kernel       F x tT,  tT = 4.5 + 0.045 min(R, 500)   (R = sum of N^d, the rays of a full tree: one pixel at a
       //                     time on each of the 8 n_cu resident waves, a handful of rounds per family of children)
-      //   one-queue kernel  R x step + F x tQ,  step = 7 + 0.16 n_shapes us (its deepest lane: R dependent steps of a wave-
-      //                     uniform loop over every shape),  tQ = (0.6 + 0.012 n_shapes)(1 + R / 400)
+      //   one-queue kernel  R x step + F x tQ,  step = 6 + 0.02 n_shapes us (its deepest lane: R dependent steps, scattered rays
+      //                     on per-lane candidate lists),  tQ = (0.5 + 0.01 n_shapes)(1 + R / 800)
       long long q_min = -1;
       if (q_alt) {
         static const long long env_qmin = getenv("PTRACE_Q_MIN_FLAGGED") ? atoll(getenv("PTRACE_Q_MIN_FLAGGED")) : -1;
@@ -1419,9 +1428,9 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
           pw *= (double)p->num_of_rays;
           tree_rays += pw;
         }
-        const double step_ns = (7.0 + 0.16 * s->n_shapes) * 1e3;
+        const double step_ns = (6.0 + 0.02 * s->n_shapes) * 1e3;
         const double t_tree = (4.5 + 0.045 * std::min(tree_rays, 500.0)) * (2048.0 / (8.0 * s->n_cu));
-        const double t_queue = (0.6 + 0.012 * s->n_shapes) * (1.0 + tree_rays / 400.0);
+        const double t_queue = (0.5 + 0.01 * s->n_shapes) * (1.0 + tree_rays / 800.0);
         if (t_tree > t_queue) q_min = (long long)std::min(1e15, 1.1 * tree_rays * step_ns / (t_tree - t_queue));
         if (env_qmin >= 0) q_min = env_qmin;
         if (env_qchoice == 2) q_min = 0;
@@ -1469,9 +1478,13 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
         aq.p_max_path = 48;
         aq.s_min_path = 16;
         aq.count_base = grid + grid_first;
-        aq.diag_lds = -1;
         aq.scene_lds = -1;
         aq.grid_occ_lds = -1;
+        // the scale+translate records behind the frame stack when they fit (world_query_lanes gathers them per lane)
+        const size_t q_diag_bytes = (size_t)s->n_diag * sizeof(PtDiagRec);
+        const bool q_diag = s->n_diag > 0 && q_diag_bytes <= 48 * 1024 && q_frame_lds + q_diag_bytes <= PT_LDS_BUDGET;
+        aq.diag_lds = q_diag ? (int)(q_frame_lds / 8) : -1;
+        const size_t q_lds = q_frame_lds + (q_diag ? q_diag_bytes : 0);
         PtKArgs cold2 = aq;
         cold2.out = nullptr;
         cold2.qpar = 0;
@@ -1481,9 +1494,18 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
           s->args2_valid = true;
           s->args2_stream = st;
         }
-        HIP_TRY(path_lds_limit((const void *)pt_path_kernel<true, true>, q_frame_lds));
         const void *tree_fn = main_fn;
-        PT_LAUNCH((pt_path_kernel<true, true>), grid_q, q_frame_lds, true, aq);
+        static const int env_qlat = getenv("PTRACE_Q_LANES") ? atoi(getenv("PTRACE_Q_LANES")) : 1;  // 0: the wave-uniform shape loop (pt_path_kernel<true, true>)
+        if (!env_qlat) {
+          HIP_TRY(path_lds_limit((const void *)pt_path_kernel<true, true>, q_lds));
+          PT_LAUNCH((pt_path_kernel<true, true>), grid_q, q_lds, true, aq);
+        } else if (small_world) {
+          HIP_TRY(path_lds_limit((const void *)pt_path_flagged_kernel<1>, q_lds));
+          PT_LAUNCH((pt_path_flagged_kernel<1>), grid_q, q_lds, true, aq);
+        } else {
+          HIP_TRY(path_lds_limit((const void *)pt_path_flagged_kernel<0>, q_lds));
+          PT_LAUNCH((pt_path_flagged_kernel<0>), grid_q, q_lds, true, aq);
+        }
         main_fn = tree_fn;  // (pt_stats.vgprs: the tree kernel's; pt_stats.kernel follows the device's choice, see fold_stats)
         HIP_TRY(hipMemcpyAsync(s->ray_counter_host + 2, s->queue_last + PT_Q_CHOICE, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         s->choice_pending = true;
