@@ -392,21 +392,31 @@ def boundary_rows(flat, device: int, rays_per_frame: int):
             self.width, self.height = w, h
             self.pixels = [RefColor() for _ in range(w * h)]
 
+    t0 = time.perf_counter()
     img = RefImage(W, H)
+    rows["python_hdrimage_constructor_ms"] = (time.perf_counter() - t0) * 1e3  # (what HdrImage(W, H) itself costs: hdrimages.py:70)
     frame64 = np.asarray(out, dtype=np.float64)
     t0 = time.perf_counter()
     _fill_image(img, frame64)
-    rows["python_hdrimage_fill_ms"] = (time.perf_counter() - t0) * 1e3
+    rows["python_hdrimage_first_fill_ms"] = (time.perf_counter() - t0) * 1e3
     t0 = time.perf_counter()
     px = img.pixels[W * 360 + 640]
     rows["python_hdrimage_first_pixel_read_us"] = (time.perf_counter() - t0) * 1e6
+    ts = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        _fill_image(img, frame64)
+        ts.append((time.perf_counter() - t0) * 1e3)
+    rows["python_hdrimage_fill_ms"] = float(np.median(ts))
     img2 = RefImage(W, H)
     t0 = time.perf_counter()
     _fill_image(img2, frame64, eager=True)
     rows["python_hdrimage_eager_fill_ms"] = (time.perf_counter() - t0) * 1e3
     rows["python_hdrimage_note"] = ("handing a frame to a reference-style HdrImage (a list of W*H Color objects, hdrimages.py:70): "
                                     "`fill` installs pytracer_amd.pixels.LazyPixels over the numpy frame (a Color is made when an "
-                                    "index is first read and kept from then on), `eager_fill` builds all 921 600 objects "
+                                    "index is first read and kept from then on); `first_fill` is the same on a freshly constructed "
+                                    "image and is dominated by FREEING the 921 600 black Color objects its constructor made "
+                                    "(`constructor_ms`: not this library's); `eager_fill` builds all 921 600 objects "
                                     "(GpuImageTracer(eager_fill=True), round 3's only way)")
     assert (px.r, px.g, px.b) == tuple(frame64[360, 640].tolist())
     ds.close()

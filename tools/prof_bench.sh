@@ -38,11 +38,22 @@ KB="python3 $ROOT/tools/kbench.py c3n10 --rounds 4"
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $OUT/pmc_tree -- $KB > $OUT/pmc_tree.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_LDS SQ_INSTS_SMEM --output-format csv -d $OUT/pmc_tree2 -- $KB > $OUT/pmc_tree2.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_CVT SQ_INSTS_VMEM SQ_INSTS_BRANCH --output-format csv -d $OUT/pmc_tree3 -- $KB > $OUT/pmc_tree3.log 2>&1
+# primary + shadow rays (C2 scene + two point lights): pt_tile_kernel<POINTLIGHT>; orthogonal path tracing: pt_path_kernel;
+# a frame FULL of flagged pixels at the CLI's N = 10, D = 3 (C2 scene with its ground plane): pt_path_flagged_kernel
+for cfg in pl c3ortho c2n10; do
+  KB="python3 $ROOT/tools/kbench.py $cfg --rounds 4"
+  rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $OUT/pmc_$cfg -- $KB > $OUT/pmc_$cfg.log 2>&1
+  rocprofv3 --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_LDS SQ_INSTS_SMEM --output-format csv -d $OUT/pmc_${cfg}_2 -- $KB > $OUT/pmc_${cfg}_2.log 2>&1
+  rocprofv3 --pmc SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_CVT SQ_INSTS_VMEM SQ_INSTS_BRANCH --output-format csv -d $OUT/pmc_${cfg}_3 -- $KB > $OUT/pmc_${cfg}_3.log 2>&1
+done
 # C5 (10 000 spheres, Flat): HBM bytes of its two kernels (BASELINE.json configs[4] asks for rocprof HBM GB/s)
 KB="python3 $ROOT/tools/kbench.py c5 --rounds 4"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_c5f -- $KB > $OUT/pmc_c5f.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_c5w -- $KB > $OUT/pmc_c5w.log 2>&1
 cd $ROOT
+python3 tools/pmc_summary.py $OUT/pmc_pl $OUT/pmc_pl_2 $OUT/pmc_pl_3 --kernel "pt_tile_kernel<3, 3, false, false" --json $OUT/pmc_pointlight_tile.json --source "rocprofv3 --pmc (three passes) on 'python3 tools/kbench.py pl --rounds 4' (C2 scene + two point lights, PointLightRenderer: primary + shadow rays); medians over the launches; tools/prof_bench.sh $TAG" > /dev/null || true
+python3 tools/pmc_summary.py $OUT/pmc_c3ortho $OUT/pmc_c3ortho_2 $OUT/pmc_c3ortho_3 --kernel "pt_path_kernel<true, false>" --json $OUT/pmc_c3ortho_path.json --source "rocprofv3 --pmc (three passes) on 'python3 tools/kbench.py c3ortho --rounds 4' (C3 scene through an orthogonal camera: one queue over all pixels); medians over the launches; tools/prof_bench.sh $TAG" > /dev/null || true
+python3 tools/pmc_summary.py $OUT/pmc_c2n10 $OUT/pmc_c2n10_2 $OUT/pmc_c2n10_3 --kernel "pt_path_flagged_kernel" --json $OUT/pmc_c2n10_flagged.json --source "rocprofv3 --pmc (three passes) on 'python3 tools/kbench.py c2n10 --rounds 4' (C2 scene with its ground plane, PathTracer N = 10, D = 3, S = 1: 490 k flagged pixels, the device picks the one-queue kernel); medians over the launches; tools/prof_bench.sh $TAG" > /dev/null || true
 python3 tools/pmc_summary.py $OUT/pmc_c5f $OUT/pmc_c5w --kernel "pt_tile_kernel<1, 4, true, false" --json $OUT/pmc_c5_tile.json --source "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate runs) on 'python3 tools/kbench.py c5 --rounds 4' (C5: 1280x720, 10 000 spheres, Flat); medians over the launches; tools/prof_bench.sh $TAG" > /dev/null
 python3 tools/pmc_summary.py $OUT/pmc_c5f $OUT/pmc_c5w --kernel "pt_cell_kernel" --json $OUT/pmc_c5_cell.json --source "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate runs) on 'python3 tools/kbench.py c5 --rounds 4'; medians over the launches; tools/prof_bench.sh $TAG" > /dev/null
 python3 tools/pmc_summary.py $OUT/pmc_tree $OUT/pmc_tree2 $OUT/pmc_tree3 --kernel "pt_path_tree_kernel" --json $OUT/pmc_c3n10_tree.json --source "rocprofv3 --pmc (three passes) on 'python3 tools/kbench.py c3n10 --rounds 4' (C3 scene, PathTracer N = 10, D = 3, S = 1: the CLI's defaults); medians over the launches; tools/prof_bench.sh $TAG" > /dev/null
