@@ -52,7 +52,7 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_c5f -- $KB > $OUT/pmc
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_c5w -- $KB > $OUT/pmc_c5w.log 2>&1
 cd $ROOT
 python3 tools/pmc_summary.py $OUT/pmc_pl $OUT/pmc_pl_2 $OUT/pmc_pl_3 --kernel "pt_tile_kernel<3, 3, false, false" --json $OUT/pmc_pointlight_tile.json --source "rocprofv3 --pmc (three passes) on 'python3 tools/kbench.py pl --rounds 4' (C2 scene + two point lights, PointLightRenderer: primary + shadow rays); medians over the launches; tools/prof_bench.sh $TAG" > /dev/null || true
-python3 tools/pmc_summary.py $OUT/pmc_c3ortho $OUT/pmc_c3ortho_2 $OUT/pmc_c3ortho_3 --kernel "pt_path_kernel<true, false>" --json $OUT/pmc_c3ortho_path.json --source "rocprofv3 --pmc (three passes) on 'python3 tools/kbench.py c3ortho --rounds 4' (C3 scene through an orthogonal camera: one queue over all pixels); medians over the launches; tools/prof_bench.sh $TAG" > /dev/null || true
+python3 tools/pmc_summary.py $OUT/pmc_c3ortho $OUT/pmc_c3ortho_2 $OUT/pmc_c3ortho_3 --kernel "pt_path_regions_kernel" --json $OUT/pmc_c3ortho_second_pass.json --source "rocprofv3 --pmc (three passes) on 'python3 tools/kbench.py c3ortho --rounds 4' (C3 scene through an orthogonal camera: first pass with beams, second pass by regions); medians over the launches; tools/prof_bench.sh $TAG" > /dev/null || true
 python3 tools/pmc_summary.py $OUT/pmc_c2n10 $OUT/pmc_c2n10_2 $OUT/pmc_c2n10_3 --kernel "pt_path_flagged_kernel" --json $OUT/pmc_c2n10_flagged.json --source "rocprofv3 --pmc (three passes) on 'python3 tools/kbench.py c2n10 --rounds 4' (C2 scene with its ground plane, PathTracer N = 10, D = 3, S = 1: 490 k flagged pixels, the device picks the one-queue kernel); medians over the launches; tools/prof_bench.sh $TAG" > /dev/null || true
 python3 tools/pmc_summary.py $OUT/pmc_c5f $OUT/pmc_c5w --kernel "pt_tile_kernel<1, 4, true, false" --json $OUT/pmc_c5_tile.json --source "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate runs) on 'python3 tools/kbench.py c5 --rounds 4' (C5: 1280x720, 10 000 spheres, Flat); medians over the launches; tools/prof_bench.sh $TAG" > /dev/null
 python3 tools/pmc_summary.py $OUT/pmc_c5f $OUT/pmc_c5w --kernel "pt_cell_kernel" --json $OUT/pmc_c5_cell.json --source "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate runs) on 'python3 tools/kbench.py c5 --rounds 4'; medians over the launches; tools/prof_bench.sh $TAG" > /dev/null
