@@ -656,10 +656,10 @@ def run_single(args, local_rank):
     if args.in_flight:
         result["frames_in_flight"] = in_flight_rows(flat, cam, par, args.steps, local_rank, rays_per_step, pmc, n_simd, clock_hz)
     else:  # (not measured by this command -- its launches run back to back --: the committed line of `bench.py --in-flight`)
-        committed = load_profile("r03_bench_in_flight.json")
+        committed = load_profile("r04_bench_in_flight.json")
         if committed is not None and "frames_in_flight" in committed:
             result["frames_in_flight_committed"] = dict(committed["frames_in_flight"],
-                                                        source="profiles/r03_bench_in_flight.json = `python bench.py --in-flight "
+                                                        source="profiles/r04_bench_in_flight.json = `python bench.py --in-flight "
                                                                "--no-extras --no-cpu-baseline` on one MI355X; NOT measured by this run")
     if not args.no_extras:
         result["extra"] = extra_rows(local_rank)

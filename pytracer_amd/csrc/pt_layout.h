@@ -25,7 +25,7 @@ static_assert(sizeof(PtShapeRec) == 128, "PtShapeRec must be 128 B");
 
 struct alignas(256) PtShapeAux {
   double m[12];  // rows 0..2 of transformation.m
-  double pig_c1[3], pig_c2[3];
+  double pig_c1[3], pig_c2[3];  // (needs_uv == 0, i.e. both pigments uniform: pig_c2 = pig_c1 + emi_c1, the Flat colour of the shape)
   double emi_c1[3], emi_c2[3];
   double pig_steps, emi_steps, brdf_param;
   int32_t brdf_kind, pig_kind, emi_kind, pig_tex, emi_tex, needs_uv;

@@ -1193,21 +1193,38 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))
           rk.d = dir[k];
           rk.tmin = tmin;
           V3 p1, p2;
+          // (a shape whose two pigments are uniform carries pigment + emitted, added at upload with the same fp64
+          //  addition, in pig_c2: pt_layout.h)
           if constexpr (SLDS) {
             const pt_lds_rec rec = (pt_lds_rec)(const void *)pt_lds_f64 + hit;
             const pt_lds_aux ax = (pt_lds_aux)(const void *)(pt_lds_f64 + a.n_shapes * 16) + hit;
-            if (ax->needs_uv) hit_details(rec, ax, rk, h4.best_t[k], h, true);
-            p1 = brdf_pigment(a, ax, h.u, h.v);
-            p2 = emitted_pigment(a, ax, h.u, h.v);
+            if (ax->needs_uv) {
+              hit_details(rec, ax, rk, h4.best_t[k], h, true);
+              p1 = brdf_pigment(a, ax, h.u, h.v);
+              p2 = emitted_pigment(a, ax, h.u, h.v);
+              c.x = p1.x + p2.x;
+              c.y = p1.y + p2.y;
+              c.z = p1.z + p2.z;
+            } else {
+              c.x = ax->pig_c2[0];
+              c.y = ax->pig_c2[1];
+              c.z = ax->pig_c2[2];
+            }
           } else {
             const PtShapeAux *ax = cold_args(a)->aux + hit;
-            if (ax->needs_uv) hit_details(a.recs + hit, ax, rk, h4.best_t[k], h, true);
-            p1 = brdf_pigment(a, ax, h.u, h.v);
-            p2 = emitted_pigment(a, ax, h.u, h.v);
+            if (ax->needs_uv) {
+              hit_details(a.recs + hit, ax, rk, h4.best_t[k], h, true);
+              p1 = brdf_pigment(a, ax, h.u, h.v);
+              p2 = emitted_pigment(a, ax, h.u, h.v);
+              c.x = p1.x + p2.x;
+              c.y = p1.y + p2.y;
+              c.z = p1.z + p2.z;
+            } else {
+              c.x = ax->pig_c2[0];
+              c.y = ax->pig_c2[1];
+              c.z = ax->pig_c2[2];
+            }
           }
-          c.x = p1.x + p2.x;
-          c.y = p1.y + p2.y;
-          c.z = p1.z + p2.z;
         }
         PT_T4(6);
         if (act[k]) {

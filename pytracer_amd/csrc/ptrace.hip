@@ -440,6 +440,10 @@ extern "C" int pt_scene_upload(const pt_scene_desc *d, int device, pt_scene **ou
     x.pig_tex = d->pig_tex[i];
     x.emi_tex = d->emi_tex[i];
     x.needs_uv = (d->pig_kind[i] != PT_PIGMENT_UNIFORM || d->emi_kind[i] != PT_PIGMENT_UNIFORM) ? 1 : 0;
+    // both pigments uniform: color2 of the (uniform) BRDF pigment is never read, and the slot carries what FlatRenderer
+    // returns for the shape, pigment + emitted (render.py:65-74; the same fp64 addition the kernel would do per pixel)
+    if (!x.needs_uv)
+      for (int k = 0; k < 3; ++k) x.pig_c2[k] = x.pig_c1[k] + x.emi_c1[k];
     r.index = i;
     // |invm|_F^2 for the "camera inside this sphere" shortcut of the tile kernel; +inf disables it unless
     // every singular value of invm's 3x3 block is within 1e-6 .. 1e6 (Gershgorin bounds of invm^T invm)
