@@ -214,3 +214,45 @@ def test_num_of_rays_above_one_the_device_picks_the_second_pass_by_the_flagged_p
                 assert util.bits_equal(got, out) and n_sum == int(st.n_rays)
         ora, n = _oracle(oracle, scene, cam, par)
         _path_check(f"N=3 D=2 {'dense' if scene is dense else 'sparse'}", out, ora, st.n_rays, n, 3, W * H)
+
+
+def test_one_queue_second_pass_under_an_orthogonal_camera_with_textures_and_mirrors(dev, oracle):
+    """The one-queue alternative of the N > 1 second pass (pt_path_flagged_kernel) where it does NOT share the tree kernel's
+    assumptions: an orthogonal camera (no common origin: primary rays through the un-hoisted query), an image-textured
+    plane and sphere (uv from atan2 / acos), mirrors (no scatter draws), no dome (misses), Russian roulette from depth 1 --
+    on a frame dense enough for the device to pick it; against the oracle, and partition-invariant."""
+    from pytracer_amd import flatten, hostmodel as hm
+
+    if __import__("os").environ.get("PTRACE_QCHOICE", "1") != "1":
+        pytest.skip("the choice is forced by PTRACE_QCHOICE")
+    g = hm.PCG(99, 1)
+    r = g.random_float
+    tex = hm.HdrImage(8, 4)
+    tex.set_array(np.array([[[r(), r(), r()] for _ in range(8)] for _ in range(4)]))
+    w = hm.World()
+    w.add_shape(hm.Plane(hm.translation(hm.Vec(0.0, 0.0, -0.6)),
+                         hm.Material(hm.DiffuseBRDF(hm.ImagePigment(tex)), hm.CheckeredPigment(hm.BLACK, hm.Color(0.2, 0.2, 0.2), 3))))
+    w.add_shape(hm.Sphere(hm.translation(hm.Vec(1.0, 0.3, 0.2)) * hm.rotation_y(25.0) * hm.scaling(hm.Vec(0.7, 0.5, 0.6)),
+                          hm.Material(hm.DiffuseBRDF(hm.ImagePigment(tex)), hm.UniformPigment(hm.Color(0.05, 0.0, 0.1)))))
+    w.add_shape(hm.Sphere(hm.translation(hm.Vec(0.5, -0.8, 0.0)) * hm.scaling(hm.Vec(0.3, 0.3, 0.3)),
+                          hm.Material(hm.SpecularBRDF(hm.UniformPigment(hm.Color(0.9, 0.8, 0.7))))))
+    w.add_shape(hm.Sphere(hm.translation(hm.Vec(0.2, 0.9, -0.2)) * hm.scaling(hm.Vec(0.35, 0.35, 0.35)),
+                          hm.Material(hm.DiffuseBRDF(hm.UniformPigment(hm.Color(0.3, 0.7, 0.4))), hm.UniformPigment(hm.Color(0.4, 0.3, 0.1)))))
+    scene = flatten.flatten_world(w)
+    W, H = 480, 360
+    for cam_obj in (hm.OrthogonalCamera(W / H, hm.translation(hm.Vec(-1.0, 0.0, 0.4)) * hm.rotation_y(20.0)),
+                    hm.PerspectiveCamera(1.2, W / H, hm.translation(hm.Vec(-1.5, 0.0, 0.5)) * hm.rotation_y(15.0))):
+        cam = flatten.flatten_camera(cam_obj)
+        par = abi.make_params(W, H, abi.RENDERER_PATHTRACER, samples_per_side=2, num_of_rays=3, max_depth=3, rr_limit=1,
+                              pcg_mode=abi.PCG_PIXEL, path_state=45, path_seq=54, background=(0.05, 0.1, 0.3))
+        with dev.DeviceScene(scene) as ds:
+            out = ds.render(cam, par)
+            st = ds.stats()
+            got = np.zeros_like(out)
+            for rank in range(2):
+                p = abi.copy_params(par, n_ranks=2, rank=rank, row_block=24)
+                got[abi.rows_for_rank(H, 24, 2, rank)] = ds.render(cam, p)
+        assert st.kernel == abi.KERNEL_PATH, st.kernel
+        ora, n = _oracle(oracle, scene, cam, par)
+        _path_check(f"one-queue second pass, {type(cam_obj).__name__}", out, ora, st.n_rays, n, 4, W * H)
+        assert util.bits_equal(got, out)
