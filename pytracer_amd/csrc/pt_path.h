@@ -608,25 +608,67 @@ PT_DEV void path_trace(const PtKArgs &a) {
           const int dbg_vbase0 = vbase;
           int dbg_fin = 0;
 #endif
+          // What the walk reads of a lane: radiance, whether its sample finished, its rays, and (PT_PCG_PIXEL) the sample's
+          // index, draws, start and end state.  With the frame stack in LDS the lanes PARK these in slot 0 of it -- no lane is
+          // inside a path at the end of a round, the stack is empty -- and the walk reads them from there: one LDS read per
+          // value instead of two cross-lane permutes per double (the walk was 17 - 22 % of the second pass's cycles under
+          // PT_PCG_SAMPLE: 16 turns for a pixel with 16 lanes).
+          const int park = w.lds_base + (int)(threadIdx.x & ~63u);  // field f of lane l of this wave: park + f * PT_BLOCK + l
+          if (LDSF) {
+            const int me = park + lane;
+            pt_lds_f64[me] = ret.x;
+            pt_lds_f64[me + PT_BLOCK] = ret.y;
+            pt_lds_f64[me + 2 * PT_BLOCK] = ret.z;
+            // (fin | sample index, 23 bits: S <= 1024 | the draws' low byte, all that `hist` keeps | rays of the sample)
+            pt_lds_masks[me + 3 * PT_BLOCK] = (unsigned long long)(fin ? 1u : 0u) | ((unsigned long long)((unsigned)samp & 0x7fffffu) << 1) |
+                                              ((unsigned long long)(pcg.n & 0xffu) << 24) | ((unsigned long long)srays << 32);
+            if (pcg_mode != PT_PCG_SAMPLE) {
+              pt_lds_masks[me + 4 * PT_BLOCK] = st_start;
+              pt_lds_masks[me + 5 * PT_BLOCK] = pcg.state;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          }
           for (int jj = 0; jj < L; ++jj) {
             const int src = (leader + jj) & 63;
-            uint64_t s_from = 0, s_to = 0;  // (PT_PCG_SAMPLE validates nothing: five cross-lane reads less per turn)
-            unsigned s_draws = 0;
-            if (pcg_mode != PT_PCG_SAMPLE) {
-              s_from = __shfl((unsigned long long)st_start, src, 64);
-              s_to = __shfl((unsigned long long)pcg.state, src, 64);
-              s_draws = (unsigned)__shfl((int)pcg.n, src, 64);
+            uint64_t s_from = 0, s_to = 0;  // (PT_PCG_SAMPLE validates nothing: no states, no draws)
+            unsigned s_draws = 0, s_rays;
+            int s_fin, s_samp = 0;
+            double rx_, ry_, rz_;
+            if (LDSF) {
+              const int at = park + src;
+              const unsigned long long meta = pt_lds_masks[at + 3 * PT_BLOCK];
+              rx_ = pt_lds_f64[at];
+              ry_ = pt_lds_f64[at + PT_BLOCK];
+              rz_ = pt_lds_f64[at + 2 * PT_BLOCK];
+              s_fin = (int)(meta & 1ULL);
+              s_samp = (int)((meta >> 1) & 0x7fffffULL);
+              s_draws = (unsigned)(meta >> 24) & 0xffu;
+              s_rays = (unsigned)(meta >> 32);
+              if (pcg_mode != PT_PCG_SAMPLE) {
+                s_from = pt_lds_masks[at + 4 * PT_BLOCK];
+                s_to = pt_lds_masks[at + 5 * PT_BLOCK];
+              }
+            } else {
+              if (pcg_mode != PT_PCG_SAMPLE) {
+                s_from = __shfl((unsigned long long)st_start, src, 64);
+                s_to = __shfl((unsigned long long)pcg.state, src, 64);
+                s_draws = (unsigned)__shfl((int)pcg.n, src, 64);
+                s_samp = __shfl(samp, src, 64);
+              }
+              s_fin = __shfl((int)fin, src, 64);
+              s_rays = (unsigned)__shfl((int)srays, src, 64);
+              rx_ = __shfl(ret.x, src, 64);
+              ry_ = __shfl(ret.y, src, 64);
+              rz_ = __shfl(ret.z, src, 64);
             }
-            const int s_fin = __shfl((int)fin, src, 64);
-            const unsigned s_rays = (unsigned)__shfl((int)srays, src, 64);
-            const double rx_ = __shfl(ret.x, src, 64), ry_ = __shfl(ret.y, src, 64), rz_ = __shfl(ret.z, src, 64);
             if (pcg_mode == PT_PCG_SAMPLE) {
               chain = chain && s_fin != 0;
             } else {
               // the lane's sample counts iff it is the NEXT one (its level = the samples committed so far this round) and it
               // started from the state the sequential program is in; lanes come level by level, so a hypothesis that was
               // wrong (or a level already settled by an earlier lane) is passed over and the walk goes on
-              const int s_samp = __shfl(samp, src, 64);
               chain = s_fin != 0 && s_samp == vbase && s_from == vstate;
             }
 #ifdef PT_DEBUG_TIME
@@ -642,10 +684,12 @@ PT_DEV void path_trace(const PtKArgs &a) {
                 cum.y = ry_;
                 cum.z = rz_;
               }
-              vstate = s_to;
-              if (vbase >= hperiod)  // which guess would have been right for this sample: its upper neighbour's draws, or its predecessor's?
-                pscore += (int)(((unsigned)(hist >> (8 * (hperiod - 1))) & 0xffu) == (s_draws & 0xffu)) - (int)(((unsigned)hist & 0xffu) == (s_draws & 0xffu));
-              hist = (hist << 8) | (uint64_t)(s_draws & 0xffu);
+              if (pcg_mode != PT_PCG_SAMPLE) {
+                vstate = s_to;
+                if (vbase >= hperiod)  // which guess would have been right for this sample: its upper neighbour's draws, or its predecessor's?
+                  pscore += (int)(((unsigned)(hist >> (8 * (hperiod - 1))) & 0xffu) == (s_draws & 0xffu)) - (int)(((unsigned)hist & 0xffu) == (s_draws & 0xffu));
+                hist = (hist << 8) | (uint64_t)(s_draws & 0xffu);
+              }
               prays += s_rays;
               vbase++;
 #ifdef PT_DEBUG_TIME
@@ -796,8 +840,10 @@ PT_DEV void path_trace(const PtKArgs &a) {
           pix = -1;
           if (in_unit) {
             const int bit = nth_set_bit(todo, first + pidx);
-            pix = (long long)(ry * PT_REGION + (bit >> 3)) * W + (rx * PT_REGION + (bit & 7));
-            pixel_coords(a, pix, col, grow);
+            const int lrow = ry * PT_REGION + (bit >> 3);
+            col = rx * PT_REGION + (bit & 7);
+            pix = (long long)lrow * W + col;
+            grow = global_row(a, lrow);  // (pixel_coords would divide the 64-bit index by W to find what is known here)
             gpix = (unsigned long long)grow * ca->W + col;
             if (pcg_mode != PT_PCG_SAMPLE) {
               pcg_seed(pcg, ca->s0, ca->q0 + gpix);
