@@ -54,7 +54,8 @@ int main(int argc, char **argv) {
     int32_t brdf_kind[N] = {PT_BRDF_DIFFUSE, PT_BRDF_DIFFUSE}, pig_kind[N] = {PT_PIGMENT_UNIFORM, PT_PIGMENT_CHECKERED};
     int32_t emi_kind[N] = {PT_PIGMENT_UNIFORM, PT_PIGMENT_UNIFORM}, tex[N] = {-1, -1};
     double brdf_param[N] = {0.0, 0.0}, steps[N] = {1.0, 4.0}, esteps[N] = {1.0, 1.0};
-    double pig_c1[3 * N] = {0.9, 0.3, 0.2, 0.5, 0.1, 0.1}, pig_c2[3 * N] = {0.0, 0.1, 0.0, 0.2, 0.0, 0.5};
+    /* colours are channel-major: channel k of shape i at c[k * n + i] */
+    double pig_c1[3 * N] = {0.9, 0.5, 0.3, 0.1, 0.2, 0.1}, pig_c2[3 * N] = {0.0, 0.2, 0.0, 0.0, 0.0, 0.5};
     double emi_c1[3 * N] = {0.125, 0.0, 0.0, 0.0, 0.0, 0.0}, emi_c2[3 * N] = {0, 0, 0, 0, 0, 0};
     pt_scene_desc d;
     memset(&d, 0, sizeof d);
