@@ -134,10 +134,11 @@ def cli():
 @click.option("--pcg-mode", type=click.Choice(["auto", "seq", "pixel", "sample"]), default="auto",
               help="Random streams.  auto (default): onoff / flat / pointlight draw their jitter from the reference's own "
                    "sequential stream PCG(42, 54) -- the frame `python -m pytracer render` writes with the same flags, bit "
-                   "for bit -- and pathtracing uses one generator per pixel (its scattering stream is serial in the "
-                   "reference; the per-pixel alignment is what its CLI frames are pinned in).  seq: the reference's stream "
-                   "(refused for pathtracing).  pixel / sample: one generator per pixel / per sample (samples of a pixel "
-                   "independent: several times faster with --samples-per-pixel > 1).")
+                   "for bit -- and pathtracing uses one generator per sample (its scattering stream is serial in the "
+                   "reference and cannot be reproduced in parallel; per-sample and per-pixel generators are both pinned by "
+                   "reference-held frames and coincide at the default --samples-per-pixel 1).  seq: the reference's stream "
+                   "(refused for pathtracing).  pixel: one generator per pixel, consumed in program order (slower with "
+                   "--samples-per-pixel > 1: a pixel's samples then depend on each other).  sample: one per sample.")
 @click.option("--host-postprocess", is_flag=True, default=False,
               help="Copy the fp64 frame to the host first and post-process there (the round-2 behaviour; same bytes).")
 @click.argument("input_scene_name", type=str)

@@ -141,13 +141,17 @@ def test_drop_in_default_is_the_reference_stream_and_advances_the_tracers_pcg(de
     ora2, _ = oracle.render(scene, cam, abi.copy_params(par, jitter_state=js, jitter_seq=jq), sqr_mode=oracle.SQR_MUL)
     oracle.set_sqr_mode(oracle.SQR_POW)
     assert util.bits_equal(image.array, ora2) and not util.bits_equal(image.array, first)
-    # the path tracer keeps its per-pixel alignment under "auto", and "seq" is refused for it
+    # the path tracer takes one generator per sample under "auto" (one per pixel on request), and "seq" is refused for it
     pt = hm.PathTracer(world, pcg=hm.PCG(45, 54), num_of_rays=1, max_depth=2)
     tracer.fire_all_rays(pt)
-    par_pt = abi.make_params(W, H, abi.RENDERER_PATHTRACER, samples_per_side=S, num_of_rays=1, max_depth=2, pcg_mode=abi.PCG_PIXEL,
+    par_pt = abi.make_params(W, H, abi.RENDERER_PATHTRACER, samples_per_side=S, num_of_rays=1, max_depth=2, pcg_mode=abi.PCG_SAMPLE,
                              path_state=45, path_seq=54)
     with dev.DeviceScene(scene) as ds:
         assert util.bits_equal(image.array, ds.render(cam, par_pt))
+        px_tracer = GpuImageTracer(image, camera, samples_per_side=S, pcg_mode="pixel")
+        px_tracer.fire_all_rays(pt)
+        assert util.bits_equal(image.array, ds.render(cam, abi.copy_params(par_pt, pcg_mode=abi.PCG_PIXEL)))
+        px_tracer.close()
     with pytest.raises(Exception, match="serial"):
         GpuImageTracer(image, camera, samples_per_side=S, pcg_mode="seq").fire_all_rays(pt)
     tracer.close()
