@@ -1021,9 +1021,10 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAV
 // ... FLAGGED with the scattered rays on per-lane candidate lists (world_query_lanes) and everything inline, like the second
 // pass by regions: it runs with 20 doubles per depth and lane of frame stack in LDS -- one workgroup per CU at the CLI's
 // D = 3, one wave per SIMD --, so registers are no object and a step's latency is what counts
-template <int LEAN>
-__global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(1, 2))) void pt_path_flagged_kernel(const PtKArgs a) {
-  path_trace<false, true, true, false, LEAN, true>(a);
+// (LDSF = false: stacks deeper than the LDS holds -- D > 3 -- live in HBM, same layout; two waves per SIMD then)
+template <int LEAN, bool LDSF = true>
+__global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(LDSF ? 1 : 2, 2))) void pt_path_flagged_kernel(const PtKArgs a) {
+  path_trace<false, LDSF, true, false, LEAN, true>(a);
 }
 // second pass behind pt_tile_kernel<PATHTRACER> (perspective camera): the flagged pixels, by region
 #ifndef PT_WAVES_REGIONS

@@ -1127,13 +1127,15 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
   // FULL of them is throughput-bound and a lane per pixel, refilled from one queue, wins (profiles/r03_tree_dense_frames.txt:
   // the reference's demo scene at 1280x960, 16.3 against 10.6 ms).  Which of the two a frame is only the first pass knows
   // (F, on the device): both kernels are enqueued and pt_unit_scatter writes which one works (PT_Q_CHOICE).  The one-queue
-  // kernel takes part only where its per-lane frame stack fits the LDS (N > 1: 20 doubles per depth and lane; D <= 3).
+  // kernel keeps its per-lane frame stack (N > 1: 20 doubles per depth and lane) in LDS where that fits (D <= 3), in HBM beyond.
   static const int env_qchoice = getenv("PTRACE_QCHOICE") ? atoi(getenv("PTRACE_QCHOICE")) : 1;  // 0: never, 2: always (measurement)
-  const size_t q_frame_lds = (size_t)std::max(p->max_depth, 1) * 20 * PT_BLOCK * sizeof(double);
-  const bool q_alt = tree && env_qchoice != 0 && q_frame_lds <= PT_LDS_BUDGET;
+  const size_t q_frame_bytes = (size_t)std::max(p->max_depth, 1) * 20 * PT_BLOCK * sizeof(double);  // per workgroup
+  const bool q_lds_frames = q_frame_bytes <= PT_LDS_BUDGET;  // (D <= 3; deeper stacks live in HBM, same layout: `ws`)
+  const size_t q_frame_lds = q_lds_frames ? q_frame_bytes : 0;
+  const bool q_alt = tree && env_qchoice != 0;
   int grid_q = 0;
   if (q_alt) {
-    const int wgq = std::min<int>(3, (int)(PT_LDS_BUDGET / q_frame_lds));
+    const int wgq = q_lds_frames ? std::min<int>(3, (int)(PT_LDS_BUDGET / q_frame_bytes)) : 2;
     grid_q = (int)std::max<long long>(1, std::min<long long>(want, (long long)s->n_cu * wgq));
   }
   int grid_first = 0;  // path tracer, first pass (pt_tile_kernel<PATHTRACER>): one wave per 8x8 region
@@ -1203,8 +1205,10 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
     static const int env_smin = getenv("PTRACE_S_MIN") ? atoi(getenv("PTRACE_S_MIN")) : 0;
     a.p_max_path = env_pmax > 0 ? env_pmax : (path_tiled ? 1 : 48);
     a.s_min_path = env_smin > 0 ? env_smin : (path_tiled ? 1 : 16);
-    const size_t need = (size_t)std::max(p->max_depth, 1) * a.frame_doubles * (size_t)a.nthreads * sizeof(double);
-    if (!lds_frames && need > s->ws_bytes) {
+    size_t need = lds_frames ? 0 : (size_t)std::max(p->max_depth, 1) * a.frame_doubles * (size_t)a.nthreads * sizeof(double);
+    if (q_alt && !q_lds_frames)  // (the tree kernel's stack is in LDS: the workspace is the one-queue kernel's)
+      need = std::max(need, q_frame_bytes * (size_t)grid_q);
+    if (need > s->ws_bytes) {
       HIP_TRY(hipStreamSynchronize(st));
       if (s->ws) HIP_TRY(hipFree(s->ws));
       s->ws = nullptr;
@@ -1432,7 +1436,7 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
           pw *= (double)p->num_of_rays;
           tree_rays += pw;
         }
-        const double step_ns = (6.0 + 0.02 * s->n_shapes) * 1e3;
+        const double step_ns = (6.0 + 0.02 * s->n_shapes) * 1e3 * (q_lds_frames ? 1.0 : 1.3);  // (frames in HBM: measured on D = 4 ... 8)
         const double t_tree = (4.5 + 0.045 * std::min(tree_rays, 500.0)) * (2048.0 / (8.0 * s->n_cu));
         const double t_queue = (0.5 + 0.01 * s->n_shapes) * (1.0 + tree_rays / 800.0);
         if (t_tree > t_queue) q_min = (long long)std::min(1e15, 1.1 * tree_rays * step_ns / (t_tree - t_queue));
@@ -1486,7 +1490,7 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
         aq.grid_occ_lds = -1;
         // the scale+translate records behind the frame stack when they fit (world_query_lanes gathers them per lane)
         const size_t q_diag_bytes = (size_t)s->n_diag * sizeof(PtDiagRec);
-        const bool q_diag = s->n_diag > 0 && q_diag_bytes <= 48 * 1024 && q_frame_lds + q_diag_bytes <= PT_LDS_BUDGET;
+        const bool q_diag = s->n_diag > 0 && q_diag_bytes <= 48 * 1024 && q_frame_lds + q_diag_bytes <= (q_lds_frames ? PT_LDS_BUDGET : PT_LDS_BUDGET / 2);
         aq.diag_lds = q_diag ? (int)(q_frame_lds / 8) : -1;
         const size_t q_lds = q_frame_lds + (q_diag ? q_diag_bytes : 0);
         PtKArgs cold2 = aq;
@@ -1500,7 +1504,16 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
         }
         const void *tree_fn = main_fn;
         static const int env_qlat = getenv("PTRACE_Q_LANES") ? atoi(getenv("PTRACE_Q_LANES")) : 1;  // 0: the wave-uniform shape loop (pt_path_kernel<true, true>)
-        if (!env_qlat) {
+        aq.ws = s->ws;
+        if (!q_lds_frames) {  // the frame stack in HBM (D > 3): two workgroups per CU
+          if (small_world) {
+            HIP_TRY(path_lds_limit((const void *)pt_path_flagged_kernel<1, false>, q_lds));
+            PT_LAUNCH((pt_path_flagged_kernel<1, false>), grid_q, q_lds, true, aq);
+          } else {
+            HIP_TRY(path_lds_limit((const void *)pt_path_flagged_kernel<0, false>, q_lds));
+            PT_LAUNCH((pt_path_flagged_kernel<0, false>), grid_q, q_lds, true, aq);
+          }
+        } else if (!env_qlat) {
           HIP_TRY(path_lds_limit((const void *)pt_path_kernel<true, true>, q_lds));
           PT_LAUNCH((pt_path_kernel<true, true>), grid_q, q_lds, true, aq);
         } else if (small_world) {

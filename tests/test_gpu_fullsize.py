@@ -193,12 +193,14 @@ def test_num_of_rays_above_one_the_device_picks_the_second_pass_by_the_flagged_p
     one-queue kernel (a lane per flagged pixel) where the frame is full of them.  Same frame either way: against the oracle,
     and the dense frame cut over three ranks (each shard decides for itself) equals the whole."""
     W, H = 640, 360
-    kw = dict(samples_per_side=1, num_of_rays=3, max_depth=2, rr_limit=3, path_state=45, path_seq=54)
     dense, cam = _synthetic(32, True, False, W, H)    # a ground plane: every pixel below the horizon is flagged
     sparse, _ = _synthetic(32, False, False, W, H)    # spheres in front of a sky: 3 % of the pixels
     if __import__("os").environ.get("PTRACE_QCHOICE", "1") != "1":
         pytest.skip("the choice is forced by PTRACE_QCHOICE")
-    for scene, want_kernel in ((dense, abi.KERNEL_PATH), (sparse, abi.KERNEL_PATH_TREE)):
+    # (N, D) = (3, 2): the one-queue kernel's frame stack fits the LDS; (2, 5), roulette from depth 2: it lives in HBM
+    for scene, want_kernel, n_rays, depth, rr in ((dense, abi.KERNEL_PATH, 3, 2, 3), (sparse, abi.KERNEL_PATH_TREE, 3, 2, 3),
+                                                  (dense, abi.KERNEL_PATH, 2, 5, 2), (sparse, abi.KERNEL_PATH_TREE, 2, 5, 2)):
+        kw = dict(samples_per_side=1, num_of_rays=n_rays, max_depth=depth, rr_limit=rr, path_state=45, path_seq=54)
         par = abi.make_params(W, H, abi.RENDERER_PATHTRACER, **kw)
         with dev.DeviceScene(scene) as ds:
             out = ds.render(cam, par)
@@ -213,7 +215,7 @@ def test_num_of_rays_above_one_the_device_picks_the_second_pass_by_the_flagged_p
                     n_sum += int(ds.stats().n_rays)
                 assert util.bits_equal(got, out) and n_sum == int(st.n_rays)
         ora, n = _oracle(oracle, scene, cam, par)
-        _path_check(f"N=3 D=2 {'dense' if scene is dense else 'sparse'}", out, ora, st.n_rays, n, 3, W * H)
+        _path_check(f"N={n_rays} D={depth} {'dense' if scene is dense else 'sparse'}", out, ora, st.n_rays, n, 3, W * H)
 
 
 def test_one_queue_second_pass_under_an_orthogonal_camera_with_textures_and_mirrors(dev, oracle):

@@ -17,6 +17,9 @@ CASES = [  # scene, W, H, N, D, S
     ("c3", 1280, 720, 10, 3, 1), ("c3", 1920, 1080, 10, 3, 1),
     ("demo", 1280, 960, 4, 3, 1), ("plane", 1280, 720, 4, 3, 1), ("demo", 1280, 960, 10, 2, 1), ("plane", 1280, 720, 10, 2, 1),
     ("demo", 1280, 960, 3, 3, 2), ("plane", 1280, 720, 20, 2, 1), ("demo", 1280, 960, 2, 3, 1), ("plane", 1280, 720, 2, 3, 1),
+    # stacks deeper than the LDS holds (D > 3): the one-queue kernel keeps them in HBM
+    ("plane", 1280, 720, 2, 5, 1), ("plane", 1280, 720, 3, 5, 1), ("plane", 1280, 720, 2, 8, 1), ("plane", 640, 360, 3, 5, 1),
+    ("plane", 1280, 720, 4, 4, 1), ("demo", 1280, 960, 3, 5, 1), ("c3", 1280, 720, 3, 5, 1), ("plane", 320, 180, 3, 5, 1),
 ]
 
 
