@@ -1130,7 +1130,8 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
   // kernel keeps its per-lane frame stack (N > 1: 20 doubles per depth and lane) in LDS where that fits (D <= 3), in HBM beyond.
   static const int env_qchoice = getenv("PTRACE_QCHOICE") ? atoi(getenv("PTRACE_QCHOICE")) : 1;  // 0: never, 2: always (measurement)
   const size_t q_frame_bytes = (size_t)std::max(p->max_depth, 1) * 20 * PT_BLOCK * sizeof(double);  // per workgroup
-  const bool q_lds_frames = q_frame_bytes <= PT_LDS_BUDGET;  // (D <= 3; deeper stacks live in HBM, same layout: `ws`)
+  static const int env_qldsf = getenv("PTRACE_Q_LDS_FRAMES") ? atoi(getenv("PTRACE_Q_LDS_FRAMES")) : 1;  // 0: always in HBM (measurement)
+  const bool q_lds_frames = env_qldsf != 0 && q_frame_bytes <= PT_LDS_BUDGET;  // (D <= 3; deeper stacks live in HBM, same layout: `ws`)
   const size_t q_frame_lds = q_lds_frames ? q_frame_bytes : 0;
   const bool q_alt = tree && env_qchoice != 0;
   int grid_q = 0;
