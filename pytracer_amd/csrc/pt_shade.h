@@ -71,10 +71,13 @@ PT_DEV V3 pigment_color(const PtKArgs &a, int kind, CP c1, CP c2, double steps, 
   }
   CP c = c1;
   if (kind == PT_PIGMENT_CHECKERED) {
-    const long long iu = (long long)floor(u * steps);
-    const long long iv = (long long)floor(v * steps);
-    // Python's % 2 is non-negative; (x & 1) is the same parity for negative x in two's complement
-    c = ((iu & 1LL) == (iv & 1LL)) ? c1 : c2;
+    // materials.py:96-100: int(floor(u * n)) % 2 == int(floor(v * n)) % 2.  The parity of an integer-valued double t without
+    // a conversion to a 64-bit integer (a dozen instructions on this hardware, and undefined beyond 2^63): t is odd iff
+    // halving it leaves a fraction -- t * 0.5 is exact, so is floor, so is the doubling; beyond 2^53 every double is even,
+    // which is what Python's exact int() finds too.  Python's % 2 is non-negative, so -3 is odd like 3.
+    const double tu = floor(u * steps), tv = floor(v * steps);
+    const bool odd_u = floor(tu * 0.5) * 2.0 != tu, odd_v = floor(tv * 0.5) * 2.0 != tv;
+    c = (odd_u == odd_v) ? c1 : c2;
   }
   V3 r = {c[0], c[1], c[2]};
   return r;
