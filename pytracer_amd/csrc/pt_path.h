@@ -121,10 +121,6 @@ PT_DEV int nth_set_bit(unsigned long long m, int n) {
 #ifdef PT_DEBUG_TIME
 #define PT_TRACE_LEN 8192
 __device__ unsigned long long pt_trace[PT_TRACE_LEN + 64 * 80];  // (+ the traced unit's validated draw counts: [pixel][sample], tools/dbgdraws.py)
-#define PT_UNITLOG_LEN 16384
-// per work unit of the second pass: start tick, end tick, rounds | iterations << 32, pixels | lanes per pixel << 8 |
-// workgroup << 16, then the unit's cycles in: scattered-ray queries, shade, sample start + primary query, commit + fetch
-__device__ unsigned long long pt_unitlog[PT_UNITLOG_LEN * 8];
 #endif
 
 // ---- PathTracer (render.py:99-139) as a per-lane state machine ----------------------------------------

@@ -253,6 +253,11 @@ PT_DEV void lat_note(int which, unsigned long long dt) {
   }
 }
 #endif  // world_query_lanes: prefilter cycles, walk cycles, iterations, calls; 4..7: units / rounds
+#define PT_UNITLOG_LEN 16384
+// per work unit of the path tracer's second pass: start tick, end tick, rounds | iterations << 32, pixels | lanes per pixel << 8 |
+// workgroup << 16, then the unit's cycles in: scattered-ray queries, shade, sample start + primary query, commit + fetch
+// (pt_tile4_kernel: per wave its cycles, the per-tile part of them, its end tick)
+__device__ unsigned long long pt_unitlog[PT_UNITLOG_LEN * 8];
 #define PT_DBG_WAVES 16384
 __device__ unsigned long long pt_dbg_wave[PT_DBG_WAVES * 8];  // the same, per wave, summed up at the end of the kernel
 static __device__ void pt_dbg_flush() {

@@ -1247,6 +1247,16 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))
   if ((threadIdx.x & 63) == 0 && ((blockIdx.y * gridDim.x + blockIdx.x) & 15) == 0)
     for (int q = 0; q < 8; ++q) atomicAdd(pt_queue(a) + 1 + q, tsum[q]);
 #endif
+  if ((threadIdx.x & 63) == 0) {  // every wave's cycles, by workgroup and wave (tools/dbgtile4_waves.py: how uneven are a workgroup's four tiles?)
+    const int wv = (blockIdx.y * gridDim.x + blockIdx.x) * 4 + (int)(threadIdx.x >> 6);
+    if (wv < PT_UNITLOG_LEN) {
+      unsigned long long tot_ = 0;
+      for (int q = 0; q < 8; ++q) tot_ += tsum[q];
+      pt_unitlog[wv * 8] = tot_;
+      pt_unitlog[wv * 8 + 1] = tsum[0] + tsum[1] + tsum[2] + tsum[3];  // prologue, cone, cull, dome check: per tile
+      pt_unitlog[wv * 8 + 2] = __builtin_amdgcn_s_memtime();
+    }
+  }
   if ((threadIdx.x & 63) == 0 && ((blockIdx.y * gridDim.x + blockIdx.x) & 15) == 0) {  // (sampled waves) the longest one, and how many took more than 16 / 24 / 32 kcycles
     unsigned long long tot = 0;
     for (int q = 0; q < 8; ++q) tot += tsum[q];
