@@ -503,6 +503,27 @@ def g5_seq():
                   32, 24, S=2, mode=abi.PCG_SEQ)
 
 
+def g5_sample():
+    """Mode SAMPLE (one generator per sample) is what `GpuImageTracer` and the CLI give the path tracer by default
+    since round 4: more frames of the verbatim reference driven into it (the re-seeding proxy, `Seeder(per_sample=True)`) --
+    the reference's own demo scene with several rays per hit (the tree kernel's case), an odd number of samples per side, and
+    the textured world through a perspective camera with roulette from depth 1."""
+    with open("/root/reference/examples/demo.txt", "rt") as f:
+        scene = parse_scene(InputStream(f), {})
+    world, cam = scene.world, scene.camera
+    frame_fixture("g5_demo_path_24x18_n3d2_s2_sample", world, cam,
+                  lambda: PathTracer(world, pcg=PCG(45, 54), num_of_rays=3, max_depth=2), 24, 18, S=2,
+                  mode=abi.PCG_SAMPLE, s0=45, q0=54)
+    w3 = ref_synthetic_world(32)
+    frame_fixture("g5_c3_path_24x14_n1d3_s3_sample", w3, ref_synthetic_camera(24, 14),
+                  lambda: PathTracer(w3, pcg=PCG(45, 54), num_of_rays=1, max_depth=3), 24, 14, S=3,
+                  mode=abi.PCG_SAMPLE, s0=45, q0=54)
+    w2 = ref_synthetic_world(32, with_plane=True)
+    frame_fixture("g5_c2plane_path_32x18_n2d3_s2_sample", w2, ref_synthetic_camera(32, 18),
+                  lambda: PathTracer(w2, pcg=PCG(7, 11), num_of_rays=2, max_depth=3, russian_roulette_limit=1), 32, 18, S=2,
+                  mode=abi.PCG_SAMPLE, s0=7, q0=11)
+
+
 def g9_furnace():
     """test_all.py:1015-1051: closed diffuse unit sphere, N=1, D=100, rr_limit=101."""
     pcg = PCG()
@@ -567,16 +588,16 @@ if __name__ == "__main__":
         del argv[at:at + 2]
     table = {"g1": g1_pcg, "g2": g2_xform, "g3": g3_shapes, "g4": g4_camera, "g6": g6_g7_scatter_onb,
              "g8": g8_pigments, "g9": g9_furnace, "g5": g5_frames, "g10": g10_postprocess, "g5c4": g5_c4,
-             "g5cli": g5_cli, "g5seq": g5_seq}
+             "g5cli": g5_cli, "g5seq": g5_seq, "g5sample": g5_sample}
     if argv:
-        parses = sum(1 for k in argv if k in ("g5", "g5cli", "g5seq"))
+        parses = sum(1 for k in argv if k in ("g5", "g5cli", "g5seq", "g5sample"))
         if parses > 1:
-            raise SystemExit("g5, g5cli and g5seq all parse examples/demo.txt: run them in separate processes (SURVEY.md H5)")
+            raise SystemExit("g5, g5cli, g5seq and g5sample all parse examples/demo.txt: run them in separate processes (SURVEY.md H5)")
         for k in argv:
             table[k]()
     else:
         import subprocess
 
-        for k in ["g1", "g2", "g3", "g4", "g6", "g8", "g9", "g5", "g10", "g5cli", "g5c4", "g5seq"]:  # (g10 reads g5's frames)
+        for k in ["g1", "g2", "g3", "g4", "g6", "g8", "g9", "g5", "g10", "g5cli", "g5c4", "g5seq", "g5sample"]:  # (g10 reads g5's frames)
             subprocess.run([sys.executable, os.path.abspath(__file__), "--out", OUT_DIR, k], check=True,
                            env=dict(os.environ, PYTHONDONTWRITEBYTECODE="1"))
