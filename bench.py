@@ -980,6 +980,35 @@ def run_multi(args, rank, local_rank, world_size, dist, backend):
                                    dist, agree, gather_choice["sparse"], max(args.steps, 5 * args.steps))
     ds3.close()
 
+    # ... and the N = 1 line's own workload, C2 (1280x720 Flat: one launch of 14 us, nothing to shard), as N independent
+    # replicas without any collective: the figure the N = 1 line's `value` scales to if every GPU renders its own frames
+    replicas = {}
+
+    def c2_replicas():
+        flat2 = flatten.flatten_world(scenes.synthetic_world(32, with_plane=True))
+        ds2 = DeviceScene(flat2, device=local_rank)
+        try:
+            par2 = abi.make_params(1280, 720, abi.RENDERER_FLAT, out_format=abi.OUT_F32)
+            lp = ShardedFrameLoop(ds2, cam_for(1280, 720), par2, row_block=8, solo=True)
+            ds2.set_count_rays(True)
+            for i in range(max(2, args.warmup)):
+                lp.step(i, gather=False)
+            lp.finish()
+            ds2.sync()
+            rays2 = int(ds2.stats().n_rays)
+            k2 = 10 * args.steps
+            el, _, _ = timed_loop(ds2, lp, k2, dist, False, events=False)
+            t = torch.tensor([el], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            replicas.update(value=world_size * rays2 * k2 / float(t.item()) / 1e6, unit="Mray/s", ms_per_step=float(t.item()) / k2 * 1e3,
+                            steps=k2, note=f"{world_size} independent replicas of the N = 1 line's workload (C2, 1280x720 Flat, "
+                                           "one frame after the other per GPU), no collective: frames of all ranks / the slowest rank's time")
+        finally:
+            ds2.close()
+
+    if agree.error is None:
+        agree.attempt("C2 replicas", c2_replicas)
+
     if rank == 0:
         plan = ptdist.gather_plan(H, W, 8, world_size, itemsize=4, transport=ptdist.choose_transport() if agree.error is None else ptdist.P2P)
         result = {
@@ -1027,6 +1056,10 @@ def run_multi(args, rank, local_rank, world_size, dist, backend):
                                                   "blocks), same ShardedFrameLoop, gather inside the timed region",
                                          note="BASELINE.json quotes its metric 'at 1280x720, 1/2/4/8 MI355X'; C2 (14 us per frame) cannot "
                                               "shard, C3 (0.12 ms) can: n1_same_workload is this frame on rank 0 alone by the same clock")
+        if replicas:
+            result["c2_replicas"] = replicas
+        elif "C2 replicas" in agree.soft:
+            result["c2_replicas"] = {"error": agree.soft["C2 replicas"]}
         if agree.error is not None:
             result["error"] = agree.error
         print(json.dumps(result), flush=True)
