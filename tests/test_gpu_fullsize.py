@@ -195,8 +195,8 @@ def test_num_of_rays_above_one_the_device_picks_the_second_pass_by_the_flagged_p
     W, H = 640, 360
     dense, cam = _synthetic(32, True, False, W, H)    # a ground plane: every pixel below the horizon is flagged
     sparse, _ = _synthetic(32, False, False, W, H)    # spheres in front of a sky: 3 % of the pixels
-    if __import__("os").environ.get("PTRACE_QCHOICE", "1") != "1":
-        pytest.skip("the choice is forced by PTRACE_QCHOICE")
+    if __import__("os").environ.get("PTRACE_QCHOICE", "1") != "1" or __import__("os").environ.get("PTRACE_TREE", "1") == "0":
+        pytest.skip("the choice is forced by PTRACE_QCHOICE / PTRACE_TREE (measurement switches)")
     # (N, D) = (3, 2): the one-queue kernel's frame stack fits the LDS; (2, 5), roulette from depth 2: it lives in HBM
     for scene, want_kernel, n_rays, depth, rr in ((dense, abi.KERNEL_PATH, 3, 2, 3), (sparse, abi.KERNEL_PATH_TREE, 3, 2, 3),
                                                   (dense, abi.KERNEL_PATH, 2, 5, 2), (sparse, abi.KERNEL_PATH_TREE, 2, 5, 2)):
@@ -225,8 +225,8 @@ def test_one_queue_second_pass_under_an_orthogonal_camera_with_textures_and_mirr
     on a frame dense enough for the device to pick it; against the oracle, and partition-invariant."""
     from pytracer_amd import flatten, hostmodel as hm
 
-    if __import__("os").environ.get("PTRACE_QCHOICE", "1") != "1":
-        pytest.skip("the choice is forced by PTRACE_QCHOICE")
+    if __import__("os").environ.get("PTRACE_QCHOICE", "1") != "1" or __import__("os").environ.get("PTRACE_TREE", "1") == "0":
+        pytest.skip("the choice is forced by PTRACE_QCHOICE / PTRACE_TREE (measurement switches)")
     g = hm.PCG(99, 1)
     r = g.random_float
     tex = hm.HdrImage(8, 4)
