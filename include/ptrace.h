@@ -254,9 +254,15 @@ int pt_image_sparse_decode_many(int device, int n_shards, const void *const *fix
                                 int row_block, int n_ranks, void *stream);
 /* Copy the last error message of the calling thread (NUL-terminated) into buf; returns its length. */
 int pt_last_error(char *buf, size_t n);
-/* Library/ABI version: (major<<16)|minor; this header describes 1.3.  The minor grows whenever a struct here grows or an
+/* 1 iff HIP_FORCE_DEV_KERNARG is set to a non-zero value in this process: the HIP runtime then keeps kernel ARGUMENTS in
+ * device memory (it reads the variable once, when it initialises) and every launch is ~1 us shorter
+ * (profiles/r04_dev_kernarg.txt).  The library never sets it: the caller does, before the process's first HIP call
+ * (pytracer_amd.prefer_device_kernargs(), the `render` command and bench.py do).  A value set after the runtime came up
+ * is reported here but has no effect. */
+int pt_device_kernargs(void);
+/* Library/ABI version: (major<<16)|minor; this header describes 1.4.  The minor grows whenever a struct here grows or an
  * entry point is added (1.2: pt_stats gained `kernel` and `_reserved` -- 56 bytes, which pt_get_stats writes in full --,
- * pt_scene_clone, pt_image_sparse_*; 1.3: PT_PCG_SEQ on the device for OnOff / Flat / PointLight): a caller built
+ * pt_scene_clone, pt_image_sparse_*; 1.3: PT_PCG_SEQ on the device for OnOff / Flat / PointLight; 1.4: pt_device_kernargs, no load-time setenv): a caller built
  * against an older header must check pt_version() before it hands pt_get_stats its smaller struct. */
 int pt_version(void);
 

@@ -15,7 +15,7 @@ EXPORTS = ("pt_device_count", "pt_scene_upload", "pt_scene_clone", "pt_scene_fre
            "pt_render", "pt_render_device", "pt_get_stats", "pt_set_count_rays", "pt_sync", "pt_last_error",
            "pt_version", "pt_profile_begin", "pt_profile_end", "pt_set_timing", "pt_image_pack_pfm",
            "pt_image_average_luminosity", "pt_image_tonemap", "pt_host_alloc", "pt_host_free", "pt_set_dome_shortcut", "pt_device_info",
-           "pt_image_sparse_fixed_bytes", "pt_image_sparse_encode", "pt_image_sparse_decode", "pt_image_sparse_decode_many")
+           "pt_image_sparse_fixed_bytes", "pt_image_sparse_encode", "pt_image_sparse_decode", "pt_image_sparse_decode_many", "pt_device_kernargs")
 
 
 # every symbol include/ptrace_debug.h declares for ordinary builds (diagnostics: not part of the boundary)
@@ -24,8 +24,8 @@ DEBUG_EXPORTS = ("pt_debug_probe", "pt_debug_cull_probe", "pt_debug_hit_probe", 
 
 
 # include/ptrace.h: pt_version() = major << 16 | minor; abi.Stats mirrors the 56-byte pt_stats of minor >= 2, the tracer's
-# default alignment needs the PT_PCG_SEQ of minor >= 3
-ABI_MAJOR, ABI_MINOR_NEEDED = 1, 3
+# default alignment needs the PT_PCG_SEQ of minor >= 3, device.device_kernargs() the entry point of minor 4
+ABI_MAJOR, ABI_MINOR_NEEDED = 1, 4
 
 
 class PtraceError(RuntimeError):
@@ -109,6 +109,7 @@ def lib():
         if ver >> 16 != ABI_MAJOR or (ver & 0xFFFF) < ABI_MINOR_NEEDED:
             raise ImportError(f"{_LIB_PATH} implements ABI {ver >> 16}.{ver & 0xFFFF}; this package needs {ABI_MAJOR}.>={ABI_MINOR_NEEDED} "
                               "(pt_stats layout, PT_PCG_SEQ): rebuild with `python -m pytracer_amd.build --force`")
+        L.pt_device_kernargs.restype = C.c_int
         L.pt_set_timing.restype = C.c_int
         L.pt_set_timing.argtypes = [C.c_void_p, C.c_int]
         L.pt_profile_begin.restype = C.c_int

@@ -148,12 +148,15 @@ def render(width, height, algorithm, pfm_output, png_output, num_of_rays, max_de
         if pcg_mode == "seq" and algorithm == "pathtracing":
             raise UsageError("--pcg-mode seq with --algorithm pathtracing: the reference's scattering stream is one generator "
                              "consumed in the order the paths of all pixels end in (render.py:118,128) -- serial by "
-                             "construction; use pixel (default) or sample")
+                             "construction; use sample (what auto, the default, picks for pathtracing) or pixel")
         job = plan_render(width, height, algorithm, num_of_rays, max_depth, init_state, init_seq, samples_per_pixel,
                           declare_float, input_scene_name)
     except UsageError as e:
         click.echo(f"pytracer_amd render: {e}", err=True)
         sys.exit(2)
+    from . import prefer_device_kernargs
+
+    prefer_device_kernargs()  # (this process is ours: kernel arguments in device memory, before its first HIP call)
     click.echo(f"{width}x{height} px, {algorithm}, {job.samples_per_side ** 2} sample(s) per pixel, "
                f"{len(job.world.shapes)} shape(s), GPU {device}")
     image = hm.HdrImage(width, height)

@@ -27,14 +27,14 @@
 #endif
 // major << 16 | minor.  The minor grows whenever a struct of include/ptrace.h grows or an entry point is added (minor 2:
 // pt_stats gained `kernel` + `_reserved`, pt_scene_clone / pt_image_sparse_* arrived; minor 3: PT_PCG_SEQ accepted for
-// OnOff / Flat / PointLight at any samples_per_side); a caller built against an older header checks pt_version() first.
-#define PT_VERSION ((1 << 16) | 3)
+// OnOff / Flat / PointLight at any samples_per_side; minor 4: pt_device_kernargs, and the library no longer sets
+// HIP_FORCE_DEV_KERNARG when it is loaded); a caller built against an older header checks pt_version() first.
+#define PT_VERSION ((1 << 16) | 4)
 
-// Kernel arguments in DEVICE memory: by default the HIP runtime keeps the kernarg segment in host memory, and the first
-// scalar load of every wave of a launch then crosses the host link (~1.5 us of a 14-us frame: profiles/r04_dev_kernarg.txt).
-// The runtime reads the variable when it initialises, so this runs when the library is loaded -- a caller that links
-// libptrace.so (or dlopens it before its first HIP call) gets it; one that has set the variable itself keeps its choice.
-__attribute__((constructor)) static void pt_prefer_device_kernargs() { setenv("HIP_FORCE_DEV_KERNARG", "1", 0); }
+// (Kernel arguments in device memory -- HIP_FORCE_DEV_KERNARG=1, ~1 us per launch, profiles/r04_dev_kernarg.txt -- are the
+// CALLER's choice: the HIP runtime reads the variable when it initialises, and a library that edited the process environment
+// at load time would change HIP for every other user of the runtime in the process.  pytracer_amd.prefer_device_kernargs(),
+// the `render` command and bench.py set it before their first HIP call; pt_device_kernargs() reports what is in effect.)
 
 static thread_local char g_err[512] = "";
 
@@ -157,6 +157,11 @@ struct pt_scene {
 };
 
 extern "C" int pt_version(void) { return PT_VERSION; }
+
+extern "C" int pt_device_kernargs(void) {
+  const char *v = getenv("HIP_FORCE_DEV_KERNARG");
+  return v && atoi(v) != 0 ? 1 : 0;
+}
 
 extern "C" int pt_last_error(char *buf, size_t n) {
   const size_t len = strlen(g_err);

@@ -199,6 +199,12 @@ def device_count() -> int:
     return int(_lib.lib().pt_device_count())
 
 
+def device_kernargs() -> bool:
+    """True iff ``HIP_FORCE_DEV_KERNARG`` asks the HIP runtime for kernel arguments in device memory
+    (``pytracer_amd.prefer_device_kernargs()`` before the first HIP call; ``pt_device_kernargs``)."""
+    return bool(_lib.lib().pt_device_kernargs())
+
+
 def camera_probe(cam: abi.Camera, width: int, height: int, pix) -> np.ndarray:
     """Diagnostics: ``ImageTracer.fire_ray`` for ``[n, 4]`` (col, row, u_pixel, v_pixel) -> ``[n, 7]`` (origin, dir, tmin)."""
     pix = np.ascontiguousarray(pix, dtype=np.float64).reshape(-1, 4)

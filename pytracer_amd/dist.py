@@ -509,7 +509,8 @@ class ShardedFrameLoop:
 
     def _gather(self, b: int) -> None:
         with torch.cuda.stream(self.comm):
-            self.comm.wait_event(self._rendered[b])
+            if self._rendered[b] is not None:
+                self.comm.wait_event(self._rendered[b])
             gather_image(self.bufs[b], self.height, self.row_block, group=self.group, dst=0,
                          out=self.full[b] if self.rank == 0 else None,
                          staging=self.staging if self.rank == 0 else None, sparse=self.sparse)
@@ -553,7 +554,15 @@ class ShardedFrameLoop:
                 torch.cuda.synchronize()
             for k in self.PHASES:
                 total[k] += clock.ms.get(k, 0.0)
+        # the probe rendered into buffer 0 and (in a process group) assembled that frame into full[0]; everything has been
+        # drained, so the loop's bookkeeping is reset to exactly that state (image() used to raise here after a
+        # step(gather=False), and a later step could wait on events of frames long gone)
+        torch.cuda.synchronize()
         self.last = 0
+        self._assembled = True
+        self._pending = []
+        self._free = [None] * len(self.bufs)
+        self._rendered = [None] * len(self.bufs)
         return {k: v / max(1, frames) for k, v in total.items()}
 
     def image(self) -> Optional[torch.Tensor]:

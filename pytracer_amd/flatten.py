@@ -148,14 +148,21 @@ _MULT_INV = pow(_MULT, -1, 1 << 64)
 _M64 = (1 << 64) - 1
 
 
-def recover_seeds(pcg) -> Tuple[int, int]:
+def recover_seeds(pcg, constructed: bool = False) -> Tuple[int, int]:
     """(init_state, init_seq) such that ``PCG(init_state, init_seq)`` is in the state ``pcg`` is in NOW: the seeds it was
     built with if it has not been drawn from since, otherwise the seeds of the generator that starts where this one has
     got to (a tracer whose ``pcg`` an earlier frame already drew from continues its stream, as the reference does).
 
+    ``constructed=True`` (the per-pixel and per-sample alignments, whose generators are DERIVED from a seed pair and do not
+    continue anybody's stream): a generator that remembers what it was built with (``init_state`` / ``init_seq``
+    attributes, as :class:`pytracer_amd.hostmodel.PCG` does) gives those, drawn from or not -- round 3's behaviour, which
+    ``pcg_mode="pixel"`` keeps reproducing; the reference's own PCG remembers nothing and is solved for.
+
     The reference's PCG keeps only (state, inc) (pcg.py:25-41).  For a fresh generator
     state = ((inc + init_state) * MULT + inc) mod 2^64 and inc = (init_seq << 1) | 1, so both
     seeds can be solved for exactly (seeds < 2^63)."""
+    if constructed and hasattr(pcg, "init_state") and hasattr(pcg, "init_seq"):
+        return int(pcg.init_state), int(pcg.init_seq)
     inc = int(pcg.inc) & _M64
     state = int(pcg.state) & _M64
     init_state = ((((state - inc) & _M64) * _MULT_INV) - inc) & _M64
@@ -191,14 +198,15 @@ def renderer_params(renderer, width: int, height: int, samples_per_side: int = 0
             f"{name!r} is not a renderer the device path implements "
             f"(expected one of {sorted(RENDERER_KINDS)}); arbitrary callables cannot run on the GPU")
     kw = dict(background=_rgb(renderer.background_color))
-    j_state, j_seq = recover_seeds(tracer_pcg) if tracer_pcg is not None else (42, 54)
+    derived = pcg_mode != abi.PCG_SEQ  # (per-pixel / per-sample generators are derived from the seeds a PCG was built with)
+    j_state, j_seq = recover_seeds(tracer_pcg, derived) if tracer_pcg is not None else (42, 54)
     p_state, p_seq = j_state, j_seq
     if name == "OnOffRenderer":
         kw["onoff_color"] = _rgb(renderer.color)
     elif name == "PathTracer":
         kw.update(num_of_rays=renderer.num_of_rays, max_depth=renderer.max_depth,
                   rr_limit=renderer.russian_roulette_limit)
-        p_state, p_seq = recover_seeds(renderer.pcg)
+        p_state, p_seq = recover_seeds(renderer.pcg, derived)
     elif name == "PointLightRenderer":
         kw["ambient"] = _rgb(renderer.ambient_color)
     return abi.make_params(width, height, RENDERER_KINDS[name], samples_per_side=samples_per_side,

@@ -1,4 +1,8 @@
-"""LazyPixels — what ``GpuImageTracer`` installs as ``image.pixels`` of a reference-style ``HdrImage``.
+"""LazyPixels — what ``GpuImageTracer(..., lazy_pixels=True)`` installs as ``image.pixels`` of a reference-style
+``HdrImage``.  OPT-IN: by default the tracer fills the existing list object in place, exactly as the reference's
+``set_pixel`` loop does, because replacing the list is visible to a caller that kept ``px = image.pixels`` or that needs a real
+``list`` (``isinstance``, ``append``, ``+``, ``sort``, pickling).  A caller that only indexes, iterates or writes the image
+out can ask for this object and skip 0.4 s of interpreter time per 720p frame.
 
 The reference's ``HdrImage`` keeps a Python list of ``width * height`` ``Color`` objects (hdrimages.py:70) and reaches
 them through ``self.pixels[i]`` only: ``get_pixel`` / ``set_pixel`` (hdrimages.py:78-94), ``for pix in self.pixels`` and
@@ -11,7 +15,9 @@ So the frame stays a numpy ``[H*W, 3]`` fp64 array and a ``Color`` is made when 
 kept from then on: ``pixels[i]`` returns the SAME object every time, as a list would, so that ``pixels[i].r = x``
 (``clamp_image``) is not lost.  Assignment replaces the object.  Slices, ``pixels[:] = colors``, iteration, ``len``,
 ``==`` against a list, ``reversed``, ``index`` / ``count`` (through ``collections.abc.Sequence``) behave like the list's.
-``as_array()`` gives the frame back as ``[H*W, 3]`` fp64 including whatever was assigned or mutated since.
+``as_array()`` gives the frame back as ``[H*W, 3]`` fp64 including whatever was assigned or mutated since.  Once EVERY pixel
+has been materialised (``normalize_image`` and ``clamp_image`` do that) the object collapses onto a plain internal list and
+drops both the index dictionary and its view of the frame.
 """
 from __future__ import annotations
 
@@ -21,19 +27,27 @@ import numpy as np
 
 
 class LazyPixels(Sequence):
-    __slots__ = ("_arr", "_made", "color_cls")
+    __slots__ = ("_arr", "_made", "_all", "_n", "color_cls")
 
     def __init__(self, arr: np.ndarray, color_cls):
         a = np.asarray(arr, dtype=np.float64)
         self._arr = a.reshape(-1, 3)   # (a view: the caller hands the frame over)
+        self._n = self._arr.shape[0]
         self._made = {}                # index -> the Color handed out / assigned for it
+        self._all = None               # every pixel materialised: the plain list of them (then _arr and _made are dropped)
         self.color_cls = color_cls
 
     def __len__(self) -> int:
-        return self._arr.shape[0]
+        return self._n
+
+    def _collapse(self) -> None:
+        made = self._made
+        self._all = [made[j] for j in range(self._n)]
+        self._made = None
+        self._arr = None
 
     def _index(self, i) -> int:
-        n = self._arr.shape[0]
+        n = self._n
         j = i.__index__()
         if j < 0:
             j += n
@@ -42,31 +56,43 @@ class LazyPixels(Sequence):
         return j
 
     def _get(self, j: int):
+        if self._all is not None:
+            return self._all[j]
         c = self._made.get(j)
         if c is None:
             r, g, b = self._arr[j].tolist()
             c = self._made[j] = self.color_cls(r, g, b)
+            if len(self._made) == self._n:
+                self._collapse()
         return c
+
+    def _put(self, j: int, value) -> None:
+        if self._all is not None:
+            self._all[j] = value
+            return
+        self._made[j] = value
+        if len(self._made) == self._n:
+            self._collapse()
 
     def __getitem__(self, i):
         if isinstance(i, slice):
-            return [self._get(j) for j in range(*i.indices(self._arr.shape[0]))]
+            return [self._get(j) for j in range(*i.indices(self._n))]
         return self._get(self._index(i))
 
     def __setitem__(self, i, value) -> None:
         if isinstance(i, slice):
-            idx = range(*i.indices(self._arr.shape[0]))
+            idx = range(*i.indices(self._n))
             vals = list(value)
             if len(vals) != len(idx):
                 raise ValueError("LazyPixels keeps its length: a slice can only be assigned as many colours as it holds")
             for j, v in zip(idx, vals):
-                self._made[j] = v
+                self._put(j, v)
             return
-        self._made[self._index(i)] = value
+        self._put(self._index(i), value)
 
     def __iter__(self):
         get = self._get
-        for j in range(self._arr.shape[0]):
+        for j in range(self._n):
             yield get(j)
 
     def __eq__(self, other):
@@ -77,10 +103,12 @@ class LazyPixels(Sequence):
     __hash__ = None
 
     def __repr__(self) -> str:
-        return f"LazyPixels({self._arr.shape[0]} pixels, {len(self._made)} materialised)"
+        return f"LazyPixels({self._n} pixels, {self._n if self._all is not None else len(self._made)} materialised)"
 
     def as_array(self) -> np.ndarray:
         """``[H*W, 3]`` fp64 with every assignment and mutation applied (a copy when there were any)."""
+        if self._all is not None:
+            return np.array([(c.r, c.g, c.b) for c in self._all], dtype=np.float64).reshape(-1, 3)
         if not self._made:
             return self._arr
         out = self._arr.copy()

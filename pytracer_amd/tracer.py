@@ -53,10 +53,16 @@ into ``image`` -- the PFM floats and the tone-mapped bytes are then the only dev
 (main.py:203-213 on the device; 14 MB instead of the 22 MB fp64 frame at 1280x720).  ``image`` keeps its size and is
 filled on demand by ``tracer.download()``.
 
-A reference-style ``HdrImage`` (a list of ``Color`` objects, hdrimages.py:70) gets its frame as a lazy sequence
-(:mod:`pytracer_amd.pixels`): ``image.pixels`` is REPLACED by an object that indexes, iterates, assigns and keeps object
-identity like the list did and makes a ``Color`` when an index is first read; ``eager_fill=True`` fills the existing
-list object in place instead (0.49 s per 720p frame in the interpreter).
+A reference-style ``HdrImage`` (a list of ``Color`` objects, hdrimages.py:70) has that list filled IN PLACE, one new
+``Color`` of the image's own class per pixel, as the reference's ``set_pixel`` loop does (0.4 - 0.5 s per 720p frame in the
+interpreter; a caller that kept ``px = image.pixels`` sees the frame).  ``lazy_pixels=True`` (opt-in; round 4 did this by
+default) REPLACES ``image.pixels`` by a :class:`pytracer_amd.pixels.LazyPixels` instead: it indexes, iterates,
+assigns and keeps object identity like the list did and makes a ``Color`` when an index is first read -- 0.001 ms per frame,
+for callers that only index / iterate / write the image out.
+
+``tracer.pcg`` is advanced behind a ``"seq"`` frame (by the ``2 W H S²`` draws the reference's loop makes) only when the
+caller SUPPLIED the generator: a tracer built without ``pcg`` starts every frame from ``PCG()`` -- the reference's shared
+default-argument generator (imagetracer.py:34) is not imitated.
 
 ``fallback="host"`` (opt-in, never the default): a reference renderer whose world the device cannot express (an
 unknown shape / BRDF / pigment class, a non-affine matrix) is itself a callable ``Ray -> Color``; with this option it
@@ -102,10 +108,12 @@ class _RayView:
 class GpuImageTracer:
     def __init__(self, image, camera, samples_per_side: int = 0, pcg=None, device: int = 0,
                  pcg_mode: str = "auto", resident: bool = False, fallback: Optional[str] = None,
-                 eager_fill: bool = False):
+                 lazy_pixels: bool = False, eager_fill: Optional[bool] = None):
         if fallback not in (None, "host"):
             raise ValueError('fallback must be None or "host"')
-        self.eager_fill = bool(eager_fill)
+        if eager_fill is not None:  # (round 4's spelling of the same switch, with the opposite default)
+            lazy_pixels = not eager_fill
+        self.lazy_pixels = bool(lazy_pixels)
         self.resident = bool(resident)
         self.fallback = fallback
         self.device_image = None   # resident=True: the last frame, in HBM
@@ -113,6 +121,7 @@ class GpuImageTracer:
         self.image = image
         self.camera = camera
         self.samples_per_side = samples_per_side
+        self._own_pcg = pcg is None  # (no generator supplied: every frame starts from PCG())
         self.pcg = pcg if pcg is not None else PCG()
         self.device = device
         if pcg_mode not in _PCG_MODES:
@@ -262,7 +271,8 @@ class GpuImageTracer:
                     band //= 2
             st.n_rays, st.n_rays_resolved, st.kernel_ms, st.total_ms, st.n_pixels = n_rays, n_res, kernel_ms, total_ms, w * h
             self.last_stats = st
-        if mode == abi.PCG_SEQ and int(self.samples_per_side) > 0 and hasattr(self.pcg, "state") and hasattr(self.pcg, "inc"):
+        if (mode == abi.PCG_SEQ and int(self.samples_per_side) > 0 and not self._own_pcg
+                and hasattr(self.pcg, "state") and hasattr(self.pcg, "inc")):
             # the reference's loop leaves ImageTracer.pcg 2 W H S^2 draws further on (imagetracer.py:84-101)
             self.pcg.state = pcg_advance(int(self.pcg.state), int(self.pcg.inc), 2 * w * h * int(self.samples_per_side) ** 2)
         if dev_t is not None:
@@ -271,13 +281,13 @@ class GpuImageTracer:
             self.device_image = DeviceImage(dev_t)
         else:
             self.device_image = None
-            _fill_image(self.image, out, self.eager_fill)
+            _fill_image(self.image, out, self.lazy_pixels)
 
     def download(self) -> None:
         """resident=True: copy the frame left in HBM into ``image`` (what ``fire_all_rays`` does by itself otherwise)."""
         if self.device_image is None:
             raise RuntimeError("no resident frame: fire_all_rays(renderer) with resident=True leaves one")
-        _fill_image(self.image, self.device_image.numpy(), self.eager_fill)
+        _fill_image(self.image, self.device_image.numpy(), self.lazy_pixels)
 
     def close(self):
         if self._scene is not None:
@@ -285,23 +295,23 @@ class GpuImageTracer:
             self._scene = None
 
 
-def _fill_image(image, arr: np.ndarray, eager: bool = False) -> None:
+def _fill_image(image, arr: np.ndarray, lazy: bool = False) -> None:
     """Write ``[H, W, 3]`` into an HdrImage: the stand-in keeps a numpy array; the reference's HdrImage holds a list
-    of Color objects (hdrimages.py:70).  That list is replaced by a :class:`pytracer_amd.pixels.LazyPixels` over
-    ``arr`` (which the caller hands over): same indexing, iteration, assignment and identity semantics, a ``Color`` of
-    the image's own class made when an index is first read -- 921 600 eager objects cost 0.49 s per 720p frame.
-    ``eager=True`` fills the EXISTING list object in place instead (for a caller that holds on to ``image.pixels``)."""
+    of Color objects (hdrimages.py:70), which is filled IN PLACE (the same list object, one new Color of the image's own
+    class per pixel: what the reference's ``set_pixel`` loop leaves behind; 0.4 - 0.5 s per 720p frame).  ``lazy=True``
+    REPLACES the list by a :class:`pytracer_amd.pixels.LazyPixels` over ``arr`` (which the caller hands over): same
+    indexing, iteration, assignment and identity semantics, a ``Color`` made when an index is first read."""
     if hasattr(image, "set_array"):
         image.set_array(arr)
         return
     old = image.pixels
     color_cls = old.color_cls if isinstance(old, LazyPixels) else (type(old[0]) if len(old) else Color)
-    if eager:
-        flat = arr.reshape(-1, 3)  # (map over three lists: ~15 % less interpreter time than unpacking triples)
-        colors = list(map(color_cls, flat[:, 0].tolist(), flat[:, 1].tolist(), flat[:, 2].tolist()))
-        if isinstance(old, LazyPixels):
-            image.pixels = colors
-        else:
-            old[:] = colors
+    if lazy:
+        image.pixels = LazyPixels(np.ascontiguousarray(arr, dtype=np.float64), color_cls)
         return
-    image.pixels = LazyPixels(np.ascontiguousarray(arr, dtype=np.float64), color_cls)
+    flat = arr.reshape(-1, 3)  # (map over three lists: ~15 % less interpreter time than unpacking triples)
+    colors = list(map(color_cls, flat[:, 0].tolist(), flat[:, 1].tolist(), flat[:, 2].tolist()))
+    if isinstance(old, LazyPixels):
+        image.pixels = colors
+    else:
+        old[:] = colors

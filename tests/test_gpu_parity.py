@@ -246,7 +246,7 @@ def test_tree_kernel_in_a_world_without_a_dome(dev, oracle, n_rays, depth, rr):
         ora, n = oracle.render(scene, cam, par, sqr_mode=oracle.SQR_MUL)
         oracle.set_sqr_mode(oracle.SQR_POW)
         bad = int((util.rel_err(out, ora) > TOL).any(axis=-1).sum())
-        assert bad <= 3, (S, mode, bad)
+        assert bad <= 1, (S, mode, bad)  # (every logged run: 0; observed + 1)
         assert abs(int(st.n_rays) - n) <= 8 + n // 100000, (S, mode, int(st.n_rays), n)
 
 
@@ -541,7 +541,7 @@ def test_c3_pathtracer_vs_oracle(dev, oracle, n_rays, depth, S, mode):
     print(f"path N={n_rays} D={depth} S={S}: max rel {err.max():.3e}, outliers {bad}, rays {st.n_rays} vs {n}")
     # sin/cos last-ulp differences can flip a silhouette/checker decision after a bounce: allow a
     # handful of outlier pixels, never a systematic difference
-    assert bad <= 3
+    assert bad <= 1  # (every logged run: 0; observed + 1)
     assert abs(int(st.n_rays) - n) <= 8
 
 
@@ -598,7 +598,7 @@ def test_cell_walk_of_large_scenes_vs_oracle(dev, oracle, n, renderer, lights):
     err = util.rel_err(out, ora)
     bad = int((err > TOL).any(axis=-1).sum())
     print(f"grid n={n} renderer={renderer}: max rel {err.max():.3e}, outliers {bad}, rays {n_dev} vs {n_rays}")
-    assert bad <= 2
+    assert bad <= 1
     assert abs(int(n_dev) - n_rays) <= max(8, n_rays // 1000)
 
 
@@ -677,7 +677,7 @@ def test_random_scenes_match_oracle(dev, oracle, seed):
         err = util.rel_err(out, ora)
         bad = int((err > TOL).any(axis=-1).sum())
         # a last-bit difference in sin/cos can flip a Russian-roulette decision or a checker cell for one pixel
-        assert bad <= max(1, (W * H) // 2000), f"seed {seed}: {bad} pixels off, max rel {err.max():.3e}"
+        assert bad <= 1, f"seed {seed}: {bad} pixels off, max rel {err.max():.3e}"
     oracle.set_sqr_mode(oracle.SQR_POW)
 
 
@@ -961,7 +961,7 @@ def test_c4_as_specified_vs_oracle(dev, oracle, mode):
     err = util.rel_err(out, ora)
     bad = int((err > TOL).any(axis=-1).sum())
     print(f"C4 {W}x{H} mode={mode}: max rel {err.max():.3e}, outliers {bad}/{W * H}, rays {st.n_rays} vs {n}")
-    assert bad <= 3
+    assert bad <= 1
     assert abs(int(st.n_rays) - n) <= max(8, n // 100000)
     assert n >= W * H * 64
 
@@ -984,7 +984,7 @@ def test_c4_as_specified_three_rank_seven_row_partition_vs_oracle(dev, oracle, m
             got[rows] = shard
             ora, _ = oracle.render(scene, cam, p, sqr_mode=oracle.SQR_MUL)
             err = util.rel_err(shard, ora)
-            assert int((err > TOL).any(axis=-1).sum()) <= 2, f"rank {rank}: max rel {err.max():.3e}"
+            assert int((err > TOL).any(axis=-1).sum()) <= 1, f"rank {rank}: max rel {err.max():.3e}"
     oracle.set_sqr_mode(oracle.SQR_POW)
     assert util.bits_equal(got, full)
 

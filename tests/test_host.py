@@ -153,7 +153,9 @@ def test_fill_image_into_reference_style_hdrimage():
 
     img = RefImage(3, 2)
     arr = np.arange(18, dtype=np.float64).reshape(2, 3, 3)
-    _fill_image(img, arr)  # (a lazy sequence over the frame: tests/test_lazy_pixels.py)
+    held = img.pixels
+    _fill_image(img, arr)  # (in place; the opt-in lazy sequence: tests/test_lazy_pixels.py)
+    assert img.pixels is held
     assert all(isinstance(c, RefColor) for c in img.pixels)
     assert (img.pixels[4].r, img.pixels[4].g, img.pixels[4].b) == (12.0, 13.0, 14.0)  # (x=1, y=1) -> 1*3+1
 

@@ -1,5 +1,5 @@
-"""``pytracer_amd.pixels.LazyPixels`` -- what ``GpuImageTracer`` installs as ``image.pixels`` of a reference-style
-``HdrImage`` (VERDICT r3 missing #4) -- must behave like the list of ``Color`` objects it replaces under everything the
+"""``pytracer_amd.pixels.LazyPixels`` -- what ``GpuImageTracer(lazy_pixels=True)`` installs as ``image.pixels`` of a
+reference-style ``HdrImage`` (VERDICT r3 missing #4; opt-in since ADVICE r4: the default fills the list in place) -- must behave like the list of ``Color`` objects it replaces under everything the
 reference does with it (hdrimages.py:78-146): first on its own, then -- where the reference is importable (the build
 container) -- under the reference's OWN ``HdrImage.get_pixel / set_pixel / write_pfm / average_luminosity /
 normalize_image / clamp_image``, against the same image filled eagerly.  No GPU, no oracle."""
@@ -59,21 +59,51 @@ def test_list_semantics():
     assert px2.as_array().base is arr or px2.as_array() is arr.reshape(-1, 3) or np.shares_memory(px2.as_array(), arr)
 
 
-def test_fill_is_lazy_by_default_and_eager_on_request():
+def test_fill_is_in_place_by_default_and_lazy_on_request():
     arr = np.arange(18, dtype=np.float64).reshape(2, 3, 3)
+    img2 = RefImage(3, 2)
+    held, old5 = img2.pixels, img2.pixels[5]
+    _fill_image(img2, arr)  # the default: the reference's set_pixel loop -- same list object, new Color objects
+    assert img2.pixels is held and isinstance(held, list) and held[4].g == 13.0
+    assert held[5] is not old5 and (old5.r, old5.g, old5.b) == (0.0, 0.0, 0.0)  # set_pixel REPLACES (hdrimages.py:86-94)
+    held.append(RefColor())  # (a real list: whatever a caller does with lists works)
+    held.pop()
     img = RefImage(3, 2)
-    held = img.pixels
-    _fill_image(img, arr.copy())
+    _fill_image(img, arr.copy(), lazy=True)
     assert isinstance(img.pixels, LazyPixels) and img.pixels.color_cls is RefColor
     assert (img.pixels[4].r, img.pixels[4].g, img.pixels[4].b) == (12.0, 13.0, 14.0)
-    _fill_image(img, arr.copy() + 1.0)  # a second frame into the same image: the colour class is remembered
+    _fill_image(img, arr.copy() + 1.0, lazy=True)  # a second frame into the same image: the colour class is remembered
     assert isinstance(img.pixels[0], RefColor) and img.pixels[0].r == 1.0
-    img2 = RefImage(3, 2)
-    held = img2.pixels
-    _fill_image(img2, arr, eager=True)
-    assert img2.pixels is held and isinstance(held, list) and held[4].g == 13.0
-    _fill_image(img, arr, eager=True)  # eager after lazy: a plain list again
+    _fill_image(img, arr)  # in place after lazy: a plain list again
     assert isinstance(img.pixels, list) and img.pixels[5].b == 17.0
+
+
+def test_tracer_spells_the_switch_both_ways():
+    from pytracer_amd.tracer import GpuImageTracer
+
+    img = RefImage(2, 2)
+    assert GpuImageTracer(img, None).lazy_pixels is False
+    assert GpuImageTracer(img, None, lazy_pixels=True).lazy_pixels is True
+    assert GpuImageTracer(img, None, eager_fill=False).lazy_pixels is True  # round 4's spelling
+    assert GpuImageTracer(img, None, eager_fill=True).lazy_pixels is False
+
+
+def test_collapses_to_a_list_once_everything_was_read():
+    arr = np.arange(36, dtype=np.float64).reshape(3, 4, 3)
+    px = LazyPixels(arr.copy(), RefColor)
+    first = px[3]
+    first.g = -5.0
+    seen = list(px)  # (what normalize_image / clamp_image do: every pixel materialised)
+    assert px._made is None and px._arr is None and isinstance(px._all, list) and "12 materialised" in repr(px)
+    assert px[3] is first and seen[3] is first and px[3].g == -5.0 and len(px) == 12
+    c = RefColor(1.0, 2.0, 3.0)
+    px[-1] = c
+    assert px[11] is c and px[2:4][1] is first
+    back = px.as_array()
+    assert back.shape == (12, 3) and back[3, 1] == -5.0 and back[11].tolist() == [1.0, 2.0, 3.0] and back[0].tolist() == [0.0, 1.0, 2.0]
+    px2 = LazyPixels(arr.copy(), RefColor)
+    px2[:] = [RefColor(float(i), 0.0, 0.0) for i in range(12)]  # assigned, never read: collapses as well
+    assert px2._all is not None and px2[7].r == 7.0
 
 
 def test_a_720p_frame_is_handed_over_in_under_a_millisecond():
@@ -82,7 +112,7 @@ def test_a_720p_frame_is_handed_over_in_under_a_millisecond():
     img.width, img.height = W, H
     arr = np.random.default_rng(1).random((H, W, 3))
     t0 = time.perf_counter()
-    _fill_image(img, arr)
+    _fill_image(img, arr, lazy=True)
     dt = time.perf_counter() - t0
     assert len(img.pixels) == W * H and dt < 5e-3, f"{dt * 1e3:.3f} ms"  # (measured ~0.02 ms; 490 ms eagerly)
     assert img.pixels[W * 5 + 3].g == arr[5, 3, 1]
@@ -115,8 +145,8 @@ def test_reference_hdrimage_methods_on_lazy_pixels(ref):
     W, H = 7, 5
     arr = np.random.default_rng(3).random((H, W, 3)) * 4.0
     lazy, eager = HdrImage(W, H), HdrImage(W, H)
-    _fill_image(lazy, arr.copy())
-    _fill_image(eager, arr.copy(), eager=True)
+    _fill_image(lazy, arr.copy(), lazy=True)
+    _fill_image(eager, arr.copy())
     assert isinstance(lazy.pixels, LazyPixels) and isinstance(eager.pixels, list)
 
     def same():

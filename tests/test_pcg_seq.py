@@ -37,6 +37,29 @@ def test_seeds_are_recovered_from_a_generator_that_has_been_drawn_from():
     assert (h.state, h.inc) == (g.state, g.inc) and [h.random() for _ in range(5)] == [g.random() for _ in range(5)]
 
 
+def test_derived_alignments_keep_the_seeds_a_generator_was_built_with():
+    """pixel / sample generators are derived from a seed pair, so a PCG that has been drawn from still names
+    the pair it was BUILT with (round 3's frames); only "seq" continues the stream from where the generator has got to."""
+    world = scenes.synthetic_world(8)
+    g, t = hm.PCG(45, 54), hm.PCG(7, 9)
+    for _ in range(5):
+        g.random()
+        t.random()
+    assert flatten.recover_seeds(g, constructed=True) == (45, 54) and flatten.recover_seeds(g) != (45, 54)
+    pt = hm.PathTracer(world, pcg=g, num_of_rays=1, max_depth=2)
+    for mode in (abi.PCG_PIXEL, abi.PCG_SAMPLE):
+        par = flatten.renderer_params(pt, 16, 9, samples_per_side=2, tracer_pcg=t, pcg_mode=mode)
+        assert (par.path_state, par.path_seq, par.jitter_state, par.jitter_seq) == (45, 54, 7, 9)
+    par = flatten.renderer_params(hm.FlatRenderer(world), 16, 9, samples_per_side=2, tracer_pcg=t, pcg_mode=abi.PCG_SEQ)
+    h = hm.PCG(par.jitter_state, par.jitter_seq)
+    assert (h.state, h.inc) == (t.state, t.inc)  # "seq": the stream goes on where the tracer's generator is
+
+    class Bare:  # the reference's PCG: (state, inc) only -> solved for, whatever the mode
+        state, inc = hm.PCG(45, 54).state, hm.PCG(45, 54).inc
+
+    assert flatten.recover_seeds(Bare, constructed=True) == (45, 54)
+
+
 def test_seq_fixtures_exist_for_the_three_renderers():
     names = [n for n in util.FRAME_FIXTURES if n.startswith("g5_seq_")]
     kinds = set()
