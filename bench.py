@@ -61,6 +61,12 @@ VALU_ISSUE_CYCLES = {"SQ_INSTS_VALU_ADD_F64": 4, "SQ_INSTS_VALU_MUL_F64": 4, "SQ
                      "SQ_INSTS_VALU_CVT": 4, "SQ_INSTS_VALU_INT32": 2, "SQ_INSTS_VALU_INT64": 4}
 VALU_OTHER_CYCLES = (2, 3, 4)   # (low, priced, high) for instructions outside the class counters
 SALU_ISSUE_CYCLES = 4
+# What a scalar instruction costs the VECTOR issue of its SIMD: not nothing.  Measured with the same
+# microbenchmark under rocprofv3 (profiles/r03_issue_pmc_probe.txt, 4 waves per SIMD): v_mul_f64 alone 4.88 SIMD-cycles per
+# instruction, v_mul_f64 + s_add_u32 1:1 6.29 -> +1.41 per scalar instruction; v_add_u32 2.58 -> 6.15 with s_add_u32 1:1
+# (the scalar unit's 4 cycles per SIMD become the bound there); v_add_f32 + s_add_u32 2:1 2.77 per VALU -> +0.24, 4:1 -> +1.56.
+# Priced: 1.4 SIMD-cycles of lost vector issue per scalar instruction (the fp64 figure: the kernels here are fp64 chains).
+SALU_COISSUE_PENALTY_CYCLES = 1.4
 FP64_CLASSES = ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64")
 
 
@@ -75,12 +81,27 @@ def priced_issue(counters, simd_cycles):
     base = sum(counters[k] * c for k, c in VALU_ISSUE_CYCLES.items())
     lo, mid, hi = (base + other * c for c in VALU_OTHER_CYCLES)
     f64 = sum(counters[k] * VALU_ISSUE_CYCLES[k] for k in FP64_CLASSES)
-    return {"valu_issue_cycles": mid, "frac": mid / simd_cycles, "frac_other_at_2": lo / simd_cycles, "frac_other_at_4": hi / simd_cycles,
-            "fp64_pipe_frac": f64 / simd_cycles,
-            "salu_issue_frac": counters.get("SQ_INSTS_SALU", 0.0) * SALU_ISSUE_CYCLES / simd_cycles,
-            "mean_cycles_per_valu_instruction": mid / valu,
-            "instructions_by_class": {**{k.replace("SQ_INSTS_VALU_", "").lower(): counters[k] for k in VALU_ISSUE_CYCLES}, "other": other},
-            "fp64_instruction_share": sum(counters[k] for k in FP64_CLASSES) / valu}
+    salu = counters.get("SQ_INSTS_SALU", 0.0)
+    row = {"valu_issue_cycles": mid, "frac": mid / simd_cycles, "frac_other_at_2": lo / simd_cycles, "frac_other_at_4": hi / simd_cycles,
+           "fp64_pipe_frac": f64 / simd_cycles,
+           "salu_issue_frac": salu * SALU_ISSUE_CYCLES / simd_cycles,
+           # vector issue INCLUDING what the scalar instructions take from it (they do not issue entirely beside the VALU)
+           "frac_with_salu_coissue": (mid + salu * SALU_COISSUE_PENALTY_CYCLES) / simd_cycles,
+           "mean_cycles_per_valu_instruction": mid / valu,
+           "instructions_by_class": {**{k.replace("SQ_INSTS_VALU_", "").lower(): counters[k] for k in VALU_ISSUE_CYCLES}, "other": other},
+           "unclassed_share": other / valu,
+           "fp64_instruction_share": sum(counters[k] for k in FP64_CLASSES) / valu}
+    # counter-derived cross-checks, no price table involved: SQ_ACTIVE_INST_VALU counts quad-cycles of VALU execution (1 per
+    # ordinary instruction whether it issues in 2 or 4 cycles, 2 / 4 for 8- / 16-cycle transcendentals:
+    # profiles/r03_issue_pmc_probe.txt), so x 4 / SIMD-cycles is the utilisation with every fp32 / int32 instruction
+    # charged 4 cycles -- an UPPER bracket of `frac`; SQ_WAIT_ANY / SQ_WAVE_CYCLES: share of their lifetime the waves wait
+    if "SQ_ACTIVE_INST_VALU" in counters:
+        row["frac_counter_active_inst_valu_x4"] = counters["SQ_ACTIVE_INST_VALU"] * 4.0 / simd_cycles
+    if counters.get("SQ_WAVE_CYCLES"):
+        for name, key in (("SQ_WAIT_ANY", "wave_cycles_waiting_any_frac"), ("SQ_WAIT_INST_ANY", "wave_cycles_waiting_inst_frac")):
+            if name in counters:
+                row[key] = counters[name] / counters["SQ_WAVE_CYCLES"]
+    return row
 
 C4 = dict(n_spheres=256, wide=True, W=3840, H=2160,
           kw=dict(renderer=abi.RENDERER_PATHTRACER, samples_per_side=8, num_of_rays=1, max_depth=5, rr_limit=3,
@@ -288,7 +309,9 @@ def extra_rows(device: int):
                        ("C3_same_PT_PCG_SAMPLE", "pmc_c3_second_pass_sample.json"),
                        ("C4_same_PT_PCG_SAMPLE", "pmc_c4_second_pass_sample.json")):
         pmc = load_profile(fname)
-        if pmc is not None and tag in rows:
+        if pmc is not None and not fresh(pmc) and tag in rows:
+            rows[tag]["second_pass_executed"] = {"frac": None, "reason": pmc["stale"]}
+        if fresh(pmc) and tag in rows:
             valu, dur = pmc["counters"]["SQ_INSTS_VALU"], pmc["dur_us"] * 1e-6
             simd_cycles = n_cu * 4 * dur * clock_khz * 1e3
             pr = priced_issue(pmc["counters"], simd_cycles)
@@ -296,19 +319,24 @@ def extra_rows(device: int):
                 "kernel": "pt_path_regions_kernel", "valu_wave_instructions_per_launch": valu, "kernel_us_under_pmc_collection": pmc["dur_us"],
                 "valu_issue_utilisation_if_every_instruction_took_4_cycles": valu * 4 / simd_cycles,
                 "valu_issue_utilisation": pr["frac"] if pr else None, "fp64_pipe_frac": pr["fp64_pipe_frac"] if pr else None,
+                "frac_counter_active_inst_valu_x4": pr.get("frac_counter_active_inst_valu_x4") if pr else None,
+                "unclassed_share": pr["unclassed_share"] if pr else None,
+                "code_hash": pmc.get("code_hash"), "kernel_resources": pmc.get("kernel_resources"),
                 "source": pmc.get("source")}
     # C5: HBM bytes per frame of its two kernels (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 passes, medians
     # committed under profiles/) over the kernel time measured here
     c5 = rows.get("C5_flat_1280x720_10k_spheres")
     tile, cell = load_profile("pmc_c5_tile.json"), load_profile("pmc_c5_cell.json")
-    if c5 is not None and tile is not None and cell is not None and "hbm_bytes_per_launch" in tile and "hbm_bytes_per_launch" in cell:
+    if c5 is not None and (tile is not None and not fresh(tile) or cell is not None and not fresh(cell)):
+        c5["hbm"] = {"frac": None, "reason": (tile if not fresh(tile) else cell)["stale"]}
+    if c5 is not None and fresh(tile) and fresh(cell) and "hbm_bytes_per_launch" in tile and "hbm_bytes_per_launch" in cell:
         nbytes = tile["hbm_bytes_per_launch"] + cell["hbm_bytes_per_launch"]
         gbs = nbytes / (c5["ms_per_frame"] * 1e-3) / 1e9
         c5["hbm"] = {"bytes_per_frame": nbytes, "achieved_GB_s": gbs, "peak_GB_s": PEAK_HBM_GBS, "frac": gbs / PEAK_HBM_GBS,
                      "algorithmic_bytes_per_frame": 1280 * 720 * 12 + 10000 * (128 + 256 + 16),
                      "note": "pt_cell_kernel + pt_tile_kernel<FLAT, HIER>: pixels written once, the 10 000 shapes' bounds read per "
                              "32x32-pixel cell group, survivor lists written and re-read -- far from the HBM roof: the frame is "
-                             "bound by the culling arithmetic", "source": tile.get("source")}
+                             "bound by the culling arithmetic", "code_hash": tile.get("code_hash"), "source": tile.get("source")}
     return rows
 
 
@@ -423,12 +451,40 @@ def boundary_rows(flat, device: int, rays_per_frame: int):
     return rows
 
 
-def load_profile(name):
+_loaded_code_hash = None
+
+
+def loaded_code_hash():
+    """sha256 of the device code of the library this process loaded (pytracer_amd.build.code_hash of _lib.lib_path())."""
+    global _loaded_code_hash
+    if _loaded_code_hash is None:
+        from pytracer_amd import _lib
+        from pytracer_amd.build import code_hash
+
+        _loaded_code_hash = code_hash(_lib.lib_path())
+    return _loaded_code_hash
+
+
+def load_profile(name, want_hash="loaded"):
+    """A committed PMC summary (profiles/pmc_*.json, tools/pmc_summary.py) -- but only if it measured THIS binary: the file
+    records the sha256 of the device code it was collected on, and a file of another build (or of a round before files
+    carried a hash) comes back as {"stale": reason} so that nothing is priced from it."""
     path = os.path.join(ROOT, "profiles", name)
-    if os.path.exists(path):
-        with open(path) as f:
-            return json.load(f)
-    return None
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        pmc = json.load(f)
+    if want_hash is None:
+        return pmc
+    have = loaded_code_hash() if want_hash == "loaded" else want_hash
+    if pmc.get("code_hash") != have:
+        return {"stale": f"profiles/{name} was collected on device code {str(pmc.get('code_hash'))[:16]}, this run loaded {have[:16]}: "
+                         "not priced (re-run tools/prof_bench.sh on this build)"}
+    return pmc
+
+
+def fresh(pmc):
+    return pmc is not None and "stale" not in pmc
 
 
 def fence(dist):
@@ -460,22 +516,39 @@ def timed_loop(ds, loop, steps, dist, gather, events=True):
     return elapsed, kernel_total_ms, launches
 
 
-def bracketed_loop(ds, loop, steps):
+def bracketed_loop(ds, loop, steps, repeats=1):
     """The K launches of the timed region between ONE pair of HIP events recorded on the stream the kernels are
     launched on (no host synchronisation, no per-launch events in between): -> average duration of a launch in
-    seconds = what rocprofv3's kernel trace shows for the same kernel run back to back."""
+    seconds = what rocprofv3's kernel trace shows for the same kernel run back to back.  Median of `repeats` such loops."""
     ds.set_count_rays(False)
     ds.set_timing(False)
-    loop.step(0, gather=False)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(loop.stream)
-    for i in range(steps):
-        loop.step(i, gather=False)
-    e1.record(loop.stream)
-    e1.synchronize()
+    per_launch = []
+    for _ in range(max(1, repeats)):
+        loop.step(0, gather=False)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(loop.stream)
+        for i in range(steps):
+            loop.step(i, gather=False)
+        e1.record(loop.stream)
+        e1.synchronize()
+        per_launch.append(e0.elapsed_time(e1) * 1e-3 / steps)
     ds.set_timing(True)
-    return e0.elapsed_time(e1) * 1e-3 / steps
+    return float(np.median(per_launch))
+
+
+def pre_roll(loop, min_ms=30.0, chunk=50):
+    """Untimed launches of the headline kernel until `min_ms` of wall time have passed (chunks of `chunk` frames, a device
+    synchronisation behind each): the GPU's clocks ramp over the first milliseconds of work, and a 20-launch timed loop of
+    14-us frames (the driver's command) is over before they have (VERDICT r4 weak #4 / next 2).  -> (launches, ms)."""
+    t0 = time.perf_counter()
+    n = 0
+    while (time.perf_counter() - t0) * 1e3 < min_ms:
+        for i in range(chunk):
+            loop.step(i, gather=False)
+        n += chunk
+        torch.cuda.synchronize()
+    return n, (time.perf_counter() - t0) * 1e3
 
 
 def in_flight_rows(flat, cam, par, steps, local_rank, rays_per_step, pmc, n_simd, clock_hz):
@@ -540,14 +613,20 @@ def run_single(args, local_rank):
     rays_per_step, resolved = int(st.n_rays), int(st.n_rays_resolved)
     n_wg = st.grid
     # the headline: K frames back to back -- the K-step loop REPEATED (20 launches of 14 us are a 0.3 ms
-    # timed region); `value` / `ms_per_step` are the MEDIAN repeat, min and max beside them
-    repeats = max(1, args.repeats)
+    # timed region); `value` / `ms_per_step` are the MEDIAN repeat, min and max beside them.  Before the first timed loop the
+    # same launches run untimed for >= 30 ms (clocks), and the loop is repeated until >= 20 ms have been timed (at least
+    # --repeats times): K stays what --steps says for every loop
+    ds.set_count_rays(False)
+    ds.set_timing(False)
+    pre_n, pre_ms = pre_roll(loop, args.pre_roll_ms)
+    est_loop_s = max(1e-6, pre_ms * 1e-3 / max(1, pre_n) * args.steps)
+    repeats = max(1, args.repeats, min(400, int(np.ceil(args.min_timed_ms * 1e-3 / est_loop_s))))
     elapsed_all = [timed_loop(ds, loop, args.steps, None, False, events=False)[0] for _ in range(repeats)]
     elapsed = float(np.median(elapsed_all))
     parity = parity_check(flat, cam, par, loop.image())  # the frame those loops left in HBM, against the oracle's
     elapsed_ev, kernel_total_ms, launches = timed_loop(ds, loop, args.steps, None, False, events=True)  # the same, every launch with its own event pair
     per_launch_pair_s = kernel_total_ms / max(launches, 1) * 1e-3
-    avg_kernel_s = bracketed_loop(ds, loop, args.steps)  # the same K launches between one event pair on their stream
+    avg_kernel_s = bracketed_loop(ds, loop, args.steps, repeats)  # the same K launches between one event pair on their stream (median of the repeats)
     ms_per_step = elapsed / args.steps * 1e3
 
     # the same frames with the dome shortcut off: every primary ray generated and traced
@@ -572,7 +651,7 @@ def run_single(args, local_rank):
         "bound": "valu_issue",
         "achieved": None, "peak": None, "unit": "T lane-op/s (executed VALU lane-operations, any type)", "frac": None, "traffic": None,
         "kernel": "pt_tile4_kernel<FLAT> (16x16 tiles, four pixels per lane, culled shape lists, hoisted scale+translate tests)",
-        "avg_kernel_ms": avg_kernel_s * 1e3, "launches_timed": args.steps,
+        "avg_kernel_ms": avg_kernel_s * 1e3, "launches_timed": args.steps * repeats,
         "avg_kernel_ms_method": "K launches back to back between one HIP event pair recorded on their stream / K (rocprofv3's "
                                 "kernel trace of the same command shows the same average for launches run back to back)",
         "per_launch_event_pair_ms": per_launch_pair_s * 1e3,
@@ -587,11 +666,17 @@ def run_single(args, local_rank):
                 "average duration measured here over every timed launch).  `achieved` = executed VALU lane-operations per "
                 "second; `peak` = achieved / frac = the rate at which this instruction mix would issue with no SIMD ever idle.  "
                 "fp64_pipe_frac counts the fp64 instructions alone (x 4, transcendentals x 16); salu_issue_frac the scalar "
-                "instructions (x 4 per SIMD, issued beside the VALU).",
+                "instructions (x 4 per SIMD); frac_with_salu_coissue adds the vector issue a scalar instruction costs (1.4 "
+                "cycles, measured: profiles/r03_issue_pmc_probe.txt); frac_counter_active_inst_valu_x4 = SQ_ACTIVE_INST_VALU x 4 / "
+                "SIMD-cycles, a pure counter figure that charges every fp32 / int32 instruction 4 cycles (upper bracket); "
+                "executed.code_hash = the device code the counters were collected on, compared with the library this run loaded.",
     }
     if avg_kernel_s * 1e3 > ms_per_step * 1.05:
         roofline["avg_kernel_ms"] = None
         roofline["note"] += " (kernel time discarded: it exceeded the step time)"
+    elif pmc is not None and not fresh(pmc):
+        roofline["reason_frac_is_null"] = pmc["stale"]
+        roofline["note"] += " (NOT PRICED: " + pmc["stale"] + ")"
     elif pmc is not None:
         valu = pmc["counters"]["SQ_INSTS_VALU"]
         simd_cycles = n_simd * avg_kernel_s * clock_hz
@@ -602,12 +687,32 @@ def run_single(args, local_rank):
         roofline["executed"] = {"valu_wave_instructions_per_launch": valu,
                                 "salu_wave_instructions_per_launch": pmc["counters"].get("SQ_INSTS_SALU"),
                                 "kernel_us_under_pmc_collection": pmc.get("dur_us"), "simds": n_simd, "clock_GHz": clock_hz / 1e9,
-                                "kernel_profiled": pmc.get("kernel"), "source": pmc.get("source")}
+                                "kernel_profiled": pmc.get("kernel"), "source": pmc.get("source"),
+                                "code_hash": pmc.get("code_hash"), "code_hash_matches_loaded_library": pmc.get("code_hash") == loaded_code_hash(),
+                                "kernel_resources": pmc.get("kernel_resources")}
         if pr is not None:
             roofline["frac"] = pr["frac"]
             roofline["peak"] = ach / pr["frac"]
-            roofline.update({k: pr[k] for k in ("frac_other_at_2", "frac_other_at_4", "fp64_pipe_frac", "salu_issue_frac")})
-            roofline["executed"].update({k: pr[k] for k in ("mean_cycles_per_valu_instruction", "instructions_by_class", "fp64_instruction_share")})
+            roofline.update({k: pr[k] for k in ("frac_other_at_2", "frac_other_at_4", "fp64_pipe_frac", "salu_issue_frac", "frac_with_salu_coissue",
+                                                "frac_counter_active_inst_valu_x4", "wave_cycles_waiting_any_frac", "wave_cycles_waiting_inst_frac") if k in pr})
+            roofline["executed"].update({k: pr[k] for k in ("mean_cycles_per_valu_instruction", "instructions_by_class", "unclassed_share", "fp64_instruction_share")})
+            roofline["frac_method"] = "class counters, unclassed instructions at 3 cycles"
+            mix = pmc.get("static_mix")
+            if mix:  # tools/isa_mix.py: the kernel's disassembly priced instruction by instruction, block counts bounded by the counters
+                roofline["executed"]["static_mix"] = {k: v for k, v in mix.items() if k not in ("static_valu_mix", "dynamic_mix_at_min")}
+                if mix.get("valu_issue_cycles_bounds") and mix.get("code_hash") == loaded_code_hash():
+                    # every VALU instruction of the disassembly at its measured price; how often each basic block runs bounded by
+                    # the control-flow graph and all per-launch counters: frac = the middle of what they allow, the bounds beside it
+                    lo_c, hi_c = mix["valu_issue_cycles_bounds"]
+                    roofline["frac_bounds_from_disassembly"] = [lo_c / simd_cycles, hi_c / simd_cycles]
+                    roofline["frac_class_counters_other_at_3"] = roofline["frac"]
+                    roofline["frac"] = 0.5 * (lo_c + hi_c) / simd_cycles
+                    roofline["peak"] = ach / roofline["frac"]
+                    roofline["frac_method"] = ("tools/isa_mix.py: the kernel's disassembly, every VALU instruction at its MEASURED issue cost "
+                                               "(tools/micro/issue.hip, issue2.hip), basic-block execution counts bounded by two linear "
+                                               "programmes over the control-flow graph and the per-launch PMC counters; frac = midpoint")
+                    salu = pmc["counters"].get("SQ_INSTS_SALU", 0.0)
+                    roofline["frac_with_salu_coissue"] = (0.5 * (lo_c + hi_c) + salu * SALU_COISSUE_PENALTY_CYCLES) / simd_cycles
         else:
             roofline["note"] += " (profiles/pmc_c2.json lacks the per-class counters: frac not priced)"
     roofline["algorithmic_equivalent"] = {
@@ -630,8 +735,13 @@ def run_single(args, local_rank):
         "ms_per_step": ms_per_step,
         "repeats": {"n": repeats, "ms_per_step_median": ms_per_step, "ms_per_step_min": min(elapsed_all) / args.steps * 1e3,
                     "ms_per_step_max": max(elapsed_all) / args.steps * 1e3,
-                    "ms_per_step_all": [e / args.steps * 1e3 for e in elapsed_all],
-                    "note": "the K-step timed loop run `n` times back to back; value and ms_per_step are the median repeat"},
+                    "ms_per_step_first_5": [e / args.steps * 1e3 for e in elapsed_all[:5]],
+                    "ms_per_step_last_5": [e / args.steps * 1e3 for e in elapsed_all[-5:]],
+                    "timed_ms_total": sum(elapsed_all) * 1e3,
+                    "pre_roll": {"launches": pre_n, "ms": pre_ms, "note": "untimed launches of the same kernel before the first timed loop (clock ramp)"},
+                    "note": "the K-step timed loop run `n` times back to back (until >= 20 ms are timed); value and ms_per_step are the median repeat"},
+        "hip_force_dev_kernarg": os.environ.get("HIP_FORCE_DEV_KERNARG"),
+        "code_hash": loaded_code_hash(),
         "parity_check": parity,
         "higher_is_better": True,
         "scaling": "weak",
@@ -653,14 +763,9 @@ def run_single(args, local_rank):
         result["error"] = f"parity_check failed: the timed frame differs from the oracle's in {parity.get('pixels_differing', '?')} pixels"
         result["value_unchecked"], result["value"] = result["value"], None
     ds.close()
-    if args.in_flight:
-        result["frames_in_flight"] = in_flight_rows(flat, cam, par, args.steps, local_rank, rays_per_step, pmc, n_simd, clock_hz)
-    else:  # (not measured by this command -- its launches run back to back --: the committed line of `bench.py --in-flight`)
-        committed = load_profile("r04_bench_in_flight.json")
-        if committed is not None and "frames_in_flight" in committed:
-            result["frames_in_flight_committed"] = dict(committed["frames_in_flight"],
-                                                        source="profiles/r04_bench_in_flight.json = `python bench.py --in-flight "
-                                                               "--no-extras --no-cpu-baseline` on one MI355X; NOT measured by this run")
+    if not args.no_in_flight:  # measured by THIS run (round 4 pasted a committed line here): a few hundred frames, behind the headline loops
+        result["frames_in_flight"] = in_flight_rows(flat, cam, par, args.in_flight_steps, local_rank, rays_per_step, pmc if fresh(pmc) else None,
+                                                    n_simd, clock_hz)
     if not args.no_extras:
         result["extra"] = extra_rows(local_rank)
         result["boundary"] = boundary_rows(flat, local_rank, rays_per_step)
@@ -1136,9 +1241,12 @@ def main():
     ap.add_argument("--repeats", type=int, default=5, help="N=1: how often the K-step timed loop is repeated (median reported)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
-    ap.add_argument("--in-flight", action="store_true",
-                    help="N=1: also time the same frames with 2 and 4 of them in flight (pytracer_amd.pipeline); off by default so "
-                         "that every launch of the headline kernel in the default command runs back to back")
+    ap.add_argument("--pre-roll-ms", type=float, default=30.0, help="N=1: untimed launches before the first timed loop, in ms of wall time")
+    ap.add_argument("--min-timed-ms", type=float, default=20.0, help="N=1: the K-step loop is repeated until this much has been timed")
+    ap.add_argument("--no-in-flight", action="store_true", help="N=1: skip the rows with 2 and 4 frames in flight")
+    ap.add_argument("--in-flight-steps", type=int, default=100,
+                    help="N=1: frames per in-flight row (few against the headline's launches: rocprofv3's average of the headline "
+                         "kernel over the whole command stays that of launches run back to back)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

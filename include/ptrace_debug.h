@@ -50,6 +50,41 @@ int pt_debug_scatter_probe(const double *in, int n, double *out, unsigned long l
  * -DPT_DEBUG_TIME build). */
 int pt_debug_read_queue(pt_scene *scene, unsigned long long *out16);
 
+/* What a frame WILL launch -- the plan pt_render / pt_render_device follow (csrc/pt_plan.h) -- computed on the HOST from a scene
+ * DESCRIPTION, a camera and the parameters: no device is touched, so the choice of kernels, grids, LDS and thresholds is
+ * testable on any machine (tests/test_plan.py).  n_cu: compute units to plan for (<= 0: 256, the MI355X); dome_shortcut as
+ * pt_set_dome_shortcut.  Kernel names are the templates' with their variant spelled out, "" where a stage does not run. */
+typedef struct pt_plan_info {
+  int32_t kernel;            /* PT_KERNEL_* of the render kernel proper (before the device's choice, see alt_kernel) */
+  int32_t rows;              /* image rows of this rank */
+  int64_t npix;
+  char pre_kernel[48];       /* "pt_cell_kernel" for worlds of more than 256 shapes, else "" */
+  char first_kernel[64];     /* path tracer: the first pass */
+  char main_kernel[64];      /* the render kernel proper / the path tracer's second pass */
+  char alt_kernel[64];       /* num_of_rays > 1: the one-queue kernel enqueued behind the tree kernel (the device picks) */
+  int32_t grid, grid_first, grid_alt;         /* workgroups of 256 threads */
+  int32_t grid4_x, grid4_y, npx;              /* pt_tile4_kernel: its 2-D grid and pixels per lane */
+  int64_t lds_first, lds_main, lds_alt;       /* dynamic LDS per workgroup, bytes */
+  int32_t frame_stack_home;  /* path tracer: 0 none, 1 LDS, 2 HBM */
+  int32_t alt_frame_stack_home;
+  int32_t frame_doubles;     /* fields per stack frame */
+  int64_t workspace_bytes;   /* frame stack in HBM */
+  int64_t q_min_flagged;     /* flagged pixels from which the device lets the one-queue kernel work (-1: never) */
+  int32_t wg_per_cu, block_h, hier, ortho, hoist, tile4_lds;
+  int32_t n_spheres, n_diag, has_grid, ball_levels;  /* the scene facts the plan was made from */
+  int32_t units_need, nregions, min_rounds, spec_draws;
+  int32_t _reserved[8];
+} pt_plan_info;
+int pt_debug_plan(const pt_scene_desc *desc, const pt_camera *cam, const pt_params *params, int n_cu, int dome_shortcut,
+                  pt_plan_info *out);
+/* The plan a handle's next frame follows (its own n_cu and switches). */
+int pt_debug_plan_scene(pt_scene *scene, const pt_camera *cam, const pt_params *params, pt_plan_info *out);
+/* One of the debug / measurement switches (csrc/pt_plan.h: PT_TUNING_TABLE; by field name or by its PTRACE_* environment
+ * name).  The table is read from the environment when the library first needs it; this changes it afterwards, also between
+ * scenes of one process.  None changes a pixel.  Returns PT_ERR_INVALID for an unknown name. */
+int pt_debug_set_tuning(const char *name, long long value);
+int pt_debug_get_tuning(const char *name, long long *value);
+
 #ifdef PT_DEBUG_TIME /* instrumented builds only (tools/dbg*.py) */
 int pt_debug_read_dbg(unsigned long long *out8, int reset);
 int pt_debug_read_lat_hist(unsigned long long *out160, int clear);

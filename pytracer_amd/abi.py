@@ -124,6 +124,80 @@ class Stats(C.Structure):
     ]
 
 
+class PlanInfo(C.Structure):
+    """``pt_plan_info`` (include/ptrace_debug.h): what a frame will launch, from the host-side planner (csrc/pt_plan.h)."""
+
+    _fields_ = [
+        ("kernel", C.c_int32),
+        ("rows", C.c_int32),
+        ("npix", C.c_int64),
+        ("_pre_kernel", C.c_char * 48),
+        ("_first_kernel", C.c_char * 64),
+        ("_main_kernel", C.c_char * 64),
+        ("_alt_kernel", C.c_char * 64),
+        ("grid", C.c_int32),
+        ("grid_first", C.c_int32),
+        ("grid_alt", C.c_int32),
+        ("grid4_x", C.c_int32),
+        ("grid4_y", C.c_int32),
+        ("npx", C.c_int32),
+        ("lds_first", C.c_int64),
+        ("lds_main", C.c_int64),
+        ("lds_alt", C.c_int64),
+        ("frame_stack_home", C.c_int32),
+        ("alt_frame_stack_home", C.c_int32),
+        ("frame_doubles", C.c_int32),
+        ("workspace_bytes", C.c_int64),
+        ("q_min_flagged", C.c_int64),
+        ("wg_per_cu", C.c_int32),
+        ("block_h", C.c_int32),
+        ("hier", C.c_int32),
+        ("ortho", C.c_int32),
+        ("hoist", C.c_int32),
+        ("tile4_lds", C.c_int32),
+        ("n_spheres", C.c_int32),
+        ("n_diag", C.c_int32),
+        ("has_grid", C.c_int32),
+        ("ball_levels", C.c_int32),
+        ("units_need", C.c_int32),
+        ("nregions", C.c_int32),
+        ("min_rounds", C.c_int32),
+        ("spec_draws", C.c_int32),
+        ("_reserved", C.c_int32 * 8),
+    ]
+
+    STACK_HOMES = {0: None, 1: "LDS", 2: "HBM"}
+
+    @property
+    def pre_kernel(self) -> str:
+        return self._pre_kernel.decode()
+
+    @property
+    def first_kernel(self) -> str:
+        return self._first_kernel.decode()
+
+    @property
+    def main_kernel(self) -> str:
+        return self._main_kernel.decode()
+
+    @property
+    def alt_kernel(self) -> str:
+        return self._alt_kernel.decode()
+
+    @property
+    def kernels(self):
+        """The kernels of the frame in launch order (names as csrc/pt_plan.h spells them)."""
+        return [k for k in (self.pre_kernel, self.first_kernel, self.main_kernel, self.alt_kernel) if k]
+
+    @property
+    def frame_stack(self):
+        return self.STACK_HOMES[self.frame_stack_home]
+
+    @property
+    def alt_frame_stack(self):
+        return self.STACK_HOMES[self.alt_frame_stack_home]
+
+
 def _f64(a, shape=None) -> np.ndarray:
     a = np.ascontiguousarray(a, dtype=np.float64)
     if shape is not None:

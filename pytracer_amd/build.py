@@ -19,7 +19,38 @@ DEPS = ["ptrace.hip", "pt_kernels.h", "pt_math.h", "pt_query.h", "pt_shade.h", "
         "pt_tree.h", "pt_probes.h", "pt_layout.h", "pt_post.h", os.path.join("..", "..", "include", "ptrace.h"),
         os.path.join("..", "..", "include", "ptrace_debug.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-fast-math", "-std=c++17", "-fPIC",
-         "-shared", "-Wall", "-Wno-unused-function", "-Wno-pass-failed"]
+         "-shared", "-Wall", "-Wno-unused-function", "-Wno-pass-failed",
+         # a fixed compilation-unit id: by default clang derives it from the command line (paths included), which would make
+         # code_hash() depend on WHERE the library was built
+         "-cuid=libptrace"]
+
+
+def code_hash(lib: str = LIB) -> str:
+    """sha256 of the DEVICE code in ``lib``: the bytes of its ``.hip_fatbin`` ELF section (the gfx950 code object bundle
+    hipcc embedded).  Two builds with this hash equal run the same kernels; bench.py compares it with the hash recorded
+    in every ``profiles/pmc_*.json`` it prices a roofline from and refuses to price on a mismatch.
+    Pure Python (ELF64 little-endian section table): needs no ROCm tool, works wherever the library file is."""
+    import hashlib
+    import struct
+
+    with open(lib, "rb") as f:
+        data = f.read()
+    if data[:4] != b"\x7fELF" or data[4] != 2 or data[5] != 1:
+        raise ValueError(f"{lib}: not a little-endian ELF64 file")
+    shoff, = struct.unpack_from("<Q", data, 0x28)
+    shentsize, shnum, shstrndx = struct.unpack_from("<HHH", data, 0x3A)
+
+    def section(i):
+        name, _type, _flags, _addr, off, size = struct.unpack_from("<IIQQQQ", data, shoff + i * shentsize)
+        return name, off, size
+
+    _, stroff, strsize = section(shstrndx)
+    names = data[stroff:stroff + strsize]
+    for i in range(shnum):
+        name, off, size = section(i)
+        if names[name:names.index(b"\0", name)] == b".hip_fatbin":
+            return hashlib.sha256(data[off:off + size]).hexdigest()
+    raise ValueError(f"{lib}: no .hip_fatbin section (not a HIP library?)")
 
 
 def _hipcc() -> str:

@@ -123,8 +123,6 @@ struct PtKArgs {
   int tree_uniform_max;            // pt_path_tree_kernel: worlds up to this many shapes are queried by the wave-uniform loop
   int dbg_trace_unit;              // -DPT_DEBUG_TIME builds: the unit whose steps are traced (PTRACE_TRACE_UNIT)
   int spec_draws;                  // ... PT_PCG_PIXEL: draws per sample assumed for a pixel nothing is known about yet
-  int spec_win_lanes;              // ... pixels with at least this many lanes may speculate over a window of start states (seed_round; 65: never)
-  int spec_win_cover;              // ... in 16ths: the chance assumed for a pixel's next count to lie inside the window of its last eight
   unsigned long long *region_mask; // path tracer: [region] pixels the first pass left to pt_path_kernel
   unsigned char *region_keys;      // path tracer: [region] their number
   unsigned int *cell_list;         // large scenes: [cell][cell_stride] surviving slots (pt_cell_kernel)

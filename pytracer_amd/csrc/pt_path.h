@@ -317,12 +317,8 @@ PT_DEV void path_trace(const PtKArgs &a) {
   uint64_t hist = 0;
   int pscore = 0;                   // ... how much more often the upper neighbour was the better guess than the predecessor (per pixel)
   const int hperiod = (S >= 1 && S <= 8) ? S : 1;
-  // PT_PCG_PIXEL, pixels NEITHER guess works for (paths that bounce between spheres draw five or six different counts, none
-  // of them more than a third of the time: profiles/r03_c3_pixel_tail_units.txt): where a pixel has lanes to spare they
-  // trace the next samples from EVERY start state its recent counts allow -- sample vbase + d from vstate advanced by each
-  // integer in [d lo, d hi], lo / hi the smallest / largest count among its last eight samples -- and the round commits,
-  // level by level, whichever lane started from the state the level before it ended in (seed_round: "window").
-  int level = 0;                    // this lane's sample of the round is vbase + level
+  // (Round 4 also let pixels with lanes to spare trace the next samples from a WINDOW of start states; it moved a full frame
+  //  by nothing -- four lanes per pixel -- and was deleted in round 5: profiles/DROPPED_VARIANTS.md.)
   uint64_t st_start = 0;            // state this lane's sample started from
   unsigned srays = 0, prays = 0;    // rays of the current sample; of the pixel's validated samples
   unsigned long long gpix = 0;      // global pixel index (seeds)
@@ -347,13 +343,12 @@ PT_DEV void path_trace(const PtKArgs &a) {
     ray = primary_ray(a, col, grow, up, vp);
   };
 
-  // TILED: the sample of the round this lane traces (`level`: vbase + level) and the generator state it starts from.
-  // -> whether that sample exists (vbase + level < nsamp)
+  // TILED: the sample of the round this lane traces (vbase + jlane) and the generator state it starts from.
+  // -> whether that sample exists (vbase + jlane < nsamp)
   auto seed_round = [&]() -> bool {
     pt_kargs c = cold_args(a);
-    level = jlane;
     if (pcg_mode == PT_PCG_SAMPLE) {
-      samp = vbase + level;
+      samp = vbase + jlane;
       if (samp < nsamp) pcg_seed(pcg, c->s0, c->q0 + gpix * (unsigned)nsamp + (unsigned)samp);
     } else {
       // (sample vbase + i: what its upper neighbour vbase + i - period drew, if the pixel has got that far and that guess
@@ -364,53 +359,8 @@ PT_DEV void path_trace(const PtKArgs &a) {
         ahead = 0;
         for (int i = 0; i < jlane; ++i)
           ahead += (unsigned)(hist >> (vbase + (i % period) >= period ? 8 * (period - 1 - (i % period)) : 0)) & 0xffu;
-      } else if (L >= c->spec_win_lanes) {
-        // smallest and largest count of the last eight samples; how many of the seven neighbouring pairs drew alike
-        // (bytes of x that are zero: exact per-byte test, no borrow between bytes)
-        unsigned lo = (unsigned)hist & 0xffu, hi = lo;
-#pragma unroll
-        for (int k = 1; k < 8; ++k) {
-          const unsigned v = (unsigned)(hist >> (8 * k)) & 0xffu;
-          lo = v < lo ? v : lo;
-          hi = v > hi ? v : hi;
-        }
-        if (hi > lo) {
-          const uint64_t x = (hist ^ (hist >> 8)) & 0x00ffffffffffffffULL;
-          const uint64_t z = ~(((x & 0x7f7f7f7f7f7f7f7fULL) + 0x7f7f7f7f7f7f7f7fULL) | x | 0x7f7f7f7f7f7f7f7fULL) & 0x0080808080808080ULL;
-          // samples a round is expected to commit: the chain, 1 + p + p^2 + ... over L lanes with p the share of pairs that
-          // drew alike -- against the window, one level per d w + 1 lanes (w = hi - lo), each level reached with
-          // probability `cover` (the next count lies in [lo, hi])
-          const float pr = ((float)__popcll(z) + 0.5f) * (1.0f / 7.5f), cover = (float)c->spec_win_cover * (1.0f / 16.0f);
-          float e_chain = 0.0f, t = 1.0f;
-          for (int k = 0; k < L && k < 16; ++k) {
-            e_chain += t;
-            t *= pr;
-          }
-          const int w = (int)(hi - lo);
-          float e_win = 0.0f;
-          t = 1.0f;
-          for (int d = 0, n = 0; d < 16; ++d) {
-            const int width = d * w + 1;
-            if (n + width > L) {
-              e_win += t * (float)(L - n) / (float)width;
-              break;
-            }
-            n += width;
-            e_win += t;
-            t *= cover;
-          }
-          if (e_win > e_chain) {
-            int d = 0, r = jlane;
-            while (r >= d * w + 1) {
-              r -= d * w + 1;
-              ++d;
-            }
-            level = d;
-            ahead = (unsigned)d * lo + (unsigned)r;
-          }
-        }
       }
-      samp = vbase + level;
+      samp = vbase + jlane;
       pcg.state = pcg_advance(vstate, pcg.inc, ahead);
     }
     pcg.n = 0;
@@ -662,9 +612,7 @@ PT_DEV void path_trace(const PtKArgs &a) {
             if (pcg_mode == PT_PCG_SAMPLE) {
               chain = chain && s_fin != 0;
             } else {
-              // the lane's sample counts iff it is the NEXT one (its level = the samples committed so far this round) and it
-              // started from the state the sequential program is in; lanes come level by level, so a hypothesis that was
-              // wrong (or a level already settled by an earlier lane) is passed over and the walk goes on
+              // the lane's sample counts iff it is the NEXT one and it started from the state the sequential program is in
               chain = s_fin != 0 && s_samp == vbase && s_from == vstate;
             }
 #ifdef PT_DEBUG_TIME

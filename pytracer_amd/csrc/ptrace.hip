@@ -20,11 +20,9 @@
 #include "../../include/ptrace_debug.h"
 #include "pt_kernels.h"
 #include "pt_layout.h"
+#include "pt_plan.h"
 #include "pt_post.h"
 
-#ifndef PT_TILE4_NPX_SMALL
-#define PT_TILE4_NPX_SMALL 4  // pixels per lane of pt_tile4_kernel on frames with few 16x16 tiles (2: measured slower)
-#endif
 // major << 16 | minor.  The minor grows whenever a struct of include/ptrace.h grows or an entry point is added (minor 2:
 // pt_stats gained `kernel` + `_reserved`, pt_scene_clone / pt_image_sparse_* arrived; minor 3: PT_PCG_SEQ accepted for
 // OnOff / Flat / PointLight at any samples_per_side; minor 4: pt_device_kernargs, and the library no longer sets
@@ -317,20 +315,26 @@ static int handle_state(pt_scene *s) {
   return PT_OK;
 }
 
-extern "C" int pt_scene_upload(const pt_scene_desc *d, int device, pt_scene **out) {
-  if (!out) return fail(PT_ERR_INVALID, "null output handle");
-  *out = nullptr;
-  int rc = check_desc(d);
-  if (rc) return rc;
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
-    return fail(PT_ERR_NODEVICE, "no HIP device visible");
-  if (device < 0 || device >= ndev) return fail(PT_ERR_INVALID, "device %d out of range [0,%d)", device, ndev);
-  HIP_TRY(hipSetDevice(device));
+// What pt_scene_upload computes on the HOST before anything is uploaded: the records in slot order, the culling bounds, the
+// ball hierarchy, the uniform grid.  No HIP call: pt_debug_plan runs it for a scene DESCRIPTION on any machine (the scalars
+// land in `s`, used as a plain bag of facts there).
+struct HostTables {
+  std::vector<PtShapeRec> recs;
+  std::vector<PtShapeAux> aux;
+  std::vector<PtDiagRec> diag;
+  std::vector<float4> bounds;
+  std::vector<float> bsoa;
+  std::vector<PtLight> lights;
+  std::vector<PtTex> tex;
+  std::vector<double> tex_data;
+  bool has_grid = false;
+  std::vector<unsigned> grid_cells, grid_occ;
+  std::vector<unsigned short> grid_slots;
+  std::vector<float4> grid_balls;
+  std::vector<int> grid_always;
+};
 
-  pt_scene *s = new (std::nothrow) pt_scene();
-  if (!s) return fail(PT_ERR_NOMEM, "out of host memory");
-  s->device = device;
+static void analyse_scene(const pt_scene_desc *d, const PtTuning &tn, pt_scene *s, HostTables &h) {
   s->n_shapes = d->n_shapes;
   s->n_lights = d->n_lights;
   s->n_textures = d->n_textures;
@@ -491,14 +495,6 @@ extern "C" int pt_scene_upload(const pt_scene_desc *d, int device, pt_scene **ou
   }
   std::vector<double> tex_data(d->tex_data, d->tex_data + tex_doubles);
 
-#define UP(call)            \
-  do {                      \
-    rc = (call);            \
-    if (rc) {               \
-      pt_scene_free(s);     \
-      return rc;            \
-    }                       \
-  } while (0)
   std::vector<PtDiagRec> diag(s->n_diag);
   for (int slot = 0; slot < s->n_diag; ++slot) {
     PtDiagRec &g = diag[slot];
@@ -651,8 +647,8 @@ extern "C" int pt_scene_upload(const pt_scene_desc *d, int device, pt_scene **ou
       memcpy(dc.invm, recs[slot].invm, sizeof dc.invm);
       s->dome_cands.push_back(dc);
     }
-  UP(upload(&s->recs, recs));
-  UP(upload(&s->bounds, bounds));
+  h.recs = recs;
+  h.bounds = bounds;
   // ---- uniform grid over the ordinary spheres (scenes of >= 128 spheres) ----
   // A sphere is entered into every cell that the box around its ball (the r' of the per-ray prefilter, already
   // inflated) overlaps after widening it by eps = 2e-3 cell + 1e-4 max|coordinate|.  The walk (world_query_lanes)
@@ -662,8 +658,7 @@ extern "C" int pt_scene_upload(const pt_scene_desc *d, int device, pt_scene **ou
   // a cell is >= 1/64 of it) covers both, so a point where the true ray meets a sphere always lies within eps of a
   // visited cell, i.e. in a cell the sphere is entered in.  Spheres much larger than the rest (8x the median
   // radius: a dome would be in every cell) or without a bound go to the "always" list.
-  static const int env_grid = getenv("PTRACE_GRID") ? atoi(getenv("PTRACE_GRID")) : 1;
-  if (env_grid && s->bs_levels && s->n_spheres <= 65535) {
+  if (tn.grid && s->bs_levels && s->n_spheres <= 65535) {
     auto ball = [&](int k, int q) { return bsoa[(size_t)q * s->bs_stride + k]; };  // q: 0..2 centre, 3 radius r'
     std::vector<float> radii;
     for (int k = 0; k < s->n_spheres; ++k)
@@ -689,8 +684,7 @@ extern "C" int pt_scene_upload(const pt_scene_desc *d, int device, pt_scene **ou
     }
     // (below ~1000 spheres the exhaustive packed prefilter and the cell walk cost the same -- measured on C4's 256 --
     //  and the prefilter has the sparse path for the deep stragglers; the grid wins 2.5-3.3x at 10 000)
-    static const int env_grid_min = getenv("PTRACE_GRID_MIN") ? atoi(getenv("PTRACE_GRID_MIN")) : 1024;
-    if ((int)inside.size() >= std::max(64, env_grid_min)) {
+    if ((int)inside.size() >= std::max(64, (int)tn.grid_min)) {
       double ext[3], vol = 1.0;
       for (int q = 0; q < 3; ++q) {
         const double pad = 1e-3 * (hi[q] - lo[q]) + 1e-4 * (1.0 + std::max(std::fabs(lo[q]), std::fabs(hi[q])));
@@ -700,8 +694,7 @@ extern "C" int pt_scene_upload(const pt_scene_desc *d, int device, pt_scene **ou
         vol *= ext[q];
         cmax = std::max(cmax, std::max(std::fabs(lo[q]), std::fabs(hi[q])));
       }
-      static const double env_density = getenv("PTRACE_GRID_DENSITY") ? atof(getenv("PTRACE_GRID_DENSITY")) : 4.0;  // cells per sphere
-      const double target = std::min<double>(32768.0, std::max<double>(64.0, env_density * (double)inside.size()));
+      const double target = std::min<double>(32768.0, std::max<double>(64.0, tn.grid_density * (double)inside.size()));  // (cells per sphere)
       const double side = std::cbrt(vol / target);
       long long ncell = 1;
       for (int q = 0; q < 3; ++q) {
@@ -751,11 +744,12 @@ extern "C" int pt_scene_upload(const pt_scene_desc *d, int device, pt_scene **ou
             balls.push_back(b);
           }
         }
-        UP(upload(&s->grid_cells, words));
-        UP(upload(&s->grid_occ, occ));
-        UP(upload(&s->grid_slots, slots));
-        UP(upload(&s->grid_balls, balls));
-        UP(upload(&s->grid_always, always));
+        h.grid_cells = words;
+        h.grid_occ = occ;
+        h.grid_slots = slots;
+        h.grid_balls = balls;
+        h.grid_always = always;
+        h.has_grid = true;
         s->grid_n_always = (int)always.size();
         // the margin a sphere is entered with, >= 1e-4 * cmax, covers the fp32 copy of a ray whose origin lies within
         // ~100 x the grid's coordinates (1.2e-7 |o| <= a quarter of the margin); a ray from farther away takes the
@@ -781,19 +775,74 @@ extern "C" int pt_scene_upload(const pt_scene_desc *d, int device, pt_scene **ou
       s->bs_rmax[lv] = rmax;
     }
   }
-  UP(upload(&s->bsoa, bsoa));
-  UP(upload(&s->diag, diag));
+  h.bsoa = bsoa;
+  h.diag = diag;
+  h.aux = aux;
+  h.lights = lights;
+  h.tex = tex;
+  h.tex_data = tex_data;
+}
+
+static PtSceneFacts scene_facts(const pt_scene *s) {
+  PtSceneFacts f;
+  f.n_shapes = s->n_shapes;
+  f.n_spheres = s->n_spheres;
+  f.n_diag = s->n_diag;
+  f.n_lights = s->n_lights;
+  f.bs_levels = s->bs_levels;
+  f.has_grid = s->grid_n_cells > 0 ? 1 : 0;
+  f.grid_n_cells = s->grid_n_cells;
+  f.n_cu = s->n_cu;
+  f.dome_shortcut = s->dome_shortcut ? 1 : 0;
+  return f;
+}
+
+extern "C" int pt_scene_upload(const pt_scene_desc *d, int device, pt_scene **out) {
+  if (!out) return fail(PT_ERR_INVALID, "null output handle");
+  *out = nullptr;
+  int rc = check_desc(d);
+  if (rc) return rc;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(PT_ERR_NODEVICE, "no HIP device visible");
+  if (device < 0 || device >= ndev) return fail(PT_ERR_INVALID, "device %d out of range [0,%d)", device, ndev);
+  HIP_TRY(hipSetDevice(device));
+
+  pt_scene *s = new (std::nothrow) pt_scene();
+  if (!s) return fail(PT_ERR_NOMEM, "out of host memory");
+  s->device = device;
+  HostTables h;
+  analyse_scene(d, pt_tuning(), s, h);
+#define UP(call)            \
+  do {                      \
+    rc = (call);            \
+    if (rc) {               \
+      pt_scene_free(s);     \
+      return rc;            \
+    }                       \
+  } while (0)
+  UP(upload(&s->recs, h.recs));
+  UP(upload(&s->bounds, h.bounds));
+  if (h.has_grid) {
+    UP(upload(&s->grid_cells, h.grid_cells));
+    UP(upload(&s->grid_occ, h.grid_occ));
+    UP(upload(&s->grid_slots, h.grid_slots));
+    UP(upload(&s->grid_balls, h.grid_balls));
+    UP(upload(&s->grid_always, h.grid_always));
+  }
+  UP(upload(&s->bsoa, h.bsoa));
+  UP(upload(&s->diag, h.diag));
   {
     std::vector<PtHoistDiag> hd(std::max(s->n_diag, 1));
     UP(upload(&s->hoist_diag, hd));
   }
-  UP(upload(&s->aux, aux));
-  UP(upload(&s->lights, lights));
-  UP(upload(&s->tex, tex));
-  UP(upload(&s->tex_data, tex_data));
+  UP(upload(&s->aux, h.aux));
+  UP(upload(&s->lights, h.lights));
+  UP(upload(&s->tex, h.tex));
+  UP(upload(&s->tex_data, h.tex_data));
   {
-    std::vector<PtHoist> h(std::max(n, 1));
-    UP(upload(&s->hoist, h));
+    std::vector<PtHoist> hh(std::max(s->n_shapes, 1));
+    UP(upload(&s->hoist, hh));
   }
 #undef UP
   if ((rc = handle_state(s))) return rc;
@@ -891,10 +940,6 @@ static int check_params(const pt_scene *s, const pt_camera *cam, const pt_params
   return PT_OK;
 }
 
-// LDS one workgroup of the path tracer may use (gfx950: 160 KiB per CU, all of it available to one
-// workgroup), less the few static bytes of the kernel itself
-static const size_t PT_LDS_BUDGET = 160 * 1024 - 512;
-
 // dynamic LDS above the default 64 KiB has to be asked for, once per kernel
 static hipError_t path_lds_limit(const void *kernel, size_t bytes) {
   if (bytes <= 64 * 1024) return hipSuccess;
@@ -949,8 +994,7 @@ static void fill_scene_args(const pt_scene *s, PtKArgs &a) {
   for (int q = 0; q < 3; ++q) a.bs_rmax[q] = s->bs_rmax[q];
   a.gs_stride = s->gs_stride;
   a.cs_stride = s->cs_stride;
-  static const int env_levels_min = getenv("PTRACE_LEVELS_MIN") ? atoi(getenv("PTRACE_LEVELS_MIN")) : 128;
-  a.bs_levels = s->bs_levels && s->n_spheres >= env_levels_min;
+  a.bs_levels = s->bs_levels && s->n_spheres >= pt_tuning().levels_min;
   a.grid_cells = s->grid_cells;
   a.grid_occ = s->grid_occ;
   a.grid_balls = s->grid_balls;
@@ -976,10 +1020,35 @@ static void fill_scene_args(const pt_scene *s, PtKArgs &a) {
   a.n_lights = s->n_lights;
 }
 
+static_assert(PT_PLAN_BLOCK == PT_BLOCK && PT_PLAN_REGION == PT_REGION && PT_PLAN_CELL == PT_CELL && PT_PLAN_CELL_CHUNK == PT_CELL_CHUNK &&
+                  PT_PLAN_TREE_FRAME == PT_TREE_FRAME && PT_PLAN_SCATTER_BLOCK == PT_SCATTER_BLOCK && PT_PLAN_DIAG_BYTES == sizeof(PtDiagRec) &&
+                  PT_PLAN_REC_BYTES == sizeof(PtShapeRec) && PT_PLAN_AUX_BYTES == sizeof(PtShapeAux),
+              "pt_plan.h sizes the kernels' tiles and records by number: keep them equal to the kernels' own");
+
+// grow-only device buffers of a handle: a launch that needs more lets the stream drain first
+template <typename T>
+static int ensure(T **ptr, size_t *have, size_t need, hipStream_t st) {
+  if (need <= *have) return PT_OK;
+  HIP_TRY(hipStreamSynchronize(st));
+  if (*ptr) HIP_TRY(hipFree(*ptr));
+  *ptr = nullptr;
+  *have = 0;
+  HIP_TRY(hipMalloc((void **)ptr, need * sizeof(T)));
+  *have = need;
+  return PT_OK;
+}
+
+// launch() = plan (pt_plan.h: a pure function of the scene's facts, the camera, the parameters and the tuning table) +
+// enqueue (this function: buffers, the argument block, the launches the plan names -- no decision is taken here).
 static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *out_dev, hipStream_t st) {
+  const PtTuning &tn = pt_tuning();
+  PtPlan pl;
+  pt_make_plan(scene_facts(s), cam, p, tn, pl);
+
   PtKArgs a;
   memset(&a, 0, sizeof a);
   fill_scene_args(s, a);
+  a.bs_levels = pl.bs_levels;
   a.dome_shortcut = s->dome_shortcut ? 1 : 0;
   a.out = out_dev;
   a.cam_kind = cam->kind;
@@ -1023,152 +1092,33 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
   s->launched = true;
   s->count_pending = false;
   s->choice_pending = false;
-  const int rows = pt_rows_for_rank(p);
-  a.rows_local = rows;
-  a.npass = (s->n_shapes + 63) / 64;
-  a.npix = (long long)rows * p->width;
+  a.rows_local = pl.rows;
+  a.npass = pl.npass;
+  a.npix = pl.npix;
   s->stats.n_pixels = (uint64_t)a.npix;
   if (a.npix == 0) return PT_OK;
 
-  // grid: one lane per pixel up to the resident capacity of the chip, grid-stride beyond
-  const long long want = (a.npix + PT_BLOCK - 1) / PT_BLOCK;
-  long long cap = (long long)s->n_cu * 8;  // 8 x 256-thread workgroups per CU = 32 waves/CU
-  static const int env_cull = getenv("PTRACE_CULL") ? atoi(getenv("PTRACE_CULL")) : 1;
-  size_t frame_lds = 0, diag_lds_bytes = 0;
-  bool lds_frames = false;  // path tracer: the frame stack fits in LDS
-  bool tree = false;        // path tracer, num_of_rays > 1: pt_path_tree_kernel
-  if (p->renderer == PT_RENDERER_PATHTRACER) {
-    // The path tracer hands pixels out dynamically; fewer resident lanes than pixels lets a lane
-    // that drew a cheap pixel take several more while its neighbours finish an expensive one.
-    static const int env_wg = getenv("PTRACE_PATH_WG_PER_CU") ? atoi(getenv("PTRACE_PATH_WG_PER_CU")) : 0;
-    static const int env_ldsf = getenv("PTRACE_LDS_FRAMES") ? atoi(getenv("PTRACE_LDS_FRAMES")) : 1;
-    // one queue for all pixels: 152 VGPRs, 3 waves per SIMD; second pass by regions: built for 1-2
-    const bool regions = s->n_shapes > 0 && env_cull != 0;
-    int wg_per_cu = env_wg > 0 ? env_wg : (regions ? 2 : 3);
-    // a frame is pushed for depths 0 .. max_depth-1 only (a hit at max_depth spawns nothing that is traced)
-    a.frame_doubles = p->num_of_rays > 1 ? 20 : 6;
-    frame_lds = (size_t)std::max(p->max_depth, 1) * a.frame_doubles * PT_BLOCK * sizeof(double);
-    const size_t mask_lds = regions ? (size_t)4 * a.npass * sizeof(unsigned long long) : 0;
-    // num_of_rays > 1: one pixel per wave, a node's children on lanes (pt_path_tree_kernel);
-    // its stack holds one record per NODE and wave, not one per lane
-    static const int env_tree = getenv("PTRACE_TREE") ? atoi(getenv("PTRACE_TREE")) : 1;
-    const size_t tree_lds = (size_t)std::max(p->max_depth, 1) * PT_TREE_FRAME * (PT_BLOCK / 64) * sizeof(double);
-    // One pixel per wave pays while the flagged pixels are few per resident wave (the frame then waits for its deepest
-    // tree); where they are MANY -- a ground plane filling a large frame -- throughput decides, and 64 one-lane trees per
-    // wave catch up: measured equal at 1280x720 with ~400 k flagged pixels (14.8 vs 15.5 ms, profiles/r03_tree_dense_frames.txt).
-    // The flagged count is not known when the kernels are enqueued, so the frame size stands in for it.
-    static const long long env_tree_px = getenv("PTRACE_TREE_MAX_PIXELS") ? atoll(getenv("PTRACE_TREE_MAX_PIXELS")) : 2100000LL;
-    tree = regions && p->num_of_rays > 1 && env_tree != 0 && env_ldsf != 0 && a.npix <= env_tree_px &&
-           tree_lds + mask_lds <= PT_LDS_BUDGET / 2;
-    if (tree) {
-      a.frame_doubles = PT_TREE_FRAME;
-      frame_lds = tree_lds;
-    }
-    lds_frames = env_ldsf != 0 && frame_lds + mask_lds <= PT_LDS_BUDGET;
-    // the scale+translate records ride along in LDS when they fit (world_query_lanes gathers them per lane)
-    const size_t base_lds = mask_lds + (lds_frames ? frame_lds : 0);
-    diag_lds_bytes = (size_t)s->n_diag * sizeof(PtDiagRec);
-    a.diag_lds = -1;
-    if (regions && s->n_diag > 0 && base_lds + diag_lds_bytes <= PT_LDS_BUDGET &&
-        diag_lds_bytes <= 48 * 1024) {
-      a.diag_lds = (int)(base_lds / 8);
-    } else {
-      diag_lds_bytes = 0;
-    }
-    // ... and so do the occupancy bits of the grid (one per cell: at most 8 KB)
-    const size_t occ_bytes = (regions && s->grid_cells) ? (((size_t)s->grid_n_cells + 31) / 32 * 4 + 7) / 8 * 8 : 0;
-    if (occ_bytes && base_lds + diag_lds_bytes + occ_bytes <= PT_LDS_BUDGET) {
-      a.grid_occ_lds = (int)((base_lds + diag_lds_bytes) / 4);
-      diag_lds_bytes += occ_bytes;  // (from here on: everything staged behind the frames)
-    }
-    // ... and the shapes' own records (what shading gathers per lane), while two workgroups still fit a CU
-    static const int env_slds = getenv("PTRACE_SCENE_LDS") ? atoi(getenv("PTRACE_SCENE_LDS")) : 1;
-    a.scene_lds = -1;
-    if (regions && lds_frames && env_slds && !tree) {
-      const size_t at = (base_lds + diag_lds_bytes + 255) / 256 * 256;
-      const size_t scene_bytes = (size_t)s->n_shapes * (sizeof(PtShapeRec) + sizeof(PtShapeAux));
-      if (at + scene_bytes <= PT_LDS_BUDGET / 2) {
-        a.scene_lds = (int)(at / 8);
-        diag_lds_bytes = at + scene_bytes - base_lds;
-      }
-    }
-    if (lds_frames || diag_lds_bytes)
-      wg_per_cu = std::min<int>(wg_per_cu, (int)(PT_LDS_BUDGET / std::max<size_t>(1, base_lds + diag_lds_bytes)));
-    cap = (long long)s->n_cu * wg_per_cu;
-  }
-  // the tiled path tracer (perspective camera): primary rays use the hoisted, culled tile query
-  const bool ortho = cam->kind != PT_CAMERA_PERSPECTIVE;
-  const bool path_tiled = p->renderer == PT_RENDERER_PATHTRACER && s->n_shapes > 0 && env_cull != 0;
-  // per-camera constants of the shapes (invm * origin): only a perspective camera has a common origin
-  const bool hoist = !ortho && s->n_shapes > 0 && (p->renderer != PT_RENDERER_PATHTRACER || path_tiled);
-  // 8x8 tiles with culled shape lists: primary rays (OnOff, Flat, PointLight)
-  const bool tile = s->n_shapes > 0 && env_cull != 0 && s->n_shapes >= 4 &&
-                    (p->renderer == PT_RENDERER_ONOFF || p->renderer == PT_RENDERER_FLAT ||
-                     p->renderer == PT_RENDERER_POINTLIGHT);
-  int grid = (int)std::max<long long>(1, std::min(want, cap));
-  if (tile) {
-    static const int env_twg = getenv("PTRACE_TILE_WG_PER_CU") ? atoi(getenv("PTRACE_TILE_WG_PER_CU")) : 0;
-    const long long tcap = env_twg > 0 ? (long long)s->n_cu * env_twg : cap;
-    const long long wave_tiles = (long long)((p->width + 7) / 8) * ((rows + 7) / 8);
-    grid = (int)std::max<long long>(1, std::min<long long>((wave_tiles + 3) / 4, tcap));
-  }
-  // OnOff / Flat with pixel-centre rays of a perspective camera in worlds of at most 256 shapes: 16x16 tiles, four
-  // pixels per lane (pt_tile4_kernel), a 2x2 block of tiles per workgroup of a 2-D grid
-  static const int env_tile4 = getenv("PTRACE_TILE4") ? atoi(getenv("PTRACE_TILE4")) : 1;
-  const bool tile4 = tile && env_tile4 != 0 && !ortho && p->samples_per_side == 0 && s->n_shapes <= 256 &&
-                     (p->renderer == PT_RENDERER_ONOFF || p->renderer == PT_RENDERER_FLAT) &&
-                     (a.n_ranks == 1 || a.row_block % 16 == 0);
-  dim3 grid4(1, 1, 1);
-  // two pixels per lane (16x8 tiles) where the 16x16 tiles of the frame are fewer than the waves the chip holds
-  static const int env_npx = getenv("PTRACE_TILE4_NPX") ? atoi(getenv("PTRACE_TILE4_NPX")) : 0;
-  const long long tiles16 = (long long)((p->width + 15) / 16) * ((rows + 15) / 16);
-  const int npx = env_npx == 2 || env_npx == 4 ? env_npx : (tiles16 < (long long)s->n_cu * 4 * 5 ? PT_TILE4_NPX_SMALL : 4);
-  if (tile4) {
-    const int th = npx == 4 ? 16 : 8;
-    grid4 = dim3((unsigned)(((p->width + 15) / 16 + 1) / 2), (unsigned)(((rows + th - 1) / th + 1) / 2), 1);
-    grid = (int)(grid4.x * grid4.y);
-  }
-  // num_of_rays > 1: the tree kernel (one pixel per wave) is latency-bound and wins while flagged pixels are few; a frame
-  // FULL of them is throughput-bound and a lane per pixel, refilled from one queue, wins (profiles/r03_tree_dense_frames.txt:
-  // the reference's demo scene at 1280x960, 16.3 against 10.6 ms).  Which of the two a frame is only the first pass knows
-  // (F, on the device): both kernels are enqueued and pt_unit_scatter writes which one works (PT_Q_CHOICE).  The one-queue
-  // kernel keeps its per-lane frame stack (N > 1: 20 doubles per depth and lane) in LDS where that fits (D <= 3), in HBM beyond.
-  static const int env_qchoice = getenv("PTRACE_QCHOICE") ? atoi(getenv("PTRACE_QCHOICE")) : 1;  // 0: never, 2: always (measurement)
-  const size_t q_frame_bytes = (size_t)std::max(p->max_depth, 1) * 20 * PT_BLOCK * sizeof(double);  // per workgroup
-  static const int env_qldsf = getenv("PTRACE_Q_LDS_FRAMES") ? atoi(getenv("PTRACE_Q_LDS_FRAMES")) : 1;  // 0: always in HBM (measurement)
-  const bool q_lds_frames = env_qldsf != 0 && q_frame_bytes <= PT_LDS_BUDGET;  // (D <= 3; deeper stacks live in HBM, same layout: `ws`)
-  const size_t q_frame_lds = q_lds_frames ? q_frame_bytes : 0;
-  const bool q_alt = tree && env_qchoice != 0;
-  int grid_q = 0;
-  if (q_alt) {
-    const int wgq = q_lds_frames ? std::min<int>(3, (int)(PT_LDS_BUDGET / q_frame_bytes)) : 2;
-    grid_q = (int)std::max<long long>(1, std::min<long long>(want, (long long)s->n_cu * wgq));
-  }
-  int grid_first = 0;  // path tracer, first pass (pt_tile_kernel<PATHTRACER>): one wave per 8x8 region
-  if (path_tiled) {
-    const long long regions = (long long)((p->width + PT_REGION - 1) / PT_REGION) * ((rows + PT_REGION - 1) / PT_REGION);
-    grid = (int)std::max<long long>(1, std::min<long long>((regions + 3) / 4, cap));
-    grid_first = (int)std::max<long long>(1, std::min<long long>((regions + 3) / 4, (long long)s->n_cu * 8));
-  }
-  a.nthreads = grid * PT_BLOCK;
-  s->stats.grid = grid;
+  a.frame_doubles = pl.frame_doubles;
+  a.diag_lds = pl.diag_lds;
+  a.grid_occ_lds = pl.grid_occ_lds;
+  a.scene_lds = pl.scene_lds;
+  a.nthreads = pl.nthreads;
+  a.block_h = pl.block_h;
+  s->stats.grid = pl.grid;
   s->stats.block = PT_BLOCK;
   s->stats.lds_bytes = 0;
-  s->stats.kernel = PT_KERNEL_NONE;
+  s->stats.kernel = pl.kernel;
+  const int n_count_slots = pl.grid + pl.grid_first + pl.grid_q;
 
   if (s->count_rays) {
-    if (grid + grid_first + grid_q > s->ray_partials_n) {
-      HIP_TRY(hipStreamSynchronize(st));
-      if (s->ray_partials) HIP_TRY(hipFree(s->ray_partials));
-      s->ray_partials = nullptr;
-      s->ray_partials_n = 0;
-      HIP_TRY(hipMalloc((void **)&s->ray_partials, (size_t)(grid + grid_first + grid_q) * 2 * sizeof(unsigned long long)));
-      s->ray_partials_n = grid + grid_first + grid_q;
-    }
+    size_t have = (size_t)s->ray_partials_n * 2;
+    int rc = ensure(&s->ray_partials, &have, (size_t)n_count_slots * 2, st);
+    s->ray_partials_n = (int)(have / 2);
+    if (rc) return rc;
     a.ray_counter = s->ray_partials;
   }
 
-  if (hoist && !(s->hoist_valid && s->hoist_stream == st && memcmp(&s->hoist_cam, cam, sizeof(pt_camera)) == 0)) {
+  if (pl.hoist && !(s->hoist_valid && s->hoist_stream == st && memcmp(&s->hoist_cam, cam, sizeof(pt_camera)) == 0)) {
     V3 o = {-cam->screen_distance, 0.0, 0.0};
     // camera.py:116-124: origin (-d, 0, 0) through the camera transformation, reference order
     V3 w;
@@ -1182,7 +1132,7 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
     s->hoist_stream = st;
   }
 
-  if (p->renderer == PT_RENDERER_PATHTRACER && p->max_depth < 0) {
+  if (pl.zero_frame) {
     // render.py:100-101: every primary call returns Color(0, 0, 0) without a world query
     HIP_TRY(hipEventRecord(s->ev0, st));
     HIP_TRY(hipMemsetAsync(out_dev, 0, pt_output_bytes(p), st));
@@ -1203,38 +1153,18 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
     s->queue_last = s->queue + (size_t)a.qpar * PT_QUEUE_WORDS;
     if (!s->queue_clean) HIP_TRY(hipMemsetAsync(s->queue_last, 0, PT_QUEUE_WORDS * sizeof(unsigned long long), st));
     s->queue_clean = false;  // (true again once this frame's path kernel is enqueued)
-    // step batching (path_trace): the second pass by regions never mixes the two kinds of step (a P step
-    // waits until no lane holds a ray: its lanes then move sample by sample); the one-queue kernel, which
-    // also carries the cheap background pixels, starts samples while fewer than 48 lanes hold a ray and
-    // queries scattered rays once 16 wait
-    static const int env_pmax = getenv("PTRACE_P_MAXPATH") ? atoi(getenv("PTRACE_P_MAXPATH")) : 0;
-    static const int env_smin = getenv("PTRACE_S_MIN") ? atoi(getenv("PTRACE_S_MIN")) : 0;
-    a.p_max_path = env_pmax > 0 ? env_pmax : (path_tiled ? 1 : 48);
-    a.s_min_path = env_smin > 0 ? env_smin : (path_tiled ? 1 : 16);
-    size_t need = lds_frames ? 0 : (size_t)std::max(p->max_depth, 1) * a.frame_doubles * (size_t)a.nthreads * sizeof(double);
-    if (q_alt && !q_lds_frames)  // (the tree kernel's stack is in LDS: the workspace is the one-queue kernel's)
-      need = std::max(need, q_frame_bytes * (size_t)grid_q);
-    if (need > s->ws_bytes) {
-      HIP_TRY(hipStreamSynchronize(st));
-      if (s->ws) HIP_TRY(hipFree(s->ws));
-      s->ws = nullptr;
-      s->ws_bytes = 0;
-      HIP_TRY(hipMalloc((void **)&s->ws, need));
-      s->ws_bytes = need;
-    }
+    a.p_max_path = pl.p_max_path;
+    a.s_min_path = pl.s_min_path;
+    size_t have = s->ws_bytes / sizeof(double);
+    int rc = ensure(&s->ws, &have, (pl.ws_bytes + sizeof(double) - 1) / sizeof(double), st);
+    s->ws_bytes = have * sizeof(double);
+    if (rc) return rc;
     a.ws = s->ws;
   }
 
   // path tracer: per-region masks/keys from the first pass, work units for the second from pt_unit_scatter
-  const int nregions = path_tiled ? ((p->width + PT_REGION - 1) / PT_REGION) * ((rows + PT_REGION - 1) / PT_REGION) : 0;
-  // lanes the second pass keeps resident: pt_unit_scatter cuts regions into smaller units (more lanes per
-  // pixel) as long as all flagged pixels together still fit them
-  static const int env_lanes_cap = getenv("PTRACE_UNIT_LANES_CAP") ? atoi(getenv("PTRACE_UNIT_LANES_CAP")) : -1;  // 0: a unit = a region
-  const long long lanes_cap = env_lanes_cap >= 0 ? (long long)env_lanes_cap : (long long)grid * PT_BLOCK;
-  if (path_tiled) {
-    // (pt_unit_scatter may cut up to four units per resident wave; the tree kernel takes one PIXEL per unit)
-    const int units_need = tree ? (int)std::min<long long>(a.npix + 64, 0x7fffff00LL) : nregions + (int)(4 * lanes_cap / 64) + 64;
-    if (nregions > s->region_cap || units_need > s->units_cap) {
+  if (pl.path_tiled) {
+    if (pl.nregions > s->region_cap || pl.units_need > s->units_cap) {
       HIP_TRY(hipStreamSynchronize(st));
       if (s->region_keys) HIP_TRY(hipFree(s->region_keys));
       if (s->units) HIP_TRY(hipFree(s->units));
@@ -1244,35 +1174,24 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
       s->region_mask = nullptr;
       s->region_cap = 0;
       s->units_cap = 0;
-      HIP_TRY(hipMalloc((void **)&s->region_keys, (size_t)nregions));
-      HIP_TRY(hipMalloc((void **)&s->units, (size_t)units_need * sizeof(int4)));
-      HIP_TRY(hipMalloc((void **)&s->region_mask, (size_t)nregions * sizeof(unsigned long long)));
-      s->region_cap = nregions;
-      s->units_cap = units_need;
+      HIP_TRY(hipMalloc((void **)&s->region_keys, (size_t)pl.nregions));
+      HIP_TRY(hipMalloc((void **)&s->units, (size_t)pl.units_need * sizeof(int4)));
+      HIP_TRY(hipMalloc((void **)&s->region_mask, (size_t)pl.nregions * sizeof(unsigned long long)));
+      s->region_cap = pl.nregions;
+      s->units_cap = pl.units_need;
     }
     a.units = s->units;
     a.region_keys = s->region_keys;
     a.region_mask = s->region_mask;
-    // PT_PCG_PIXEL: what a sample is assumed to draw before anything is known about its pixel: two jitter
-    // numbers and one diffuse bounce (a guess only costs a round when it is wrong, never a bit of the image)
-    static const int env_spec = getenv("PTRACE_SPEC_DRAWS") ? atoi(getenv("PTRACE_SPEC_DRAWS")) : -1;
-    a.spec_draws = env_spec >= 0 ? env_spec : (p->samples_per_side > 0 ? 4 : 2);
-    static const int env_wl = getenv("PTRACE_SPEC_WIN_LANES") ? atoi(getenv("PTRACE_SPEC_WIN_LANES")) : 8;
-    static const int env_wc = getenv("PTRACE_SPEC_WIN_COVER") ? atoi(getenv("PTRACE_SPEC_WIN_COVER")) : 13;
-    a.spec_win_lanes = env_wl;
-    a.spec_win_cover = env_wc;
+    a.spec_draws = pl.spec_draws;
+    a.tree_uniform_max = (int)tn.tree_uniform_max;  // (measured on C3, N = 10: the uniform loop 2.48 ms, candidate lists 1.92)
+    a.tree_fuse = (int)tn.tree_fuse;
+    a.dbg_trace_unit = (int)tn.trace_unit;
     // The sphere the camera is deepest inside (object-space |o'|^2 - 1 most negative, and below -0.5): the
     // first pass settles, per pixel, what can only hit that sphere (pt_tile_kernel re-checks every condition
     // from the exact hoisted constants; this only names the candidate).
     a.dome_slot = -1;
-    static const int env_tumax = getenv("PTRACE_TREE_UNIFORM_MAX") ? atoi(getenv("PTRACE_TREE_UNIFORM_MAX")) : 0;  // (measured on C3, N = 10: the uniform loop 2.48 ms, candidate lists 1.92)
-    a.tree_uniform_max = env_tumax;
-    static const int env_tfuse = getenv("PTRACE_TREE_FUSE") ? atoi(getenv("PTRACE_TREE_FUSE")) : 1;
-    a.tree_fuse = env_tfuse;
-    static const int env_trace = getenv("PTRACE_TRACE_UNIT") ? atoi(getenv("PTRACE_TRACE_UNIT")) : 0;
-    a.dbg_trace_unit = env_trace;
-    static const int env_dome = getenv("PTRACE_PIXEL_DOME") ? atoi(getenv("PTRACE_PIXEL_DOME")) : 1;
-    if (!ortho && env_dome) {
+    if (!pl.ortho && tn.pixel_dome) {
       const double ox = -cam->screen_distance * cam->m[0] + cam->m[3], oy = -cam->screen_distance * cam->m[4] + cam->m[7],
                    oz = -cam->screen_distance * cam->m[8] + cam->m[11];
       double best = -0.5;
@@ -1289,15 +1208,9 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
     }
   }
   // large scenes: two-level culling (cells of PT_CELL x PT_CELL global pixels, then 8x8 tiles)
-  static const int env_hier = getenv("PTRACE_HIER_MIN") ? atoi(getenv("PTRACE_HIER_MIN")) : 256;
-  const int cells_x = (p->width + PT_CELL - 1) / PT_CELL, cells_y = (p->height + PT_CELL - 1) / PT_CELL;
-  const int ncells = cells_x * cells_y;
-  const int cell_stride = (s->n_shapes + 63) / 64 * 64;
-  const bool hier = (tile || path_tiled) && !ortho && env_hier >= 0 && s->n_shapes > env_hier && (a.n_ranks == 1 || a.row_block % 8 == 0) &&
-                    (size_t)ncells * cell_stride * sizeof(unsigned int) <= ((size_t)2 << 30);
-  if (hier) {
-    const size_t need = (size_t)ncells * cell_stride;
-    if (need > s->cell_list_cap || ncells > s->cell_count_cap) {
+  if (pl.hier) {
+    const size_t need = (size_t)pl.ncells * pl.cell_stride;
+    if (need > s->cell_list_cap || pl.ncells > s->cell_count_cap) {
       HIP_TRY(hipStreamSynchronize(st));
       if (s->cell_list) HIP_TRY(hipFree(s->cell_list));
       if (s->cell_count) HIP_TRY(hipFree(s->cell_count));
@@ -1306,27 +1219,14 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
       s->cell_list_cap = 0;
       s->cell_count_cap = 0;
       HIP_TRY(hipMalloc((void **)&s->cell_list, need * sizeof(unsigned int)));
-      HIP_TRY(hipMalloc((void **)&s->cell_count, (size_t)ncells * sizeof(int)));
+      HIP_TRY(hipMalloc((void **)&s->cell_count, (size_t)pl.ncells * sizeof(int)));
       s->cell_list_cap = need;
-      s->cell_count_cap = ncells;
+      s->cell_count_cap = pl.ncells;
     }
     a.cell_list = s->cell_list;
     a.cell_count = s->cell_count;
-    a.cells_x = cells_x;
-    a.cell_stride = cell_stride;
-  }
-  a.block_h = 1;
-  if (path_tiled && !ortho && !hier) {
-    // first pass: a workgroup culls a block of four (two) strips, 32 x 32 (32 x 16) pixels, before it looks at the
-    // strips -- where that still leaves a block for every other workgroup: pt_tile_kernel<..., BLOCKS>
-    static const int env_bh = getenv("PTRACE_BLOCK_H") ? atoi(getenv("PTRACE_BLOCK_H")) : 0;
-    const int tiles_x = (p->width + 7) / 8, tiles_y = (rows + 7) / 8;
-    const long long strips_x = (tiles_x + 3) / 4;
-    if (2 * strips_x * ((tiles_y + 3) / 4) >= (long long)grid_first)  // (measured: still ahead with one block per two workgroups)
-      a.block_h = 4;
-    else if (2 * strips_x * ((tiles_y + 1) / 2) >= (long long)grid_first)
-      a.block_h = 2;
-    if (env_bh > 0) a.block_h = env_bh;
+    a.cells_x = pl.cells_x;
+    a.cell_stride = pl.cell_stride;
   }
   // the cold half of the argument block is read from device memory: refresh the copy when it changed
   // (the output pointer stays a by-value argument: double-buffered frames alternate it every launch)
@@ -1346,159 +1246,101 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
   const hipEvent_t ev_a = s->timing ? (prof ? s->prof[2 * s->prof_used] : s->ev0) : nullptr;
   const hipEvent_t ev_b = s->timing ? (prof ? s->prof[2 * s->prof_used + 1] : s->ev1) : nullptr;
   bool ev_started = false;
-  if (tile4) {
-    s->stats.kernel = PT_KERNEL_TILE4;
+  const int R = p->renderer;
 #ifdef PT_DEBUG_TIME
+  if (pl.tile4 || ((pl.tile || pl.path_tiled) && R != PT_RENDERER_PATHTRACER)) {
     s->queue_last = s->queue;  // (a.qpar = 0: the section sums land in block 0)
     HIP_TRY(hipMemsetAsync(s->queue, 0, 16 * sizeof(unsigned long long), st));
     if (s->queue_parity == 0) s->queue_clean = false;
+  }
 #endif
+  if (pl.tile4) {
     // small worlds: the shapes' records ride in LDS for shading (Flat; OnOff reads none of them)
-    static const int env_t4lds = getenv("PTRACE_TILE4_LDS") ? atoi(getenv("PTRACE_TILE4_LDS")) : 1;
-    const size_t scene_bytes = (size_t)s->n_shapes * (sizeof(PtShapeRec) + sizeof(PtShapeAux));
-    const bool t4lds = env_t4lds != 0 && p->renderer == PT_RENDERER_FLAT && scene_bytes <= 24 * 1024;
-    s->stats.lds_bytes = t4lds ? (int)scene_bytes : 0;
-#define PT_LAUNCH4(R, L, N, LDSB)                                                                                  \
-  do {                                                                                                             \
-    main_fn = (const void *)pt_tile4_kernel<R, L, N>;                                                              \
-    hipExtLaunchKernelGGL((pt_tile4_kernel<R, L, N>), grid4, dim3(PT_BLOCK), LDSB, st, ev_a, ev_b, 0, a);          \
+    s->stats.lds_bytes = (int)pl.lds_main;
+    const dim3 grid4(pl.grid4_x, pl.grid4_y, 1);
+#define PT_LAUNCH4(R_, L_, N_)                                                                                              \
+  do {                                                                                                                      \
+    main_fn = (const void *)pt_tile4_kernel<R_, L_, N_>;                                                                    \
+    hipExtLaunchKernelGGL((pt_tile4_kernel<R_, L_, N_>), grid4, dim3(PT_BLOCK), pl.lds_main, st, ev_a, ev_b, 0, a);         \
   } while (0)
-    if (p->renderer == PT_RENDERER_ONOFF) {
-      if (npx == 4) PT_LAUNCH4(PT_RENDERER_ONOFF, false, 4, 0); else PT_LAUNCH4(PT_RENDERER_ONOFF, false, 2, 0);
-    } else if (t4lds) {
-      if (npx == 4) PT_LAUNCH4(PT_RENDERER_FLAT, true, 4, scene_bytes); else PT_LAUNCH4(PT_RENDERER_FLAT, true, 2, scene_bytes);
+    if (R == PT_RENDERER_ONOFF) {
+      if (pl.npx == 4) PT_LAUNCH4(PT_RENDERER_ONOFF, false, 4); else PT_LAUNCH4(PT_RENDERER_ONOFF, false, 2);
+    } else if (pl.t4lds) {
+      if (pl.npx == 4) PT_LAUNCH4(PT_RENDERER_FLAT, true, 4); else PT_LAUNCH4(PT_RENDERER_FLAT, true, 2);
     } else {
-      if (npx == 4) PT_LAUNCH4(PT_RENDERER_FLAT, false, 4, 0); else PT_LAUNCH4(PT_RENDERER_FLAT, false, 2, 0);
+      if (pl.npx == 4) PT_LAUNCH4(PT_RENDERER_FLAT, false, 4); else PT_LAUNCH4(PT_RENDERER_FLAT, false, 2);
     }
 #undef PT_LAUNCH4
-  } else if (tile || path_tiled) {
-#ifdef PT_DEBUG_TIME
-    if (p->renderer != PT_RENDERER_PATHTRACER) {
-      s->queue_last = s->queue;  // (a.qpar = 0)
-      HIP_TRY(hipMemsetAsync(s->queue, 0, 16 * sizeof(unsigned long long), st));
-      if (s->queue_parity == 0) s->queue_clean = false;  // the section sums land in block 0
-    }
-#endif
-    const size_t lds = (size_t)4 * a.npass * sizeof(unsigned long long);
+  } else if (pl.tile || pl.path_tiled) {
+    const size_t lds = pl.lds_tile;
     s->stats.lds_bytes = (int)lds;
-    s->stats.kernel = path_tiled ? PT_KERNEL_PATH_REGIONS : PT_KERNEL_TILE;
-    const int tgrid = path_tiled ? grid_first : grid;
-    if (hier) {
-      // enough (cell group, shape chunk) pairs to fill the chip; a chunk is a multiple of the block
-      const int ngroups = ((cells_x + 1) / 2) * ((cells_y + 1) / 2), max_chunks = (s->n_shapes + PT_BLOCK - 1) / PT_BLOCK;
-      const int min_chunks = (s->n_shapes + PT_CELL_CHUNK - 1) / PT_CELL_CHUNK;  // a chunk's survivors fit in LDS
-      const int nchunks = std::max(min_chunks, std::min(max_chunks, (4 * s->n_cu + ngroups - 1) / ngroups));
-      const int chunk_len = (max_chunks + nchunks - 1) / nchunks * PT_BLOCK;
-      if (chunk_len > PT_CELL_CHUNK) return fail(PT_ERR_INVALID, "internal: cell chunk exceeds its LDS staging");
-      HIP_TRY(hipMemsetAsync(s->cell_count, 0, (size_t)ncells * sizeof(int), st));
-      PT_LAUNCH(pt_cell_kernel, ngroups * nchunks, 0, false, a, nchunks, chunk_len);
-      if (p->renderer == PT_RENDERER_ONOFF)
-        PT_LAUNCH((pt_tile_kernel<PT_RENDERER_ONOFF, 4, true>), tgrid, lds, !path_tiled, a, 0);
-      else if (p->renderer == PT_RENDERER_FLAT)
-        PT_LAUNCH((pt_tile_kernel<PT_RENDERER_FLAT, 4, true>), tgrid, lds, !path_tiled, a, 0);
-      else if (p->renderer == PT_RENDERER_POINTLIGHT)
-        PT_LAUNCH((pt_tile_kernel<PT_RENDERER_POINTLIGHT, PT_WAVES_POINTLIGHT, true>), tgrid, lds, !path_tiled, a, 0);
-      else
-        PT_LAUNCH((pt_tile_kernel<PT_RENDERER_PATHTRACER, 4, true>), tgrid, lds, !path_tiled, a, grid);
-    } else if (ortho) {
-      if (p->renderer == PT_RENDERER_ONOFF)
-        PT_LAUNCH((pt_tile_kernel<PT_RENDERER_ONOFF, 4, false, true>), tgrid, lds, !path_tiled, a, 0);
-      else if (p->renderer == PT_RENDERER_FLAT)
-        PT_LAUNCH((pt_tile_kernel<PT_RENDERER_FLAT, 4, false, true>), tgrid, lds, !path_tiled, a, 0);
-      else if (p->renderer == PT_RENDERER_POINTLIGHT)
-        PT_LAUNCH((pt_tile_kernel<PT_RENDERER_POINTLIGHT, PT_WAVES_POINTLIGHT, false, true>), tgrid, lds, !path_tiled, a, 0);
-      else
-        PT_LAUNCH((pt_tile_kernel<PT_RENDERER_PATHTRACER, 4, false, true>), tgrid, lds, !path_tiled, a, grid);
-    } else if (p->renderer == PT_RENDERER_ONOFF)
-      PT_LAUNCH((pt_tile_kernel<PT_RENDERER_ONOFF, 4, false>), tgrid, lds, !path_tiled, a, 0);
-    else if (p->renderer == PT_RENDERER_FLAT)
-      PT_LAUNCH((pt_tile_kernel<PT_RENDERER_FLAT, 4, false>), tgrid, lds, !path_tiled, a, 0);
-    else if (p->renderer == PT_RENDERER_POINTLIGHT)
-      PT_LAUNCH((pt_tile_kernel<PT_RENDERER_POINTLIGHT, PT_WAVES_POINTLIGHT, false>), tgrid, lds, !path_tiled, a, 0);
-    else
-    {
-      if (a.npass >= 2 && s->dome_shortcut && a.block_h > 1)  // (big frames: blocks of strips, see a.block_h above)
-        PT_LAUNCH((pt_tile_kernel<PT_RENDERER_PATHTRACER, 4, false, false, true>), tgrid, lds, !path_tiled, a, grid);
-      else
-        PT_LAUNCH((pt_tile_kernel<PT_RENDERER_PATHTRACER, 4, false>), tgrid, lds, !path_tiled, a, grid);
+    const int tgrid = pl.path_tiled ? pl.grid_first : pl.grid;
+    const bool last = !pl.path_tiled;
+    const int pgrid = pl.path_tiled ? pl.grid : 0;  // (the first pass is told the second pass's grid)
+    if (pl.hier) {
+      if (pl.cell_chunk_len > PT_CELL_CHUNK) return fail(PT_ERR_INVALID, "internal: cell chunk exceeds its LDS staging");
+      HIP_TRY(hipMemsetAsync(s->cell_count, 0, (size_t)pl.ncells * sizeof(int), st));
+      PT_LAUNCH(pt_cell_kernel, pl.cell_groups * pl.cell_chunks, 0, false, a, pl.cell_chunks, pl.cell_chunk_len);
     }
-    if (path_tiled) {
+    // pt_tile_kernel<renderer, waves, HIER, ORTHO, BLOCKS>
+#define PT_TILE_MODES(R_, W_)                                                                              \
+  do {                                                                                                     \
+    if (pl.tile_mode == PT_TILE_HIER)                                                                      \
+      PT_LAUNCH((pt_tile_kernel<R_, W_, true>), tgrid, lds, last, a, pgrid);                               \
+    else if (pl.tile_mode == PT_TILE_ORTHO)                                                                \
+      PT_LAUNCH((pt_tile_kernel<R_, W_, false, true>), tgrid, lds, last, a, pgrid);                        \
+    else                                                                                                   \
+      PT_LAUNCH((pt_tile_kernel<R_, W_, false>), tgrid, lds, last, a, pgrid);                              \
+  } while (0)
+    if (R == PT_RENDERER_ONOFF)
+      PT_TILE_MODES(PT_RENDERER_ONOFF, 4);
+    else if (R == PT_RENDERER_FLAT)
+      PT_TILE_MODES(PT_RENDERER_FLAT, 4);
+    else if (R == PT_RENDERER_POINTLIGHT)
+      PT_TILE_MODES(PT_RENDERER_POINTLIGHT, PT_WAVES_POINTLIGHT);
+    else if (pl.tile_mode == PT_TILE_BLOCKS)
+      PT_LAUNCH((pt_tile_kernel<PT_RENDERER_PATHTRACER, 4, false, false, true>), tgrid, lds, last, a, pgrid);
+    else
+      PT_TILE_MODES(PT_RENDERER_PATHTRACER, 4);
+#undef PT_TILE_MODES
+    if (pl.path_tiled) {
       // second pass: the pixels the first one flagged, fullest regions first
-      const int nsamp = p->samples_per_side > 0 ? p->samples_per_side * p->samples_per_side : 1;
-      static const int env_minr = getenv("PTRACE_UNIT_MIN_ROUNDS") ? atoi(getenv("PTRACE_UNIT_MIN_ROUNDS")) : 0;
-      const int min_rounds = env_minr != 0 ? env_minr : (a.pcg_mode == PT_PCG_SAMPLE ? -2 : 16);  // (< 0: see unit_ppu)
-      // The flagged pixels from which the one-queue kernel takes the frame (q_alt): where its estimate falls below the tree
-      // kernel's.  Both fitted to measurements on the MI355X (tools/tree_vs_queue.py, profiles/r04_tree_vs_queue.txt: 17
-      // frames of three scenes, N = 2 ... 20, D = 2 ... 3; ns per flagged pixel and sample):
-      //   tree kernel       F x tT,  tT = 4.5 + 0.045 min(R, 500)   (R = sum of N^d, the rays of a full tree: one pixel at a
-      //                     time on each of the 8 n_cu resident waves, a handful of rounds per family of children)
-      //   one-queue kernel  R x step + F x tQ,  step = 6 + 0.02 n_shapes us (its deepest lane: R dependent steps, scattered rays
-      //                     on per-lane candidate lists),  tQ = (0.5 + 0.01 n_shapes)(1 + R / 800)
-      long long q_min = -1;
-      if (q_alt) {
-        static const long long env_qmin = getenv("PTRACE_Q_MIN_FLAGGED") ? atoll(getenv("PTRACE_Q_MIN_FLAGGED")) : -1;
-        double tree_rays = 1.0, pw = 1.0;
-        for (int d = 1; d <= std::max(p->max_depth, 0); ++d) {
-          pw *= (double)p->num_of_rays;
-          tree_rays += pw;
-        }
-        const double step_ns = (6.0 + 0.02 * s->n_shapes) * 1e3 * (q_lds_frames ? 1.0 : 1.3);  // (frames in HBM: measured on D = 4 ... 8)
-        const double t_tree = (4.5 + 0.045 * std::min(tree_rays, 500.0)) * (2048.0 / (8.0 * s->n_cu));
-        const double t_queue = (0.5 + 0.01 * s->n_shapes) * (1.0 + tree_rays / 800.0);
-        if (t_tree > t_queue) q_min = (long long)std::min(1e15, 1.1 * tree_rays * step_ns / (t_tree - t_queue));
-        if (env_qmin >= 0) q_min = env_qmin;
-        if (env_qchoice == 2) q_min = 0;
-      }
-      if (tree)  // one pixel per unit: "64 lanes per pixel, whatever the number of flagged pixels"
-        hipLaunchKernelGGL(pt_unit_scatter, dim3((nregions + PT_SCATTER_BLOCK - 1) / PT_SCATTER_BLOCK), dim3(PT_SCATTER_BLOCK), 0, st, s->region_keys, s->region_mask, nregions, s->units, s->units_cap,
-                           s->queue_last, (long long)1 << 60, 64, 1, q_min);
+      if (pl.tree)  // one pixel per unit: "64 lanes per pixel, whatever the number of flagged pixels"
+        hipLaunchKernelGGL(pt_unit_scatter, dim3(pl.grid_scatter), dim3(PT_SCATTER_BLOCK), 0, st, s->region_keys, s->region_mask, pl.nregions,
+                           s->units, s->units_cap, s->queue_last, (long long)1 << 60, 64, 1, pl.q_min);
       else
-      hipLaunchKernelGGL(pt_unit_scatter, dim3((nregions + PT_SCATTER_BLOCK - 1) / PT_SCATTER_BLOCK), dim3(PT_SCATTER_BLOCK), 0, st, s->region_keys, s->region_mask, nregions, s->units, s->units_cap,
-                         s->queue_last, lanes_cap, nsamp, min_rounds);
-      // worlds without a grid and without the ball hierarchy (< 128 spheres): the query's large-world paths compiled out
-      static const int env_small = getenv("PTRACE_SMALL_QUERY") ? atoi(getenv("PTRACE_SMALL_QUERY")) : 1;
-      const bool small_world = env_small != 0 && s->grid_cells == nullptr && s->bs_levels == 0;
-      if (tree && small_world) {
-        s->stats.kernel = PT_KERNEL_PATH_TREE;
-        HIP_TRY(path_lds_limit((const void *)pt_path_tree_kernel<true>, lds + frame_lds + diag_lds_bytes));
-        PT_LAUNCH((pt_path_tree_kernel<true>), grid, lds + frame_lds + diag_lds_bytes, !q_alt, a);
-      } else if (tree) {
-        s->stats.kernel = PT_KERNEL_PATH_TREE;
-        HIP_TRY(path_lds_limit((const void *)pt_path_tree_kernel<false>, lds + frame_lds + diag_lds_bytes));
-        PT_LAUNCH((pt_path_tree_kernel<false>), grid, lds + frame_lds + diag_lds_bytes, !q_alt, a);
-      } else if (lds_frames && a.scene_lds >= 0 && small_world) {
-        HIP_TRY(path_lds_limit((const void *)pt_path_regions_kernel<true, true, 1>, lds + frame_lds + diag_lds_bytes));
-        PT_LAUNCH((pt_path_regions_kernel<true, true, 1>), grid, lds + frame_lds + diag_lds_bytes, true, a);
-      } else if (lds_frames && a.scene_lds >= 0) {
-        HIP_TRY(path_lds_limit((const void *)pt_path_regions_kernel<true, true>, lds + frame_lds + diag_lds_bytes));
-        PT_LAUNCH((pt_path_regions_kernel<true, true>), grid, lds + frame_lds + diag_lds_bytes, true, a);
-      } else if (lds_frames && env_small != 0 && s->grid_cells == nullptr) {  // (no grid: its walk compiled out)
-        HIP_TRY(path_lds_limit((const void *)pt_path_regions_kernel<true, false, 2>, lds + frame_lds + diag_lds_bytes));
-        PT_LAUNCH((pt_path_regions_kernel<true, false, 2>), grid, lds + frame_lds + diag_lds_bytes, true, a);
-      } else if (lds_frames) {
-        HIP_TRY(path_lds_limit((const void *)pt_path_regions_kernel<true>, lds + frame_lds + diag_lds_bytes));
-        PT_LAUNCH((pt_path_regions_kernel<true>), grid, lds + frame_lds + diag_lds_bytes, true, a);
-      } else {
-        HIP_TRY(path_lds_limit((const void *)pt_path_regions_kernel<false>, lds + diag_lds_bytes));
-        PT_LAUNCH((pt_path_regions_kernel<false>), grid, lds + diag_lds_bytes, true, a);
+        hipLaunchKernelGGL(pt_unit_scatter, dim3(pl.grid_scatter), dim3(PT_SCATTER_BLOCK), 0, st, s->region_keys, s->region_mask, pl.nregions,
+                           s->units, s->units_cap, s->queue_last, pl.lanes_cap, pl.nsamp, (long long)pl.min_rounds);
+      const bool last2 = !pl.q_alt;
+#define PT_SECOND(K_)                                               \
+  do {                                                              \
+    HIP_TRY(path_lds_limit((const void *)(K_), pl.lds_main));       \
+    PT_LAUNCH((K_), pl.grid, pl.lds_main, last2, a);                \
+  } while (0)
+      switch (pl.second) {
+        case PT_SECOND_TREE_LEAN: PT_SECOND((pt_path_tree_kernel<true>)); break;
+        case PT_SECOND_TREE: PT_SECOND((pt_path_tree_kernel<false>)); break;
+        case PT_SECOND_REGIONS_LDS_SCENE_LEAN: PT_SECOND((pt_path_regions_kernel<true, true, 1>)); break;
+        case PT_SECOND_REGIONS_LDS_SCENE: PT_SECOND((pt_path_regions_kernel<true, true>)); break;
+        case PT_SECOND_REGIONS_LDS_NOGRID: PT_SECOND((pt_path_regions_kernel<true, false, 2>)); break;
+        case PT_SECOND_REGIONS_LDS: PT_SECOND((pt_path_regions_kernel<true>)); break;
+        default: PT_SECOND((pt_path_regions_kernel<false>)); break;
       }
-      if (q_alt) {
+#undef PT_SECOND
+      if (pl.q_alt) {
         // ... and the one-queue kernel behind it, with an argument block of its own (a lane per pixel: 20 doubles per depth
-        // and lane in LDS, its own grid, its own slots for the ray counts); it returns at once unless PT_Q_CHOICE says 1
+        // and lane, its own grid, its own slots for the ray counts); it returns at once unless PT_Q_CHOICE says 1
         PtKArgs aq = a;
         aq.cold = s->args_dev2;
-        aq.nthreads = grid_q * PT_BLOCK;
+        aq.nthreads = pl.grid_q * PT_BLOCK;
         aq.frame_doubles = 20;
-        aq.p_max_path = 48;
-        aq.s_min_path = 16;
-        aq.count_base = grid + grid_first;
+        aq.p_max_path = pl.q_p_max_path;
+        aq.s_min_path = pl.q_s_min_path;
+        aq.count_base = pl.grid + pl.grid_first;
         aq.scene_lds = -1;
         aq.grid_occ_lds = -1;
-        // the scale+translate records behind the frame stack when they fit (world_query_lanes gathers them per lane)
-        const size_t q_diag_bytes = (size_t)s->n_diag * sizeof(PtDiagRec);
-        const bool q_diag = s->n_diag > 0 && q_diag_bytes <= 48 * 1024 && q_frame_lds + q_diag_bytes <= (q_lds_frames ? PT_LDS_BUDGET : PT_LDS_BUDGET / 2);
-        aq.diag_lds = q_diag ? (int)(q_frame_lds / 8) : -1;
-        const size_t q_lds = q_frame_lds + (q_diag ? q_diag_bytes : 0);
+        aq.diag_lds = pl.q_diag_lds;
+        aq.ws = s->ws;
         PtKArgs cold2 = aq;
         cold2.out = nullptr;
         cold2.qpar = 0;
@@ -1509,61 +1351,46 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
           s->args2_stream = st;
         }
         const void *tree_fn = main_fn;
-        static const int env_qlat = getenv("PTRACE_Q_LANES") ? atoi(getenv("PTRACE_Q_LANES")) : 1;  // 0: the wave-uniform shape loop (pt_path_kernel<true, true>)
-        aq.ws = s->ws;
-        if (!q_lds_frames) {  // the frame stack in HBM (D > 3): two workgroups per CU
-          if (small_world) {
-            HIP_TRY(path_lds_limit((const void *)pt_path_flagged_kernel<1, false>, q_lds));
-            PT_LAUNCH((pt_path_flagged_kernel<1, false>), grid_q, q_lds, true, aq);
-          } else {
-            HIP_TRY(path_lds_limit((const void *)pt_path_flagged_kernel<0, false>, q_lds));
-            PT_LAUNCH((pt_path_flagged_kernel<0, false>), grid_q, q_lds, true, aq);
-          }
-        } else if (!env_qlat) {
-          HIP_TRY(path_lds_limit((const void *)pt_path_kernel<true, true>, q_lds));
-          PT_LAUNCH((pt_path_kernel<true, true>), grid_q, q_lds, true, aq);
-        } else if (small_world) {
-          HIP_TRY(path_lds_limit((const void *)pt_path_flagged_kernel<1>, q_lds));
-          PT_LAUNCH((pt_path_flagged_kernel<1>), grid_q, q_lds, true, aq);
-        } else {
-          HIP_TRY(path_lds_limit((const void *)pt_path_flagged_kernel<0>, q_lds));
-          PT_LAUNCH((pt_path_flagged_kernel<0>), grid_q, q_lds, true, aq);
+#define PT_ALT(K_)                                              \
+  do {                                                          \
+    HIP_TRY(path_lds_limit((const void *)(K_), pl.lds_q));      \
+    PT_LAUNCH((K_), pl.grid_q, pl.lds_q, true, aq);             \
+  } while (0)
+        switch (pl.alt) {
+          case PT_ALT_FLAGGED_LEAN_HBM: PT_ALT((pt_path_flagged_kernel<1, false>)); break;
+          case PT_ALT_FLAGGED_HBM: PT_ALT((pt_path_flagged_kernel<0, false>)); break;
+          case PT_ALT_PATH_UNIFORM: PT_ALT((pt_path_kernel<true, true>)); break;
+          case PT_ALT_FLAGGED_LEAN_LDS: PT_ALT((pt_path_flagged_kernel<1>)); break;
+          default: PT_ALT((pt_path_flagged_kernel<0>)); break;
         }
+#undef PT_ALT
         main_fn = tree_fn;  // (pt_stats.vgprs: the tree kernel's; pt_stats.kernel follows the device's choice, see fold_stats)
         HIP_TRY(hipMemcpyAsync(s->ray_counter_host + 2, s->queue_last + PT_Q_CHOICE, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         s->choice_pending = true;
       }
     }
+  } else if (R == PT_RENDERER_PATHTRACER) {
+    if (pl.lds_frames) {
+      HIP_TRY(path_lds_limit((const void *)pt_path_kernel<true>, pl.lds_main));
+      PT_LAUNCH((pt_path_kernel<true>), pl.grid, pl.lds_main, true, a);
+    } else {
+      PT_LAUNCH((pt_path_kernel<false>), pl.grid, 0, true, a);
+    }
   } else {
-  s->stats.kernel = p->renderer == PT_RENDERER_PATHTRACER ? PT_KERNEL_PATH : PT_KERNEL_SIMPLE;
-  switch (p->renderer) {
-    case PT_RENDERER_ONOFF:
-      if (hoist)
-        PT_LAUNCH((pt_simple_kernel<PT_RENDERER_ONOFF, true>), grid, 0, true, a);
-      else
-        PT_LAUNCH((pt_simple_kernel<PT_RENDERER_ONOFF, false>), grid, 0, true, a);
-      break;
-    case PT_RENDERER_FLAT:
-      if (hoist)
-        PT_LAUNCH((pt_simple_kernel<PT_RENDERER_FLAT, true>), grid, 0, true, a);
-      else
-        PT_LAUNCH((pt_simple_kernel<PT_RENDERER_FLAT, false>), grid, 0, true, a);
-      break;
-    case PT_RENDERER_POINTLIGHT:
-      if (hoist)
-        PT_LAUNCH((pt_simple_kernel<PT_RENDERER_POINTLIGHT, true>), grid, 0, true, a);
-      else
-        PT_LAUNCH((pt_simple_kernel<PT_RENDERER_POINTLIGHT, false>), grid, 0, true, a);
-      break;
-    default:
-      if (lds_frames) {
-        HIP_TRY(path_lds_limit((const void *)pt_path_kernel<true>, frame_lds));
-        PT_LAUNCH((pt_path_kernel<true>), grid, frame_lds, true, a);
-      } else {
-        PT_LAUNCH((pt_path_kernel<false>), grid, 0, true, a);
-      }
-      break;
-  }
+#define PT_SIMPLE(R_)                                                              \
+  do {                                                                             \
+    if (pl.simple_hoist)                                                           \
+      PT_LAUNCH((pt_simple_kernel<R_, true>), pl.grid, 0, true, a);                \
+    else                                                                           \
+      PT_LAUNCH((pt_simple_kernel<R_, false>), pl.grid, 0, true, a);               \
+  } while (0)
+    if (R == PT_RENDERER_ONOFF)
+      PT_SIMPLE(PT_RENDERER_ONOFF);
+    else if (R == PT_RENDERER_FLAT)
+      PT_SIMPLE(PT_RENDERER_FLAT);
+    else
+      PT_SIMPLE(PT_RENDERER_POINTLIGHT);
+#undef PT_SIMPLE
   }
   HIP_TRY(hipGetLastError());
   if (p->renderer == PT_RENDERER_PATHTRACER) {  // its path kernel is enqueued: the other queue block will be zero
@@ -1593,7 +1420,7 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
     s->stats_valid = false;
   }
   if (s->count_rays) {
-    hipLaunchKernelGGL(pt_sum_counts, dim3(1), dim3(256), 0, st, s->ray_partials, grid + grid_first + grid_q, s->ray_counter);
+    hipLaunchKernelGGL(pt_sum_counts, dim3(1), dim3(256), 0, st, s->ray_partials, n_count_slots, s->ray_counter);
     HIP_TRY(hipMemcpyAsync(s->ray_counter_host, s->ray_counter, 2 * sizeof(unsigned long long),
                            hipMemcpyDeviceToHost, st));
     // ev1 was recorded BEFORE the count left the device: whoever reads ray_counter_host waits for this one
@@ -1977,6 +1804,94 @@ extern "C" int pt_image_tonemap(int device, void *img, int fmt, int width, int h
   if (rgb8 && (rc = so.out(st))) return rc;
   if (!stream || si.owned || so.owned) HIP_TRY(hipStreamSynchronize(st));
   return PT_OK;
+}
+
+static void plan_info(const PtPlan &pl, const PtSceneFacts &f, const pt_params *p, pt_plan_info *out) {
+  memset(out, 0, sizeof *out);
+  out->kernel = pl.kernel;
+  out->rows = pl.rows;
+  out->npix = pl.npix;
+  pt_plan_kernel_name(pl, p->renderer, 0, out->pre_kernel, sizeof out->pre_kernel);
+  pt_plan_kernel_name(pl, p->renderer, 1, out->first_kernel, sizeof out->first_kernel);
+  pt_plan_kernel_name(pl, p->renderer, 2, out->main_kernel, sizeof out->main_kernel);
+  pt_plan_kernel_name(pl, p->renderer, 3, out->alt_kernel, sizeof out->alt_kernel);
+  out->grid = pl.grid;
+  out->grid_first = pl.grid_first;
+  out->grid_alt = pl.grid_q;
+  out->grid4_x = (int)pl.grid4_x;
+  out->grid4_y = (int)pl.grid4_y;
+  out->npx = pl.npx;
+  out->lds_first = pl.path_tiled ? (long long)pl.lds_tile : 0;
+  out->lds_main = (long long)pl.lds_main;
+  out->lds_alt = (long long)pl.lds_q;
+  const bool path = p->renderer == PT_RENDERER_PATHTRACER && !pl.zero_frame && pl.npix > 0;
+  out->frame_stack_home = !path ? 0 : (pl.lds_frames ? 1 : 2);
+  out->alt_frame_stack_home = !pl.q_alt ? 0 : (pl.q_lds_frames ? 1 : 2);
+  out->frame_doubles = path ? pl.frame_doubles : 0;
+  out->workspace_bytes = (long long)pl.ws_bytes;
+  out->q_min_flagged = pl.q_min;
+  out->wg_per_cu = pl.wg_per_cu;
+  out->block_h = pl.block_h;
+  out->hier = pl.hier;
+  out->ortho = pl.ortho;
+  out->hoist = pl.hoist;
+  out->tile4_lds = pl.t4lds;
+  out->n_spheres = f.n_spheres;
+  out->n_diag = f.n_diag;
+  out->has_grid = f.has_grid;
+  out->ball_levels = pl.bs_levels;
+  out->units_need = pl.units_need;
+  out->nregions = pl.nregions;
+  out->min_rounds = pl.min_rounds;
+  out->spec_draws = pl.spec_draws;
+}
+
+extern "C" int pt_debug_plan(const pt_scene_desc *desc, const pt_camera *cam, const pt_params *p, int n_cu, int dome_shortcut,
+                             pt_plan_info *out) {
+  if (!out) return fail(PT_ERR_INVALID, "null argument");
+  int rc = check_desc(desc);
+  if (rc) return rc;
+  pt_scene tmp;  // (a bag of facts here: no HIP call touches it)
+  HostTables h;
+  analyse_scene(desc, pt_tuning(), &tmp, h);
+  tmp.n_cu = n_cu > 0 ? n_cu : 256;
+  tmp.dome_shortcut = dome_shortcut != 0;
+  rc = check_params(&tmp, cam, p);
+  if (rc) return rc;
+  const PtSceneFacts f = scene_facts(&tmp);
+  PtPlan pl;
+  pt_make_plan(f, cam, p, pt_tuning(), pl);
+  plan_info(pl, f, p, out);
+  return PT_OK;
+}
+
+extern "C" int pt_debug_plan_scene(pt_scene *s, const pt_camera *cam, const pt_params *p, pt_plan_info *out) {
+  if (!out) return fail(PT_ERR_INVALID, "null argument");
+  int rc = check_params(s, cam, p);
+  if (rc) return rc;
+  const PtSceneFacts f = scene_facts(s);
+  PtPlan pl;
+  pt_make_plan(f, cam, p, pt_tuning(), pl);
+  plan_info(pl, f, p, out);
+  return PT_OK;
+}
+
+extern "C" int pt_debug_set_tuning(const char *name, long long value) {
+  if (!name || !pt_tuning_set(pt_tuning(), name, value)) return fail(PT_ERR_INVALID, "unknown tuning switch %s", name ? name : "(null)");
+  return PT_OK;
+}
+
+extern "C" int pt_debug_get_tuning(const char *name, long long *value) {
+  if (!name || !value) return fail(PT_ERR_INVALID, "null argument");
+  PtTuning &t = pt_tuning();
+#define X(field, env, dflt)                                    \
+  if (strcmp(name, #field) == 0 || strcmp(name, env) == 0) {   \
+    *value = t.field;                                          \
+    return PT_OK;                                              \
+  }
+  PT_TUNING_TABLE(X)
+#undef X
+  return fail(PT_ERR_INVALID, "unknown tuning switch %s", name);
 }
 
 // debug: the 16 words of the path-tracer queue block (word 0 = queue head, 1..8 = section cycle sums of

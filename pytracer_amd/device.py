@@ -199,6 +199,27 @@ def device_count() -> int:
     return int(_lib.lib().pt_device_count())
 
 
+def plan(flat, cam: abi.Camera, params: abi.Params, n_cu: int = 256, dome_shortcut: bool = True) -> abi.PlanInfo:
+    """What ``pt_render`` would launch for this scene, camera and parameters -- kernels, grids, LDS, frame-stack home,
+    thresholds -- from the library's host-side planner (``pt_debug_plan``, csrc/pt_plan.h).  Touches no device."""
+    info = abi.PlanInfo()
+    desc = flat.desc()
+    _lib.check(_lib.lib().pt_debug_plan(C.byref(desc), C.byref(cam), C.byref(params), int(n_cu), 1 if dome_shortcut else 0, C.byref(info)))
+    return info
+
+
+def set_tuning(name: str, value: int) -> None:
+    """One of the library's debug / measurement switches (csrc/pt_plan.h: PT_TUNING_TABLE), by field or ``PTRACE_*`` name.
+    Takes effect for the next frame of every scene of the process; none changes a pixel."""
+    _lib.check(_lib.lib().pt_debug_set_tuning(name.encode(), int(value)))
+
+
+def get_tuning(name: str) -> int:
+    v = C.c_longlong(0)
+    _lib.check(_lib.lib().pt_debug_get_tuning(name.encode(), C.byref(v)))
+    return int(v.value)
+
+
 def device_kernargs() -> bool:
     """True iff ``HIP_FORCE_DEV_KERNARG`` asks the HIP runtime for kernel arguments in device memory
     (``pytracer_amd.prefer_device_kernargs()`` before the first HIP call; ``pt_device_kernargs``)."""

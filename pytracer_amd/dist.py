@@ -19,9 +19,16 @@ Most of a frame is usually the same colour to the bit -- the sky: 99 % of the pi
 and at 12 bytes per pixel the full shards of a 4K frame (87 MB into rank 0 at 8 ranks, 50 MB over ONE link at 2) take
 longer to move than to render.  So a shard travels SPARSE by default (``encode_sparse`` / ``decode_sparse``; lossless):
 cut into runs of ``SPARSE_TILE`` consecutive pixels, a run whose pixels are all bitwise equal to its first is sent as
-that one pixel, the others whole.  Two messages per remote rank: a fixed-size part (count, one flag and one pixel per
-run), then the runs that are not constant -- the receiver learns their number from the first.  ``PT_GATHER_SPARSE=0``
-(or ``sparse=False``) sends the shards whole in one message, as in round 2.
+that one pixel, the others whole.  Two messages per remote rank -- a fixed-size part (count, one flag and one pixel per
+run) and the runs that are not constant -- posted in ONE batched point-to-point group, with NO host round trip in between
+(round 5): how many runs the second message carries is not read from the first but agreed on beforehand
+WITHOUT communication -- a capacity both sides derive by the same rule from the count of the frame before
+(``SparseGatherState``: count + 25 % + 64 runs), which the sender knows from its own encode and rank 0 from the fixed part it
+received; the counts travel to the host asynchronously and are looked at one frame LATER (``confirm``), when they have long
+arrived.  A frame whose count exceeds its capacity (a scene that suddenly changes) is repaired then: the missing runs follow
+in one more message and that rank's shard is decoded again -- before the frame counts as assembled.  Only the very first
+frame of a loop, which has no history, reads its counts back before the payload is sized (round 4's protocol).
+``PT_GATHER_SPARSE=0`` (or ``sparse=False``) sends the shards whole in one message, as in round 2.
 
 Which transport a process group uses is decided ONCE and COLLECTIVELY (``choose_transport``): every rank, also one
 that owns no rows, runs the same probe and the verdicts are all-reduced, so no rank can end up in a different
@@ -228,6 +235,33 @@ def sparse_count(fixed: torch.Tensor) -> int:
     return int(fixed[:8].clone().view(torch.int64).item())
 
 
+def encode_sparse_full(shard: torch.Tensor, parity: int = 0, tile: int = SPARSE_TILE) -> Tuple[torch.Tensor, torch.Tensor]:
+    """``encode_sparse`` without the count's read-back: -> ``(fixed, payload)`` with ``payload`` at FULL capacity
+    (``[runs, tile, 3]``; its first ``count`` runs are the ones that are not constant, the rest is undefined) -- nothing here
+    waits for the device.  ``parity`` picks one of two payload buffers per stream, so that a frame's runs stay intact until
+    the frame has been confirmed (``SparseGatherState``) while the next frame is encoded into the other one."""
+    flat = shard.reshape(-1, 3)
+    npx = flat.shape[0]
+    nt = (npx + tile - 1) // tile
+    if shard.is_cuda and tile == SPARSE_TILE:
+        from . import _lib
+
+        dev = shard.device
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        fixed = torch.empty((sparse_fixed_bytes(npx, shard.element_size()),), dtype=torch.uint8, device=dev)
+        key = (dev, shard.dtype, nt, stream, int(parity) & 1)
+        if key not in _sparse_scratch:
+            _sparse_scratch[key] = torch.empty((nt, tile, 3), dtype=shard.dtype, device=dev)
+        payload = _sparse_scratch[key]
+        _lib.check(_lib.lib().pt_image_sparse_encode(dev.index or 0, shard.contiguous().data_ptr(), npx, _fmt_of(shard.dtype),
+                                                     fixed.data_ptr(), payload.data_ptr(), stream))
+        return fixed, payload
+    fixed, runs = encode_sparse(shard, tile)
+    payload = torch.zeros((nt, tile, 3), dtype=shard.dtype, device=shard.device)
+    payload[: runs.shape[0]] = runs
+    return fixed, payload
+
+
 def decode_sparse(fixed: torch.Tensor, payload: Optional[torch.Tensor], n_pixels: int, dtype: torch.dtype,
                   tile: int = SPARSE_TILE, frame: Optional[torch.Tensor] = None, row_block: int = 0, world: int = 1,
                   rank: int = 0) -> torch.Tensor:
@@ -252,9 +286,9 @@ def decode_sparse(fixed: torch.Tensor, payload: Optional[torch.Tensor], n_pixels
     tiles = firsts.expand(nt, tile, 3).contiguous()
     idx = (place >= 0).nonzero().squeeze(1)
     n = 0 if payload is None else payload.shape[0]
-    if idx.numel() != n:
+    if idx.numel() > n:  # (a payload buffer may be larger than the count: a loop's receive buffers hold every run)
         raise RuntimeError(f"sparse shard: {n} runs received, {idx.numel()} flagged")
-    if n:
+    if idx.numel():
         tiles.index_copy_(0, idx, payload.index_select(0, place[idx].to(torch.int64)))
     shard = tiles.view(nt * tile, 3)[:n_pixels]
     if frame is None:
@@ -301,11 +335,158 @@ def _gather_padded(local, height, row_block, world, rank, group, dst, out):
         dist.gather(shard, None, dst=dst, group=group)
 
 
-def _gather_sparse(local, height, row_block, world, rank, group, dst, out, nrows, clock=None):
-    """Point-to-point gather of sparse shards: the fixed parts first (sizes known from the partition), then -- once
-    ``dst`` has read the counts -- the runs that are not constant."""
+class SparseGatherState:
+    """What the sparse gather of a frame LOOP remembers between frames so that no frame waits for the host.
+
+    * ``cap[r]``: how many runs the payload message of rank ``r`` carries in the NEXT frame -- derived by ``next_cap`` from the
+      count of the last confirmed frame, on the sender from its own encode and on ``dst`` from the fixed part it received:
+      the same number on both sides without a message.  Unknown (no frame yet): that frame uses the blocking protocol.
+    * ``pending``: frames whose transfers have been posted but whose counts have not been looked at yet.  ``confirm`` (called
+      before the next gather and by ``finish``) waits for the counts' asynchronous copies -- made a frame ago: they have
+      arrived -- updates the capacities and, where a count exceeded its capacity, moves the missing runs and decodes that
+      shard again (both sides know: the comparison is the same on both).
+    """
+
+    SLACK_NUM, SLACK_DEN, EXTRA = 5, 4, 64  # capacity = count * 5/4 + 64 runs, at most every run of the shard
+
+    def __init__(self):
+        self.cap = {}        # rank -> runs in the next payload message
+        self.pending = []    # [{"counts": {rank: host tensor}, "event", "cap": {rank: int}, ...}]
+        self.frames = 0      # frames gathered through this state
+        self.blocking = 0    # ... of which with the blocking (first-frame) protocol
+        self.overflows = 0   # ... shards repaired at confirmation
+        self._recv = {}      # dst: (rank, parity) -> (fixed, payload at full capacity)
+
+    @classmethod
+    def next_cap(cls, count: int, runs: int) -> int:
+        return min(int(runs), int(count) * cls.SLACK_NUM // cls.SLACK_DEN + cls.EXTRA)
+
+    def recv_buffers(self, r: int, parity: int, fixed_bytes: int, runs: int, like: torch.Tensor):
+        key = (r, parity & 1)
+        buf = self._recv.get(key)
+        if buf is None or buf[0].numel() != fixed_bytes or buf[1].shape[0] != runs or buf[1].dtype != like.dtype:
+            buf = (torch.empty((fixed_bytes,), dtype=torch.uint8, device=like.device),
+                   torch.zeros((runs, SPARSE_TILE, 3), dtype=like.dtype, device=like.device))
+            self._recv[key] = buf
+        return buf
+
+
+def _count_to_host(fixed_heads: torch.Tensor):
+    """The int64 counts at the head of fixed part(s) -> (host tensor, event or None), WITHOUT waiting: a non-blocking copy
+    into page-locked memory with an event behind it on a HIP device, the values themselves on the CPU."""
+    heads = fixed_heads.view(torch.int64).reshape(-1)
+    if heads.is_cuda:
+        host = torch.empty(heads.shape, dtype=torch.int64).pin_memory()
+        host.copy_(heads, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(heads.device))
+        return host, ev
+    return heads.clone(), None
+
+
+def _wait_all(ops):
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+
+
+def confirm_sparse(state: SparseGatherState, group=None, dst: int = 0) -> None:
+    """Look at the counts of the frames gathered so far through ``state`` (their copies were started a frame ago): new
+    capacities, and the repair of every shard whose count exceeded the capacity it travelled with.  Collective in the sense
+    that every rank of the group calls it at the same point of its frame sequence (before the next gather / in finish)."""
+    rank = dist.get_rank(group)
+
+    def peer_of(r):
+        return dist.get_global_rank(group, r) if group is not None else r
+
+    while state.pending:
+        f = state.pending.pop(0)
+        if f["event"] is not None:
+            f["event"].synchronize()  # (a copy enqueued a frame ago)
+        if rank == dst:
+            ops, redo = [], []
+            for k, r in enumerate(f["remote"]):
+                count, cap = int(f["counts"][k]), f["cap"][r]
+                state.cap[r] = state.next_cap(count, f["runs"][r])
+                if count > cap:  # the tail of its runs follows now
+                    ops.append(dist.P2POp(dist.irecv, f["payload"][r][cap:count], peer_of(r), group))
+                    redo.append(r)
+            _wait_all(ops)
+            for r in redo:
+                state.overflows += 1
+                decode_sparse(f["fixed"][r], f["payload"][r], f["npx"][r], f["out"].dtype, frame=f["out"],
+                              row_block=f["row_block"], world=f["world"], rank=r)
+        else:
+            count, cap = int(f["counts"][0]), f["cap"][rank]
+            state.cap[rank] = state.next_cap(count, f["runs"][rank])
+            if count > cap:
+                state.overflows += 1
+                _wait_all([dist.P2POp(dist.isend, f["payload"][cap:count], peer_of(dst), group)])
+
+
+def _gather_sparse_async(local, height, row_block, world, rank, group, dst, out, nrows, state, clock=None):
+    """The sparse gather without a host round trip: both messages of every remote rank in ONE batched group, the payload cut at
+    the capacity ``state`` holds for that rank.  -> False when a capacity is still unknown (the caller then runs the blocking
+    protocol, which also seeds the capacities)."""
     W = local.shape[1]
     esize = local.element_size()
+    remote = [r for r in range(world) if r != dst and nrows[r] > 0]
+    mine = [r for r in remote if r == rank] if rank != dst else remote
+    if any(r not in state.cap for r in mine):
+        return False
+    parity = state.frames & 1
+    runs = {r: (nrows[r] * W + SPARSE_TILE - 1) // SPARSE_TILE for r in remote}
+
+    def peer_of(r):
+        return dist.get_global_rank(group, r) if group is not None else r
+
+    if rank == dst:
+        fixed, payload, ops = {}, {}, []
+        for r in remote:
+            fixed[r], payload[r] = state.recv_buffers(r, parity, sparse_fixed_bytes(nrows[r] * W, esize), runs[r], local)
+            ops.append(dist.P2POp(dist.irecv, fixed[r], peer_of(r), group))
+            if state.cap[r] > 0:
+                ops.append(dist.P2POp(dist.irecv, payload[r][: state.cap[r]], peer_of(r), group))
+        _wait_all(ops)
+        _mark(clock, "transfer_ms")
+        if nrows[dst] > 0:
+            place_shard(out, local, height, row_block, world, dst)
+        if remote:
+            decode_sparse_many([fixed[r] for r in remote], [payload[r] for r in remote], remote, out, row_block, world)
+        _mark(clock, "decode_ms")
+        counts, ev = _count_to_host(torch.stack([fixed[r][:8] for r in remote])) if remote else (torch.zeros(0, dtype=torch.int64), None)
+        state.pending.append({"counts": counts, "event": ev, "remote": remote, "cap": {r: state.cap[r] for r in remote}, "runs": runs,
+                              "fixed": fixed, "payload": payload, "npx": {r: nrows[r] * W for r in remote}, "out": out,
+                              "row_block": row_block, "world": world})
+        last_gather.update(bytes=sum(fixed[r].numel() + state.cap[r] * SPARSE_TILE * 3 * esize for r in remote), sparse=True)
+    elif nrows[rank] > 0:
+        fixed, payload = encode_sparse_full(local[: nrows[rank]].contiguous(), parity)
+        _mark(clock, "encode_ms")  # (classify + scan + pack: no read-back)
+        cap = state.cap[rank]
+        ops = [dist.P2POp(dist.isend, fixed, peer_of(dst), group)]
+        if cap > 0:
+            ops.append(dist.P2POp(dist.isend, payload[:cap], peer_of(dst), group))
+        _wait_all(ops)
+        _mark(clock, "transfer_ms")
+        counts, ev = _count_to_host(fixed[:8])
+        state.pending.append({"counts": counts, "event": ev, "cap": {rank: cap}, "runs": runs, "payload": payload, "fixed": fixed})
+    state.frames += 1
+    return True
+
+
+def _gather_sparse(local, height, row_block, world, rank, group, dst, out, nrows, clock=None, state=None):
+    """Point-to-point gather of sparse shards.  With a ``state`` that knows every capacity: both messages in one group, no
+    host round trip (``_gather_sparse_async``).  Otherwise (the first frame of a loop, or no loop at all) the blocking
+    protocol: the fixed parts first (sizes known from the partition), then -- once ``dst`` has read the counts -- the runs
+    that are not constant."""
+    W = local.shape[1]
+    esize = local.element_size()
+    if state is not None:
+        confirm_sparse(state, group, dst)  # (the frame before: its counts arrived long ago)
+        if _gather_sparse_async(local, height, row_block, world, rank, group, dst, out, nrows, state, clock):
+            return
+        state.frames += 1
+        state.blocking += 1
 
     def peer_of(r):
         return dist.get_global_rank(group, r) if group is not None else r
@@ -333,9 +514,14 @@ def _gather_sparse(local, height, row_block, world, rank, group, dst, out, nrows
             decode_sparse_many([fixed[r] for r in remote], [payload[r] for r in remote], remote, out, row_block, world)
         _mark(clock, "decode_ms")
         last_gather.update(bytes=sum(fixed[r].numel() + payload[r].numel() * esize for r in remote), sparse=True)
+        if state is not None:  # the capacities the next frames travel with
+            for r in remote:
+                state.cap[r] = state.next_cap(counts[r], (nrows[r] * W + SPARSE_TILE - 1) // SPARSE_TILE)
     elif nrows[rank] > 0:
         fixed, payload = encode_sparse(local[: nrows[rank]].contiguous())
         _mark(clock, "encode_ms")  # (classify + scan + pack, and the count's read-back)
+        if state is not None:
+            state.cap[rank] = state.next_cap(payload.shape[0], (nrows[rank] * W + SPARSE_TILE - 1) // SPARSE_TILE)
         for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, fixed, peer_of(dst), group)]):
             req.wait()
         if payload.shape[0] > 0:
@@ -346,12 +532,15 @@ def _gather_sparse(local, height, row_block, world, rank, group, dst, out, nrows
 
 def gather_image(local: torch.Tensor, height: int, row_block: int, group=None, dst: int = 0,
                  out: Optional[torch.Tensor] = None, staging: Optional[torch.Tensor] = None,
-                 sparse: Optional[bool] = None, clock: Optional[PhaseClock] = None) -> Optional[torch.Tensor]:
+                 sparse: Optional[bool] = None, clock: Optional[PhaseClock] = None,
+                 state: Optional[SparseGatherState] = None) -> Optional[torch.Tensor]:
     """Assemble the frame on ``dst`` from the ranks' compact row shards.
 
     ``local`` is this rank's ``[>= rows_of_this_rank, W, 3]`` shard (rows beyond its own are ignored).
     ``staging`` (``dst`` only, optional): a ``[world, max_shard_rows, W, 3]`` buffer the remote shards land in.
-    Returns the ``[H, W, 3]`` image on ``dst`` (``out`` when given) and ``None`` elsewhere."""
+    ``state`` (a frame loop's ``SparseGatherState``): the sparse gather then moves both of a rank's messages in one group
+    without reading a count back; the frame is final once ``confirm_sparse(state)`` has run (the next gather and
+    ``ShardedFrameLoop.finish`` do).  Returns the ``[H, W, 3]`` image on ``dst`` (``out`` when given) and ``None`` elsewhere."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     if world == 1:
@@ -374,7 +563,7 @@ def gather_image(local: torch.Tensor, height: int, row_block: int, group=None, d
         _gather_padded(local, height, row_block, world, rank, group, dst, out)
         _mark(clock, "transfer_ms")
     elif sparse:
-        _gather_sparse(local, height, row_block, world, rank, group, dst, out, nrows, clock)
+        _gather_sparse(local, height, row_block, world, rank, group, dst, out, nrows, clock, state if not staged else None)
     elif rank == dst:
         if staging is None:
             staging = torch.empty((world, max(nrows)) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
@@ -470,6 +659,8 @@ class ShardedFrameLoop:
         self._assembled = self.world == 1  # image(): the last frame rendered has been gathered
         self._pending = []            # buffers whose frames are rendered (or being rendered) and not gathered yet, oldest first
         self.sparse = sparse_default() if sparse is None else bool(sparse)
+        # the sparse gather's memory between frames: capacities agreed without a message, frames awaiting confirmation
+        self.gstate = SparseGatherState() if (self.world > 1 and self.sparse) else None
         self.gather_bytes = None      # rank 0: what the remote ranks sent for the last gathered frame
         self.last = 0
         self._count = 0
@@ -513,7 +704,7 @@ class ShardedFrameLoop:
                 self.comm.wait_event(self._rendered[b])
             gather_image(self.bufs[b], self.height, self.row_block, group=self.group, dst=0,
                          out=self.full[b] if self.rank == 0 else None,
-                         staging=self.staging if self.rank == 0 else None, sparse=self.sparse)
+                         staging=self.staging if self.rank == 0 else None, sparse=self.sparse, state=self.gstate)
             if self.rank == 0:
                 self.gather_bytes = last_gather.get("bytes")
             done = torch.cuda.Event()
@@ -524,6 +715,9 @@ class ShardedFrameLoop:
 
     def finish(self) -> None:
         self._drain()
+        if self.gstate is not None and self.gstate.pending:  # the last frames' counts: capacities, and a repair where one overflowed
+            with torch.cuda.stream(self.comm):
+                confirm_sparse(self.gstate, self.group, 0)
         torch.cuda.synchronize()
 
     PHASES = ("render_ms", "encode_ms", "transfer_ms", "decode_ms")
@@ -550,7 +744,9 @@ class ShardedFrameLoop:
                 with torch.cuda.stream(self.comm):
                     gather_image(self.bufs[0], self.height, self.row_block, group=self.group, dst=0,
                                  out=self.full[0] if self.rank == 0 else None,
-                                 staging=self.staging if self.rank == 0 else None, sparse=self.sparse, clock=clock)
+                                 staging=self.staging if self.rank == 0 else None, sparse=self.sparse, clock=clock, state=self.gstate)
+                    if self.gstate is not None:
+                        confirm_sparse(self.gstate, self.group, 0)
                 torch.cuda.synchronize()
             for k in self.PHASES:
                 total[k] += clock.ms.get(k, 0.0)

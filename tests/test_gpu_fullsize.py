@@ -66,7 +66,7 @@ def test_c2_full_frame_bit_exact_vs_oracle(dev, oracle, renderer, fmt):
             st = ds.stats()
             assert out.dtype == ora.dtype and out.tobytes() == ora.tobytes(), f"dome shortcut {dome}: device != oracle"
             assert int(st.n_rays) == n == W * H
-            assert st.kernel == abi.KERNEL_TILE4 or __import__("os").environ.get("PTRACE_TILE4", "1") == "0"
+            assert st.kernel == abi.KERNEL_TILE4 or dev.get_tuning("tile4") == 0
 
 
 @pytest.mark.parametrize("mode", [abi.PCG_PIXEL, abi.PCG_SAMPLE])
@@ -195,7 +195,7 @@ def test_num_of_rays_above_one_the_device_picks_the_second_pass_by_the_flagged_p
     W, H = 640, 360
     dense, cam = _synthetic(32, True, False, W, H)    # a ground plane: every pixel below the horizon is flagged
     sparse, _ = _synthetic(32, False, False, W, H)    # spheres in front of a sky: 3 % of the pixels
-    if __import__("os").environ.get("PTRACE_QCHOICE", "1") != "1" or __import__("os").environ.get("PTRACE_TREE", "1") == "0":
+    if dev.get_tuning("qchoice") != 1 or dev.get_tuning("tree") == 0:
         pytest.skip("the choice is forced by PTRACE_QCHOICE / PTRACE_TREE (measurement switches)")
     # (N, D) = (3, 2): the one-queue kernel's frame stack fits the LDS; (2, 5), roulette from depth 2: it lives in HBM
     for scene, want_kernel, n_rays, depth, rr in ((dense, abi.KERNEL_PATH, 3, 2, 3), (sparse, abi.KERNEL_PATH_TREE, 3, 2, 3),
@@ -225,7 +225,7 @@ def test_one_queue_second_pass_under_an_orthogonal_camera_with_textures_and_mirr
     on a frame dense enough for the device to pick it; against the oracle, and partition-invariant."""
     from pytracer_amd import flatten, hostmodel as hm
 
-    if __import__("os").environ.get("PTRACE_QCHOICE", "1") != "1" or __import__("os").environ.get("PTRACE_TREE", "1") == "0":
+    if dev.get_tuning("qchoice") != 1 or dev.get_tuning("tree") == 0:
         pytest.skip("the choice is forced by PTRACE_QCHOICE / PTRACE_TREE (measurement switches)")
     g = hm.PCG(99, 1)
     r = g.random_float

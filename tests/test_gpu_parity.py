@@ -24,8 +24,14 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-5
 
 # (measurement switches may force the round-2 kernels, e.g. PTRACE_TREE=0 PTRACE_TILE4=0 pytest -m gpu: same images)
-TREE_KERNEL = abi.KERNEL_PATH_TREE if os.environ.get("PTRACE_TREE", "1") != "0" else abi.KERNEL_PATH_REGIONS
-TILE4_KERNEL = abi.KERNEL_TILE4 if os.environ.get("PTRACE_TILE4", "1") != "0" else abi.KERNEL_TILE
+def _tuned(name):
+    from pytracer_amd import device
+
+    return device.get_tuning(name)
+
+
+TREE_KERNEL = abi.KERNEL_PATH_TREE if _tuned("tree") != 0 else abi.KERNEL_PATH_REGIONS
+TILE4_KERNEL = abi.KERNEL_TILE4 if _tuned("tile4") != 0 else abi.KERNEL_TILE
 
 
 @pytest.fixture(scope="module")

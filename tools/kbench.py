@@ -58,6 +58,9 @@ CONFIGS = {
     "pl": (32, True, False, 1280, 720, dict(renderer=abi.RENDERER_POINTLIGHT, lights=2)),
     "pl5": (10000, False, True, 1280, 720, dict(renderer=abi.RENDERER_POINTLIGHT, lights=1)),
     "c5small": (10000, False, True, 320, 180, dict(renderer=abi.RENDERER_FLAT)),
+    # the reference's demo scene (examples/demo.txt, clock = 150) at 1280x960 with the CLI's path-tracer defaults
+    "demo10": ("demo", False, False, 1280, 960, dict(renderer=abi.RENDERER_PATHTRACER, samples_per_side=1, num_of_rays=10,
+                                                     max_depth=3, rr_limit=3, path_state=45, path_seq=54)),
 }
 
 
@@ -73,7 +76,11 @@ def main():
         kw = dict(kw)
         if sample:
             kw["pcg_mode"] = abi.PCG_SAMPLE
-        world = scenes.synthetic_world(ns, with_plane=plane, wide=wide)
+        demo_cam = None
+        if ns == "demo":
+            world, demo_cam = scenes.demo_world(clock=150.0)
+        else:
+            world = scenes.synthetic_world(ns, with_plane=plane, wide=wide)
         for l in range(kw.pop("lights", 0)):
             from pytracer_amd import hostmodel as hm
             world.add_light(hm.PointLight(hm.Vec(-3.0 + 4.0 * l, 6.0 - 9.0 * l, 8.0), hm.Color(1.0, 0.9, 0.8), 0.0))
@@ -82,6 +89,8 @@ def main():
             from pytracer_amd import hostmodel as hm
             cam = flatten.flatten_camera(hm.OrthogonalCamera(W / H, hm.translation(hm.Vec(-1.0, 0.0, 1.5)) *
                                                              hm.scaling(hm.Vec(1.0, 3.0, 1.7))))
+        elif demo_cam is not None:
+            cam = flatten.flatten_camera(demo_cam)
         else:
             cam = flatten.flatten_camera(scenes.synthetic_camera(W, H))
         par = abi.make_params(W, H, out_format=abi.OUT_F64 if args.f64 else abi.OUT_F32, **kw)

@@ -6,13 +6,23 @@
         median over the matching dispatches of every counter -> OUT (what bench.py reads for roofline.executed /
         roofline.traffic).  HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes): gfx950 tallies 128-B
         read requests at 64 B (MI355X_MICROARCH.md, HBM section); the two come from separate passes.
+        The JSON also records WHICH BINARY was measured: `code_hash` = sha256 of the device code of --lib (default: the
+        in-tree libptrace.so, or $PTRACE_LIB; pytracer_amd.build.code_hash) and the kernel's registers / scratch / LDS
+        from the code object (tools/kres.py); bench.py prices a roofline from the file only when the hash is the loaded
+        library's.
 """
 import argparse
 import csv
 import glob
 import json
+import os
 import statistics
+import sys
 from collections import OrderedDict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 ap = argparse.ArgumentParser()
 ap.add_argument("dirs", nargs="+")
@@ -20,6 +30,7 @@ ap.add_argument("--kernel")
 ap.add_argument("--grid", type=int)
 ap.add_argument("--json")
 ap.add_argument("--source", default="")
+ap.add_argument("--lib", default=os.environ.get("PTRACE_LIB") or os.path.join(ROOT, "pytracer_amd", "libptrace.so"))
 args = ap.parse_args()
 
 rows = OrderedDict()
@@ -53,6 +64,24 @@ out = {
     "counters": counters,
     "source": args.source or ("rocprofv3 --pmc passes under " + ", ".join(args.dirs)),
 }
+try:  # which binary these counters belong to
+    from pytracer_amd.build import code_hash
+
+    out["code_hash"] = code_hash(args.lib)
+    out["lib"] = os.path.relpath(args.lib, ROOT) if args.lib.startswith(ROOT) else args.lib
+except (OSError, ValueError) as e:
+    out["code_hash"] = None
+    out["code_hash_error"] = str(e)
+try:
+    import kres
+
+    res = kres.kernel_resources(args.lib)
+    want = out["kernel"].replace("void ", "").strip()
+    match = [v for k, v in res.items() if k.replace("void ", "").strip() == want]
+    out["kernel_resources"] = match[0] if match else None
+except Exception as e:  # noqa: BLE001  (llvm tools missing: the hash alone ties the file to the binary)
+    out["kernel_resources"] = None
+    out["kernel_resources_error"] = f"{type(e).__name__}: {e}"[:200]
 if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
     out["fetch_size_kb_raw"] = counters["FETCH_SIZE"]
     out["write_size_kb_raw"] = counters["WRITE_SIZE"]
