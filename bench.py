@@ -213,6 +213,37 @@ def parity_check(flat, cam, par, frame):
     return row
 
 
+ORACLE_TESTS_PER_CORE_S = 9.0e7  # ray-shape tests per second and core of oracle/pt_oracle.c (C2: 2.9 Mray/s x 33 shapes on an EPYC 9575F core)
+
+
+def oracle_check(flat, cam, par, frame, rays):
+    """The assembled frame of a sharded run against the CPU oracle's frame of the same scene, camera and parameters (x*x
+    arithmetic, fp32 output): bit-identical pixels counted, outliers beyond 1e-5 relative per channel counted.  The oracle is
+    the checker, outside every timed region.  Skipped with a reason when it would take longer than PT_BENCH_ORACLE_S (default
+    200 s) on this host's usable cores -- the other ranks wait behind a barrier meanwhile."""
+    from oracle import oracle as orc
+
+    orc.build()
+    cores = max(1, min(orc.max_threads(), usable_cores()[0]))
+    est = rays * flat.n_shapes / (ORACLE_TESTS_PER_CORE_S * cores)
+    limit = float(os.environ.get("PT_BENCH_ORACLE_S", "200"))
+    if est > limit:
+        return {"checked": False, "reason": f"the oracle would need about {est:.0f} s on {cores} cores (limit {limit:.0f} s: PT_BENCH_ORACLE_S)"}
+    t0 = time.perf_counter()
+    want, n_rays = orc.render(flat, cam, abi.copy_params(par, n_ranks=1, rank=0), n_threads=cores, sqr_mode=orc.SQR_MUL)
+    orc.set_sqr_mode(orc.SQR_POW)
+    dt = time.perf_counter() - t0
+    got = frame.detach().cpu().numpy()
+    same_px = (got.view(np.uint32) == want.view(np.uint32)).all(axis=-1)
+    den = np.maximum(np.abs(got), np.abs(want)).astype(np.float64)
+    err = np.where(den > 0, np.abs(got.astype(np.float64) - want) / np.where(den > 0, den, 1.0), 0.0)
+    return {"checked": True, "bit_identical": bool(same_px.all()), "pixels": int(same_px.size), "pixels_differing": int((~same_px).sum()),
+            "pixels_beyond_1e-5": int((err > 1e-5).any(axis=-1).sum()), "max_rel_err": float(err.max()),
+            "rays_match": int(n_rays) == int(rays), "oracle_seconds": dt, "cores": cores,
+            "against": "oracle/pt_oracle.c (C restatement of the reference path, pinned to the reference's own outputs by tests/golden), "
+                       "x*x arithmetic, fp32 output; computed on rank 0's host cores outside every timed region"}
+
+
 def kernel_row(ds, cam, par, out, reps, flat):
     """Median kernel time (events in the dispatches) and ray statistics of `reps` frames."""
     ms = []
@@ -954,10 +985,18 @@ def sharded_workload(args, cfg, modes, ds, cam, rank, world_size, dist, agree, g
                 _, k1, n1 = timed_loop(ds, solo, max(2, steps // 2), None, False, events=True)
                 rows[(mode, "check")] = "ok" if torch.equal(solo.image(), loop[0].image()) else "MISMATCH"
                 rows[(mode, "n1")] = (el1, k1 / max(1, n1))
+                # ... and against the ORACLE's frame (rank 0 alone is the same kernels): the CPU restatement
+                # of the reference path on this rank's host cores, while the GPUs idle -- bounded: skipped (and said so) when the
+                # frame's ray-shape tests would take the host longer than PT_BENCH_ORACLE_S seconds
+                rows[(mode, "oracle")] = oracle_check(cfg["flat"], cam, par, loop[0].image(), rays_frame[mode])
             fence(dist)
             loop[0].close()
             if rank == 0 and rows[(mode, "check")] != "ok":  # (raised behind the fence: every rank has left its collectives)
                 raise RuntimeError(f"{tag}: the gathered frame differs from the frame rank 0 renders alone")
+            oc = rows.get((mode, "oracle")) if rank == 0 else None
+            if oc and oc.get("checked") and (oc["pixels_beyond_1e-5"] > 1 or not oc["rays_match"]):
+                raise RuntimeError(f"{tag}: the gathered frame differs from the ORACLE's in {oc['pixels_beyond_1e-5']} pixels beyond 1e-5 "
+                                   f"(rays match: {oc['rays_match']})")
 
         if not agree.run(f"gather check + one-GPU loop {tag}", check_and_solo):
             break
@@ -974,6 +1013,7 @@ def sharded_workload(args, cfg, modes, ds, cam, rank, world_size, dist, agree, g
 
     def mode_rows(mode):
         out = dict(line(mode, True), without_gather=line(mode, False), gather_check=rows.get((mode, "check")),
+                   oracle_check=rows.get((mode, "oracle")),
                    gather_bytes_per_frame_sent=rows.get((mode, "gather_bytes")),
                    rays_per_frame=rays_frame[mode], steps=steps,
                    traced_ray_fraction=1.0 - resolved_frame[mode] / max(1, rays_frame[mode]))
@@ -1070,7 +1110,7 @@ def run_multi(args, rank, local_rank, world_size, dist, backend):
             gather_choice["sparse"] = False
             gather_choice["probe_error"] = agree.soft.get("gather probe")
 
-    c4_rows = sharded_workload(args, dict(C4, name="C4"), (abi.PCG_SAMPLE, abi.PCG_PIXEL), ds, cam, rank, world_size, dist, agree,
+    c4_rows = sharded_workload(args, dict(C4, name="C4", flat=flat), (abi.PCG_SAMPLE, abi.PCG_PIXEL), ds, cam, rank, world_size, dist, agree,
                                gather_choice["sparse"], args.steps)
     ds.close()
 
@@ -1081,7 +1121,7 @@ def run_multi(args, rank, local_rank, world_size, dist, backend):
     flat3 = flatten.flatten_world(scenes.synthetic_world(C3["n_spheres"], wide=C3["wide"]))
     ds3 = SceneGroup(flat3, n_in_flight, local_rank)
     if agree.error is None:
-        c3_rows = sharded_workload(args, dict(C3, name="C3"), (abi.PCG_SAMPLE,), ds3, cam_for(C3["W"], C3["H"]), rank, world_size,
+        c3_rows = sharded_workload(args, dict(C3, name="C3", flat=flat3), (abi.PCG_SAMPLE,), ds3, cam_for(C3["W"], C3["H"]), rank, world_size,
                                    dist, agree, gather_choice["sparse"], max(args.steps, 5 * args.steps))
     ds3.close()
 
@@ -1272,7 +1312,7 @@ def main():
     import torch.distributed as dist
 
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    timeout = datetime.timedelta(seconds=int(os.environ.get("PT_DIST_TIMEOUT_S", "300")))
+    timeout = datetime.timedelta(seconds=int(os.environ.get("PT_DIST_TIMEOUT_S", "900")))  # (rank 0's oracle check: the others wait)
     if backend == "nccl":
         dist.init_process_group("nccl", rank=rank, world_size=world_size, timeout=timeout,
                                 device_id=torch.device("cuda", local_rank))

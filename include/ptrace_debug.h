@@ -65,7 +65,7 @@ typedef struct pt_plan_info {
   int32_t grid, grid_first, grid_alt;         /* workgroups of 256 threads */
   int32_t grid4_x, grid4_y, npx;              /* pt_tile4_kernel: its 2-D grid and pixels per lane */
   int64_t lds_first, lds_main, lds_alt;       /* dynamic LDS per workgroup, bytes */
-  int32_t frame_stack_home;  /* path tracer: 0 none, 1 LDS, 2 HBM */
+  int32_t frame_stack_home;  /* path tracer: 0 none, 1 LDS, 2 HBM, 3 split (the deepest slot in LDS, the others in HBM) */
   int32_t alt_frame_stack_home;
   int32_t frame_doubles;     /* fields per stack frame */
   int64_t workspace_bytes;   /* frame stack in HBM */

@@ -166,7 +166,7 @@ class PlanInfo(C.Structure):
         ("_reserved", C.c_int32 * 8),
     ]
 
-    STACK_HOMES = {0: None, 1: "LDS", 2: "HBM"}
+    STACK_HOMES = {0: None, 1: "LDS", 2: "HBM", 3: "SPLIT"}
 
     @property
     def pre_kernel(self) -> str:

@@ -139,19 +139,43 @@ struct PathCtx {
   size_t nthreads;
   int gtid;
   int lds_base, lds_frame;  // LDS frames: first double of the frame area, doubles per frame
+  int deep_slot;            // HOME 2: the one stack slot that lives in LDS (the deepest: max_depth - 1)
 };
 // The frame stack lives in LDS whenever (max_depth x frame) x 256 lanes fits beside the survivor masks
 // (LDSF): the second pass is a chain of dependent steps per pixel, and a frame access that goes to
 // HBM costs more than the step's arithmetic.  Same [slot][field][lane] layout in both homes.
+// HOME 2 (round 5, the one-queue kernel of num_of_rays > 1): SPLIT -- only the DEEPEST slot lives in LDS, the shallower ones
+// in HBM.  A tree of N children per node touches the frame at depth d once per node below it, N^(d+1) times per pixel: at the
+// CLI's N = 10, D = 3 the deepest frame takes 1000 of a pixel's 1110 frame visits, the one above it 100, the root's 10.  One
+// frame of 20 doubles per lane is 40 KB per workgroup instead of 120: two workgroups per CU -- two waves per SIMD, where
+// all three frames in LDS allow one -- and nine visits in ten still never leave the CU.
 extern __shared__ double pt_lds_f64[];  // the same dynamic LDS block as pt_lds_masks
-template <bool LDSF>
+// A frame of the split stack is reached through ONE generic pointer picked per lane when the frame is entered (a flat
+// access resolves to LDS or to memory by its address): the two homes then share every load and store instead of doubling
+// them behind a per-lane branch (which cost 180 - 350 bytes of scratch at the 256 registers two waves per SIMD leave).
+struct FrameRef {
+  double *p;        // field 0 of this lane's frame
+  size_t fstride;   // doubles between consecutive fields
+};
+PT_DEV FrameRef frame_ref_split(const PathCtx &w, int slot) {
+  FrameRef r;
+  double *lds = (double *)(pt_lds_f64 + w.lds_base + (int)threadIdx.x);
+  double *mem = w.ws + (size_t)slot * w.stride + w.gtid;
+  const bool deep = slot == w.deep_slot;
+  r.p = deep ? lds : mem;
+  r.fstride = deep ? (size_t)PT_BLOCK : w.nthreads;
+  return r;
+}
+template <int HOME>
 PT_DEV double ws_get(const PathCtx &w, int slot, int field) {
-  if (LDSF) return pt_lds_f64[w.lds_base + (slot * w.lds_frame + field) * PT_BLOCK + (int)threadIdx.x];
+  static_assert(HOME != 2, "the split stack goes through frame_ref_split");
+  if (HOME == 1) return pt_lds_f64[w.lds_base + (slot * w.lds_frame + field) * PT_BLOCK + (int)threadIdx.x];
   return w.ws[(size_t)slot * w.stride + (size_t)field * w.nthreads + w.gtid];
 }
-template <bool LDSF>
+template <int HOME>
 PT_DEV void ws_put(const PathCtx &w, int slot, int field, double v) {
-  if (LDSF)
+  static_assert(HOME != 2, "the split stack goes through frame_ref_split");
+  if (HOME == 1)
     pt_lds_f64[w.lds_base + (slot * w.lds_frame + field) * PT_BLOCK + (int)threadIdx.x] = v;
   else
     w.ws[(size_t)slot * w.stride + (size_t)field * w.nthreads + w.gtid] = v;
@@ -212,9 +236,10 @@ PT_DEV long long next_pixel(const PtKArgs &a, bool need, long long npix) {
 #endif
 // FLAGGED (!TILED only): the kernel runs BEHIND the first pass, as the alternative to pt_path_tree_kernel (PT_Q_CHOICE): it
 // returns at once unless the device chose it, and a lane keeps only pixels the first pass flagged (the others are settled).
-template <bool TILED, bool LDSF, bool LAT, bool SLDS = false, int LEAN = 0, bool FLAGGED = false>
+template <bool TILED, int LDSF, bool LAT, bool SLDS = false, int LEAN = 0, bool FLAGGED = false>
 PT_DEV void path_trace(const PtKArgs &a) {
   constexpr bool INL = LAT && PT_REGIONS_INLINE;
+  static_assert(LDSF != 2 || !TILED, "the split frame stack belongs to the one-queue kernel");
   static_assert(!SLDS || INL, "the scene is staged in LDS for the second pass only");
   static_assert(!FLAGGED || !TILED, "the flagged-pixel filter belongs to the one-queue kernel");
   PathCtx w;
@@ -228,6 +253,7 @@ PT_DEV void path_trace(const PtKArgs &a) {
     w.gtid = blockIdx.x * PT_BLOCK + threadIdx.x;
     w.lds_frame = c->frame_doubles;
     w.lds_base = TILED ? 4 * c->npass : 0;  // behind the four waves' survivor masks (8-byte units)
+    w.deep_slot = (c->D > 1 ? c->D : 1) - 1;
     ortho = c->cam_kind != PT_CAMERA_PERSPECTIVE;
     diag_lds = c->diag_lds;
     pcg_mode = c->pcg_mode;
@@ -435,27 +461,35 @@ PT_DEV void path_trace(const PtKArgs &a) {
       else
         hit_details_call(rec, ax, &ray, best_t, &h, false);
     }
-    ws_put<LDSF>(w, sp, 0, hc.x);
-    ws_put<LDSF>(w, sp, 1, hc.y);
-    ws_put<LDSF>(w, sp, 2, hc.z);
-    ws_put<LDSF>(w, sp, 3, em.x);
-    ws_put<LDSF>(w, sp, 4, em.y);
-    ws_put<LDSF>(w, sp, 5, em.z);
+    FrameRef fr = {nullptr, 0};
+    if constexpr (LDSF == 2) fr = frame_ref_split(w, sp);
+    auto fput = [&](int field, double v) {
+      if constexpr (LDSF == 2)
+        fr.p[(size_t)field * fr.fstride] = v;
+      else
+        ws_put<LDSF>(w, sp, field, v);
+    };
+    fput(0, hc.x);
+    fput(1, hc.y);
+    fput(2, hc.z);
+    fput(3, em.x);
+    fput(4, em.y);
+    fput(5, em.z);
     if (N > 1) {
-      ws_put<LDSF>(w, sp, 6, 0.0);
-      ws_put<LDSF>(w, sp, 7, 0.0);
-      ws_put<LDSF>(w, sp, 8, 0.0);
-      ws_put<LDSF>(w, sp, 9, 0.0);
-      ws_put<LDSF>(w, sp, 10, h.wp.x);
-      ws_put<LDSF>(w, sp, 11, h.wp.y);
-      ws_put<LDSF>(w, sp, 12, h.wp.z);
-      ws_put<LDSF>(w, sp, 13, h.n.x);
-      ws_put<LDSF>(w, sp, 14, h.n.y);
-      ws_put<LDSF>(w, sp, 15, h.n.z);
-      ws_put<LDSF>(w, sp, 16, ray.d.x);
-      ws_put<LDSF>(w, sp, 17, ray.d.y);
-      ws_put<LDSF>(w, sp, 18, ray.d.z);
-      ws_put<LDSF>(w, sp, 19, (double)ax->brdf_kind);
+      fput(6, 0.0);
+      fput(7, 0.0);
+      fput(8, 0.0);
+      fput(9, 0.0);
+      fput(10, h.wp.x);
+      fput(11, h.wp.y);
+      fput(12, h.wp.z);
+      fput(13, h.n.x);
+      fput(14, h.n.y);
+      fput(15, h.n.z);
+      fput(16, ray.d.x);
+      fput(17, ray.d.y);
+      fput(18, ray.d.z);
+      fput(19, (double)ax->brdf_kind);
     }
     f_wp = h.wp;
     f_n = h.n;
@@ -560,7 +594,7 @@ PT_DEV void path_trace(const PtKArgs &a) {
           // value instead of two cross-lane permutes per double (the walk was 17 - 22 % of the second pass's cycles under
           // PT_PCG_SAMPLE: 16 turns for a pixel with 16 lanes).
           const int park = w.lds_base + (int)(threadIdx.x & ~63u);  // field f of lane l of this wave: park + f * PT_BLOCK + l
-          if (LDSF) {
+          if (LDSF == 1) {
             const int me = park + lane;
             pt_lds_f64[me] = ret.x;
             pt_lds_f64[me + PT_BLOCK] = ret.y;
@@ -582,7 +616,7 @@ PT_DEV void path_trace(const PtKArgs &a) {
             unsigned s_draws = 0, s_rays;
             int s_fin, s_samp = 0;
             double rx_, ry_, rz_;
-            if (LDSF) {
+            if (LDSF == 1) {
               const int at = park + src;
               const unsigned long long meta = pt_lds_masks[at + 3 * PT_BLOCK];
               rx_ = pt_lds_f64[at];
@@ -915,35 +949,49 @@ PT_DEV void path_trace(const PtKArgs &a) {
       }
       // a child of frame sp-1 returned `ret` (render.py:135-137)
       const int fs = sp - 1;
-      const V3 hc = {ws_get<LDSF>(w, fs, 0), ws_get<LDSF>(w, fs, 1), ws_get<LDSF>(w, fs, 2)};
+      FrameRef fr = {nullptr, 0};
+      if constexpr (LDSF == 2) fr = frame_ref_split(w, fs);
+      auto fget = [&](int field) -> double {
+        if constexpr (LDSF == 2)
+          return fr.p[(size_t)field * fr.fstride];
+        else
+          return ws_get<LDSF>(w, fs, field);
+      };
+      auto fput = [&](int field, double v) {
+        if constexpr (LDSF == 2)
+          fr.p[(size_t)field * fr.fstride] = v;
+        else
+          ws_put<LDSF>(w, fs, field, v);
+      };
+      const V3 hc = {fget(0), fget(1), fget(2)};
       V3 fc = {0.0, 0.0, 0.0};
       int done = 0;
       if (N > 1) {
-        fc.x = ws_get<LDSF>(w, fs, 6);
-        fc.y = ws_get<LDSF>(w, fs, 7);
-        fc.z = ws_get<LDSF>(w, fs, 8);
-        done = (int)ws_get<LDSF>(w, fs, 9);
+        fc.x = fget(6);
+        fc.y = fget(7);
+        fc.z = fget(8);
+        done = (int)fget(9);
       }
       fc.x = fc.x + hc.x * ret.x;
       fc.y = fc.y + hc.y * ret.y;
       fc.z = fc.z + hc.z * ret.z;
       done++;
       if (done < N) {
-        ws_put<LDSF>(w, fs, 6, fc.x);
-        ws_put<LDSF>(w, fs, 7, fc.y);
-        ws_put<LDSF>(w, fs, 8, fc.z);
-        ws_put<LDSF>(w, fs, 9, (double)done);
-        f_wp = {ws_get<LDSF>(w, fs, 10), ws_get<LDSF>(w, fs, 11), ws_get<LDSF>(w, fs, 12)};
-        f_n = {ws_get<LDSF>(w, fs, 13), ws_get<LDSF>(w, fs, 14), ws_get<LDSF>(w, fs, 15)};
-        f_in = {ws_get<LDSF>(w, fs, 16), ws_get<LDSF>(w, fs, 17), ws_get<LDSF>(w, fs, 18)};
-        f_brdf = (int)ws_get<LDSF>(w, fs, 19);
+        fput(6, fc.x);
+        fput(7, fc.y);
+        fput(8, fc.z);
+        fput(9, (double)done);
+        f_wp = {fget(10), fget(11), fget(12)};
+        f_n = {fget(13), fget(14), fget(15)};
+        f_in = {fget(16), fget(17), fget(18)};
+        f_brdf = (int)fget(19);
         spawn = true;
         continue;
       }
       // render.py:139
-      ret.x = ws_get<LDSF>(w, fs, 3) + fc.x * invN;
-      ret.y = ws_get<LDSF>(w, fs, 4) + fc.y * invN;
-      ret.z = ws_get<LDSF>(w, fs, 5) + fc.z * invN;
+      ret.x = fget(3) + fc.x * invN;
+      ret.y = fget(4) + fc.y * invN;
+      ret.z = fget(5) + fc.z * invN;
       sp = fs;
     }
     PT_STAMP(5);
@@ -965,10 +1013,10 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAV
 // ... FLAGGED with the scattered rays on per-lane candidate lists (world_query_lanes) and everything inline, like the second
 // pass by regions: it runs with 20 doubles per depth and lane of frame stack in LDS -- one workgroup per CU at the CLI's
 // D = 3, one wave per SIMD --, so registers are no object and a step's latency is what counts
-// (LDSF = false: stacks deeper than the LDS holds -- D > 3 -- live in HBM, same layout; two waves per SIMD then)
-template <int LEAN, bool LDSF = true>
-__global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(LDSF ? 1 : 2, 2))) void pt_path_flagged_kernel(const PtKArgs a) {
-  path_trace<false, LDSF, true, false, LEAN, true>(a);
+// (HOME 0: the whole stack in HBM, same layout; 2: only the deepest slot in LDS -- see ws_get; two waves per SIMD in both)
+template <int LEAN, int HOME = 1>
+__global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(HOME == 1 ? 1 : 2, 2))) void pt_path_flagged_kernel(const PtKArgs a) {
+  path_trace<false, HOME, true, false, LEAN, true>(a);
 }
 // second pass behind pt_tile_kernel<PATHTRACER> (perspective camera): the flagged pixels, by region
 #ifndef PT_WAVES_REGIONS

@@ -36,6 +36,7 @@
   X(tile4_lds, "PTRACE_TILE4_LDS", 1)             /* pt_tile4_kernel<FLAT>: records staged in LDS for shading */            \
   X(qchoice, "PTRACE_QCHOICE", 1)                 /* 0: never the one-queue alternative, 2: always (measurement) */         \
   X(q_lds_frames, "PTRACE_Q_LDS_FRAMES", 1)       /* 0: the one-queue kernel's frame stack always in HBM */                 \
+  X(q_frames_home, "PTRACE_Q_FRAMES_HOME", -1)    /* ... 0 HBM, 1 LDS, 2 split (deepest slot in LDS); -1: by the plan */    \
   X(q_min_flagged, "PTRACE_Q_MIN_FLAGGED", -1)    /* >= 0: the flagged-pixel count from which the one-queue kernel works */ \
   X(q_lanes, "PTRACE_Q_LANES", 1)                 /* 0: the one-queue alternative is pt_path_kernel<true, true> */          \
   X(p_maxpath, "PTRACE_P_MAXPATH", 0)             /* step batching of path_trace (0: by kernel) */                          \
@@ -116,8 +117,10 @@ enum PtAltPass {  // the one-queue alternative enqueued behind the tree kernel (
   PT_ALT_FLAGGED_LEAN_HBM,  // pt_path_flagged_kernel<1, false>
   PT_ALT_FLAGGED_HBM,       // <0, false>
   PT_ALT_PATH_UNIFORM,      // pt_path_kernel<true, true>
-  PT_ALT_FLAGGED_LEAN_LDS,  // pt_path_flagged_kernel<1, true>
-  PT_ALT_FLAGGED_LDS,       // <0, true>
+  PT_ALT_FLAGGED_LEAN_LDS,  // pt_path_flagged_kernel<1, 1>
+  PT_ALT_FLAGGED_LDS,       // <0, 1>
+  PT_ALT_FLAGGED_LEAN_SPLIT,  // pt_path_flagged_kernel<1, 2>: the deepest stack slot in LDS, the others in HBM
+  PT_ALT_FLAGGED_SPLIT,       // <0, 2>
 };
 
 struct PtPlan {
@@ -149,6 +152,7 @@ struct PtPlan {
   size_t lds_q = 0;       // the one-queue alternative
   // path tracer
   bool lds_frames = false, q_lds_frames = false;
+  int q_home = 0;         // the one-queue alternative's frame stack: 0 HBM, 1 LDS, 2 split (deepest slot in LDS, the rest in HBM)
   int frame_doubles = 6;
   int diag_lds = -1, grid_occ_lds = -1, scene_lds = -1;  // offsets as the kernels take them (PtKArgs)
   int q_diag_lds = -1;
@@ -292,11 +296,21 @@ static inline void pt_make_plan(const PtSceneFacts &s, const pt_camera *cam, con
   // (PT_Q_CHOICE).  The one-queue kernel keeps its per-lane frame stack (20 doubles per depth and lane) in LDS where that
   // fits (D <= 3), in HBM beyond.
   const size_t q_frame_bytes = (size_t)std::max(p->max_depth, 1) * 20 * B * sizeof(double);  // per workgroup
-  pl.q_lds_frames = t.q_lds_frames != 0 && q_frame_bytes <= PT_LDS_BUDGET;
-  const size_t q_frame_lds = pl.q_lds_frames ? q_frame_bytes : 0;
+  // Where that stack lives.  All of it in LDS while it fits (D <= 3 at 20 doubles per depth and lane): one workgroup per CU,
+  // one wave per SIMD.  Beyond: SPLIT -- only the deepest slot in LDS (it takes N / (N + 1) of all frame visits), the
+  // shallower ones in HBM, two workgroups per CU.  Measured (profiles/r05_q_frames_home.txt): at D <= 3 the split stack is
+  // SLOWER than all-LDS (C2 + plane, N = 10: 10.6 against 9.2 ms; all in HBM: 11.4) -- a wave's iteration waits for its
+  // slowest lane, and with 64 lanes one of them is at a shallow node nearly every iteration: two waves per SIMD do not
+  // buy back an HBM round trip per iteration --; at D > 3 it equals or slightly beats the all-HBM stack it replaces.
+  pl.q_home = q_frame_bytes <= PT_LDS_BUDGET ? 1 : 2;
+  if (t.q_lds_frames == 0) pl.q_home = 0;
+  if (t.q_frames_home >= 0 && t.q_frames_home <= 2) pl.q_home = (int)t.q_frames_home;
+  if (pl.q_home == 1 && q_frame_bytes > PT_LDS_BUDGET) pl.q_home = 2;
+  pl.q_lds_frames = pl.q_home == 1;
+  const size_t q_frame_lds = pl.q_home == 1 ? q_frame_bytes : (pl.q_home == 2 ? (size_t)20 * B * sizeof(double) : 0);
   pl.q_alt = pl.tree && t.qchoice != 0;
   if (pl.q_alt) {
-    const int wgq = pl.q_lds_frames ? std::min<int>(3, (int)(PT_LDS_BUDGET / q_frame_bytes)) : 2;
+    const int wgq = pl.q_home == 1 ? std::min<int>(3, (int)(PT_LDS_BUDGET / q_frame_bytes)) : 2;
     pl.grid_q = (int)std::max<long long>(1, std::min<long long>(want, (long long)s.n_cu * wgq));
   }
   if (pl.path_tiled) {  // first pass (pt_tile_kernel<PATHTRACER>): one wave per 8x8 region
@@ -319,7 +333,7 @@ static inline void pt_make_plan(const PtSceneFacts &s, const pt_camera *cam, con
     pl.p_max_path = t.p_maxpath > 0 ? (int)t.p_maxpath : (pl.path_tiled ? 1 : 48);
     pl.s_min_path = t.s_min > 0 ? (int)t.s_min : (pl.path_tiled ? 1 : 16);
     size_t need = pl.lds_frames ? 0 : (size_t)std::max(p->max_depth, 1) * pl.frame_doubles * (size_t)pl.nthreads * sizeof(double);
-    if (pl.q_alt && !pl.q_lds_frames)  // (the tree kernel's stack is in LDS: the workspace is the one-queue kernel's)
+    if (pl.q_alt && pl.q_home != 1)  // (the tree kernel's stack is in LDS: the workspace is the one-queue kernel's)
       need = std::max(need, q_frame_bytes * (size_t)pl.grid_q);
     pl.ws_bytes = need;
   }
@@ -402,7 +416,7 @@ static inline void pt_make_plan(const PtSceneFacts &s, const pt_camera *cam, con
         pw *= (double)fit_n;
         tree_rays += pw;
       }
-      const double step_ns = (6.0 + 0.02 * fit_shapes) * 1e3 * (pl.q_lds_frames ? 1.0 : 1.3);  // (frames in HBM: measured on D = 4 ... 8)
+      const double step_ns = (6.0 + 0.02 * fit_shapes) * 1e3 * (pl.q_home != 0 ? 1.0 : 1.3);  // (all frames in HBM: measured on D = 4 ... 8)
       const double t_tree = (4.5 + 0.045 * std::min(tree_rays, 500.0)) * (2048.0 / (8.0 * s.n_cu));
       const double t_queue = (0.5 + 0.01 * fit_shapes) * (1.0 + tree_rays / 800.0);
       if (t_tree > t_queue) pl.q_min = (long long)std::min(1e15, 1.1 * tree_rays * step_ns / (t_tree - t_queue));
@@ -431,11 +445,13 @@ static inline void pt_make_plan(const PtSceneFacts &s, const pt_camera *cam, con
       // for the ray counts); the scale+translate records behind the frame stack when they fit
       const size_t q_diag_bytes = (size_t)s.n_diag * PT_PLAN_DIAG_BYTES;
       const bool q_diag = s.n_diag > 0 && q_diag_bytes <= 48 * 1024 &&
-                          q_frame_lds + q_diag_bytes <= (pl.q_lds_frames ? PT_LDS_BUDGET : PT_LDS_BUDGET / 2);
+                          q_frame_lds + q_diag_bytes <= (pl.q_home == 1 ? PT_LDS_BUDGET : PT_LDS_BUDGET / 2);
       pl.q_diag_lds = q_diag ? (int)(q_frame_lds / 8) : -1;
       pl.lds_q = q_frame_lds + (q_diag ? q_diag_bytes : 0);
-      if (!pl.q_lds_frames)
+      if (pl.q_home == 0)
         pl.alt = small_world ? PT_ALT_FLAGGED_LEAN_HBM : PT_ALT_FLAGGED_HBM;
+      else if (pl.q_home == 2)
+        pl.alt = small_world ? PT_ALT_FLAGGED_LEAN_SPLIT : PT_ALT_FLAGGED_SPLIT;
       else if (!t.q_lanes)
         pl.alt = PT_ALT_PATH_UNIFORM;
       else
@@ -477,8 +493,9 @@ static inline const char *pt_plan_kernel_name(const PtPlan &pl, int renderer, in
     else
       snprintf(buf, n, "pt_simple_kernel<%s, %s>", r, pl.simple_hoist ? "HOIST" : "noHOIST");
   } else if (which == 3) {
-    static const char *A[6] = {"", "pt_path_flagged_kernel<LEAN, HBM>", "pt_path_flagged_kernel<HBM>", "pt_path_kernel<LDS, FLAGGED>",
-                               "pt_path_flagged_kernel<LEAN, LDS>", "pt_path_flagged_kernel<LDS>"};
+    static const char *A[8] = {"", "pt_path_flagged_kernel<LEAN, HBM>", "pt_path_flagged_kernel<HBM>", "pt_path_kernel<LDS, FLAGGED>",
+                               "pt_path_flagged_kernel<LEAN, LDS>", "pt_path_flagged_kernel<LDS>",
+                               "pt_path_flagged_kernel<LEAN, SPLIT>", "pt_path_flagged_kernel<SPLIT>"};
     snprintf(buf, n, "%s", A[pl.alt]);
   }
   return buf;

@@ -1357,11 +1357,13 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
     PT_LAUNCH((K_), pl.grid_q, pl.lds_q, true, aq);             \
   } while (0)
         switch (pl.alt) {
-          case PT_ALT_FLAGGED_LEAN_HBM: PT_ALT((pt_path_flagged_kernel<1, false>)); break;
-          case PT_ALT_FLAGGED_HBM: PT_ALT((pt_path_flagged_kernel<0, false>)); break;
+          case PT_ALT_FLAGGED_LEAN_HBM: PT_ALT((pt_path_flagged_kernel<1, 0>)); break;
+          case PT_ALT_FLAGGED_HBM: PT_ALT((pt_path_flagged_kernel<0, 0>)); break;
           case PT_ALT_PATH_UNIFORM: PT_ALT((pt_path_kernel<true, true>)); break;
-          case PT_ALT_FLAGGED_LEAN_LDS: PT_ALT((pt_path_flagged_kernel<1>)); break;
-          default: PT_ALT((pt_path_flagged_kernel<0>)); break;
+          case PT_ALT_FLAGGED_LEAN_LDS: PT_ALT((pt_path_flagged_kernel<1, 1>)); break;
+          case PT_ALT_FLAGGED_LEAN_SPLIT: PT_ALT((pt_path_flagged_kernel<1, 2>)); break;
+          case PT_ALT_FLAGGED_SPLIT: PT_ALT((pt_path_flagged_kernel<0, 2>)); break;
+          default: PT_ALT((pt_path_flagged_kernel<0, 1>)); break;
         }
 #undef PT_ALT
         main_fn = tree_fn;  // (pt_stats.vgprs: the tree kernel's; pt_stats.kernel follows the device's choice, see fold_stats)
@@ -1826,7 +1828,7 @@ static void plan_info(const PtPlan &pl, const PtSceneFacts &f, const pt_params *
   out->lds_alt = (long long)pl.lds_q;
   const bool path = p->renderer == PT_RENDERER_PATHTRACER && !pl.zero_frame && pl.npix > 0;
   out->frame_stack_home = !path ? 0 : (pl.lds_frames ? 1 : 2);
-  out->alt_frame_stack_home = !pl.q_alt ? 0 : (pl.q_lds_frames ? 1 : 2);
+  out->alt_frame_stack_home = !pl.q_alt ? 0 : (pl.q_home == 1 ? 1 : (pl.q_home == 2 ? 3 : 2));
   out->frame_doubles = path ? pl.frame_doubles : 0;
   out->workspace_bytes = (long long)pl.ws_bytes;
   out->q_min_flagged = pl.q_min;

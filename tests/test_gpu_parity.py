@@ -30,7 +30,8 @@ def _tuned(name):
     return device.get_tuning(name)
 
 
-TREE_KERNEL = abi.KERNEL_PATH_TREE if _tuned("tree") != 0 else abi.KERNEL_PATH_REGIONS
+# (num_of_rays > 1: the tree kernel, unless a switch forces the one-queue alternative on every frame or takes the tree kernel away)
+TREE_KERNEL = (abi.KERNEL_PATH_REGIONS if _tuned("tree") == 0 else (abi.KERNEL_PATH if _tuned("qchoice") == 2 else abi.KERNEL_PATH_TREE))
 TILE4_KERNEL = abi.KERNEL_TILE4 if _tuned("tile4") != 0 else abi.KERNEL_TILE
 
 

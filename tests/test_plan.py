@@ -76,10 +76,10 @@ def test_cli_defaults_enqueue_the_tree_kernel_and_the_one_queue_alternative():
     assert p.kernels == ["pt_tile_kernel<PATHTRACER>", "pt_path_tree_kernel<LEAN>", "pt_path_flagged_kernel<LEAN, LDS>"]
     assert p.kernel == abi.KERNEL_PATH_TREE and p.frame_doubles == 20 and p.frame_stack == "LDS" and p.alt_frame_stack == "LDS"
     assert p.lds_main == 32 + 3 * 20 * 4 * 8 + 32 * 64  # per WAVE and node, not per lane; + the 32 scale+translate records
-    assert p.lds_alt == 3 * 20 * 256 * 8 + 32 * 64 and p.grid_alt == 256  # 120 KB of frames: one workgroup per CU
+    assert p.lds_alt == 3 * 20 * 256 * 8 + 32 * 64 and p.grid_alt == 256 and p.workspace_bytes == 0  # 120 KB of frames: one workgroup per CU
     assert 250_000 < p.q_min_flagged < 400_000  # C3's 29 k flagged pixels: tree; C2 + plane's 490 k: one queue
     deep = plan(world(32), 1280, 720, **dict(CLI, num_of_rays=3, max_depth=5))
-    assert deep.alt_kernel == "pt_path_flagged_kernel<LEAN, HBM>" and deep.alt_frame_stack == "HBM" and deep.grid_alt == 512
+    assert deep.alt_kernel == "pt_path_flagged_kernel<LEAN, SPLIT>" and deep.alt_frame_stack == "SPLIT" and deep.grid_alt == 512
     assert deep.workspace_bytes == 5 * 20 * 256 * 8 * 512
 
 
@@ -181,9 +181,16 @@ def test_switches_select_the_documented_variants(tuning):
     tuning("q_lds_frames", 0)
     assert plan(world(32), 1280, 720, **CLI).alt_kernel == "pt_path_flagged_kernel<LEAN, HBM>"
     tuning("q_lds_frames", 1)
+    tuning("q_frames_home", 2)  # only the deepest slot in LDS (40 KB: two workgroups per CU), the others in HBM: measured slower at D <= 3
+    two = plan(world(32), 1280, 720, **CLI)
+    assert two.alt_kernel == "pt_path_flagged_kernel<LEAN, SPLIT>" and two.grid_alt == 512 and two.lds_alt == 20 * 256 * 8 + 32 * 64
+    assert two.workspace_bytes == 3 * 20 * 256 * 8 * 512
+    tuning("q_frames_home", 1)
+    assert plan(world(32), 1280, 720, **dict(CLI, max_depth=5)).alt_kernel == "pt_path_flagged_kernel<LEAN, SPLIT>"  # (does not fit: split)
     tuning("q_lanes", 0)
     assert plan(world(32), 1280, 720, **CLI).alt_kernel == "pt_path_kernel<LDS, FLAGGED>"
     tuning("q_lanes", 1)
+    tuning("q_frames_home", -1)
     tuning("lds_frames", 0)
     assert plan(world(32), 1280, 720, **C3).main_kernel == "pt_path_regions_kernel<HBM>"
     tuning("lds_frames", 1)

@@ -36,3 +36,10 @@ for name in sys.argv[1:] or ["c3n10"]:
     for n, v in zip(names, list(q)[1:8]):
         print(f"  {n:22s} {v / 1e6:10.2f} Mcycles  {100 * v / tot:5.1f} %   {v / rounds:8.0f} cycles / round")
     ds.close()
+
+if os.environ.get("DBG_LANES"):  # the scattered-ray query's own split (world_query_lanes; counters of the whole process)
+    d = (C.c_ulonglong * 8)()
+    _lib.lib().pt_debug_read_dbg(d, 1)
+    calls = max(1, d[3])
+    print(f"world_query_lanes: calls {d[3]}, prefilter {d[0] / calls:.0f} cycles/call, walk {d[1] / calls:.0f} cycles/call, "
+          f"iterations {d[2] / calls:.2f}/call -> {d[1] / max(1, d[2]):.0f} cycles/iteration")

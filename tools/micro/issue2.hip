@@ -30,6 +30,7 @@ constexpr int CH = 16, UNROLL = 4, ITER = 1500;
   X(CNDMASK_E64_VCC, "v_cndmask_b32_e64 (vcc as the SGPR operand)", asm volatile("v_cndmask_b32_e64 %0, %0, %1, vcc" : "+v"(u[k]) : "v"(u[(k + 1) % CH])))   \
   X(CNDMASK_VCC_NODEP, "v_cndmask_b32 (e32, vcc; independent destinations)", asm volatile("v_cndmask_b32 %0, %1, %2, vcc" : "=v"(u[k]) : "v"(w32), "v"(zero_u)))   \
   X(CNDMASK_SGPR, "v_cndmask_b32 (e64, SGPR pair; issue.hip's row)", asm volatile("v_cndmask_b32 %0, %0, %1, %2" : "+v"(u[k]) : "v"(u[(k + 1) % CH]), "s"(m[0])))   \
+  X(ADDC_VCC, "v_addc_co_u32 (e32: vcc in and out)", asm volatile("v_addc_co_u32 %0, vcc, %0, %1, vcc" : "+v"(u[k]) : "v"(u[(k + 1) % CH]) : "vcc"))   \
   X(MAX_F32, "v_max_f32", asm volatile("v_max_f32 %0, %0, %1" : "+v"(f[k]) : "v"(onef)))                                     \
   X(MAX3_F32, "v_max3_f32", asm volatile("v_max3_f32 %0, %0, %1, %1" : "+v"(f[k]) : "v"(onef)))                             \
   X(LDEXP_F32, "v_ldexp_f32", asm volatile("v_ldexp_f32 %0, %0, %1" : "+v"(f[k]) : "v"(zero_u)))                            \
