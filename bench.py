@@ -224,7 +224,9 @@ def oracle_check(flat, cam, par, frame, rays):
     from oracle import oracle as orc
 
     orc.build()
-    cores = max(1, min(orc.max_threads(), usable_cores()[0]))
+    # every core this JOB may use: the other ranks wait behind a barrier meanwhile, and a launcher's OMP_NUM_THREADS (torchrun
+    # sets 1 per rank) is a default for the ranks' own libraries, not a limit on this check (the oracle sets its thread count)
+    cores = max(1, usable_cores()[0])
     est = rays * flat.n_shapes / (ORACLE_TESTS_PER_CORE_S * cores)
     limit = float(os.environ.get("PT_BENCH_ORACLE_S", "200"))
     if est > limit:
@@ -849,6 +851,16 @@ class SceneGroup:
             d.close()
 
 
+_T0 = time.perf_counter()
+
+
+def progress(msg):
+    """One line on stderr (rank 0 of a multi-rank run): which phase the job is in and since when -- a run of several minutes
+    that prints nothing looks hung from outside, and a real hang should say where."""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.perf_counter() - _T0:7.1f} s] {msg}", file=sys.stderr, flush=True)
+
+
 class Agreement:
     """Ranks agree after every phase on whether all of them got through it: a rank that raised still enters this
     all-reduce, so the others learn of it here instead of waiting in the next collective until the watchdog ends
@@ -871,6 +883,7 @@ class Agreement:
 
     def run(self, phase, fn):
         """Run `fn()` on this rank; -> True iff EVERY rank completed it (collective)."""
+        progress(phase)
         if self.error is None:
             try:
                 fn()
@@ -988,6 +1001,7 @@ def sharded_workload(args, cfg, modes, ds, cam, rank, world_size, dist, agree, g
                 # ... and against the ORACLE's frame (rank 0 alone is the same kernels): the CPU restatement
                 # of the reference path on this rank's host cores, while the GPUs idle -- bounded: skipped (and said so) when the
                 # frame's ray-shape tests would take the host longer than PT_BENCH_ORACLE_S seconds
+                progress(f"oracle check {tag} (the CPU oracle renders the whole frame on this rank's host cores; the other ranks wait)")
                 rows[(mode, "oracle")] = oracle_check(cfg["flat"], cam, par, loop[0].image(), rays_frame[mode])
             fence(dist)
             loop[0].close()

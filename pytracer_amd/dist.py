@@ -385,9 +385,30 @@ def _count_to_host(fixed_heads: torch.Tensor):
 
 
 def _wait_all(ops):
-    if ops:
+    """One batched point-to-point group.  A rehearsal on a box with fewer GPUs than ranks runs ``gloo``, which moves host memory
+    only: device tensors of the group are then staged through the host HERE, message by message (a synchronisation per message:
+    a rehearsal of the protocol, not of its timing) -- everything else of the gather, encode / decode kernels included, runs as
+    it does under RCCL."""
+    if not ops:
+        return
+    staged = [op for op in ops if op.tensor.is_cuda and dist.get_backend(op.group) == "gloo"]
+    if not staged:
         for req in dist.batch_isend_irecv(ops):
             req.wait()
+        return
+    host_ops, back = [], []
+    for op in ops:
+        if op.tensor.is_cuda:
+            h = op.tensor.cpu() if op.op is dist.isend else torch.empty(op.tensor.shape, dtype=op.tensor.dtype)
+            if op.op is dist.irecv:
+                back.append((op.tensor, h))
+            host_ops.append(dist.P2POp(op.op, h, op.peer, op.group))
+        else:
+            host_ops.append(op)
+    for req in dist.batch_isend_irecv(host_ops):
+        req.wait()
+    for dev_t, h in back:
+        dev_t.copy_(h)
 
 
 def confirm_sparse(state: SparseGatherState, group=None, dst: int = 0) -> None:
@@ -494,19 +515,14 @@ def _gather_sparse(local, height, row_block, world, rank, group, dst, out, nrows
     if rank == dst:
         remote = [r for r in range(world) if r != dst and nrows[r] > 0]
         fixed = {r: torch.empty((sparse_fixed_bytes(nrows[r] * W, esize),), dtype=torch.uint8, device=local.device) for r in remote}
-        if remote:
-            for req in dist.batch_isend_irecv([dist.P2POp(dist.irecv, fixed[r], peer_of(r), group) for r in remote]):
-                req.wait()
+        _wait_all([dist.P2POp(dist.irecv, fixed[r], peer_of(r), group) for r in remote])
         counts = {}
         if remote:
             heads = torch.stack([fixed[r][:8] for r in remote]).view(torch.int64).reshape(-1).cpu()  # (one synchronisation)
             counts = {r: int(heads[k]) for k, r in enumerate(remote)}
         _mark(clock, "transfer_ms")  # (fixed parts in, counts read back: includes waiting for the remote ranks' encode)
         payload = {r: torch.empty((counts[r], SPARSE_TILE, 3), dtype=local.dtype, device=local.device) for r in remote}
-        ops = [dist.P2POp(dist.irecv, payload[r], peer_of(r), group) for r in remote if counts[r] > 0]
-        if ops:
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
+        _wait_all([dist.P2POp(dist.irecv, payload[r], peer_of(r), group) for r in remote if counts[r] > 0])
         _mark(clock, "transfer_ms")
         if nrows[dst] > 0:
             place_shard(out, local, height, row_block, world, dst)
@@ -522,11 +538,9 @@ def _gather_sparse(local, height, row_block, world, rank, group, dst, out, nrows
         _mark(clock, "encode_ms")  # (classify + scan + pack, and the count's read-back)
         if state is not None:
             state.cap[rank] = state.next_cap(payload.shape[0], (nrows[rank] * W + SPARSE_TILE - 1) // SPARSE_TILE)
-        for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, fixed, peer_of(dst), group)]):
-            req.wait()
+        _wait_all([dist.P2POp(dist.isend, fixed, peer_of(dst), group)])
         if payload.shape[0] > 0:
-            for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, payload, peer_of(dst), group)]):
-                req.wait()
+            _wait_all([dist.P2POp(dist.isend, payload, peer_of(dst), group)])
         _mark(clock, "transfer_ms")
 
 
@@ -548,7 +562,10 @@ def gather_image(local: torch.Tensor, height: int, row_block: int, group=None, d
         return local[: len(rows)]
     transport = choose_transport(group)  # (collective on first use: every rank gets here, with or without rows)
     # rehearsal on a box with fewer GPUs than ranks (PT_DIST_BACKEND=gloo): gloo moves host memory only
-    staged = dist.get_backend(group) == "gloo" and local.is_cuda
+    if sparse is None:
+        sparse = sparse_default()  # (the same on every rank: an argument or the environment of the job)
+    # (a loop's sparse gather stages its MESSAGES through the host under gloo, see _wait_all; every other path the whole shard)
+    staged = dist.get_backend(group) == "gloo" and local.is_cuda and not (state is not None and sparse and transport == P2P)
     if staged:
         dev_out, dev_local = out, local
         local = dev_local.cpu()
@@ -557,13 +574,11 @@ def gather_image(local: torch.Tensor, height: int, row_block: int, group=None, d
     if rank == dst and out is None:
         out = torch.empty((height,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     nrows = [len(shard_rows(height, row_block, world, r)) for r in range(world)]
-    if sparse is None:
-        sparse = sparse_default()  # (the same on every rank: an argument or the environment of the job)
     if transport == PADDED:
         _gather_padded(local, height, row_block, world, rank, group, dst, out)
         _mark(clock, "transfer_ms")
     elif sparse:
-        _gather_sparse(local, height, row_block, world, rank, group, dst, out, nrows, clock, state if not staged else None)
+        _gather_sparse(local, height, row_block, world, rank, group, dst, out, nrows, clock, None if staged else state)
     elif rank == dst:
         if staging is None:
             staging = torch.empty((world, max(nrows)) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)

@@ -248,7 +248,7 @@ def test_partition_helpers():
 
 
 # ---- the frame LOOP's sparse gather: capacities agreed without a message, no count read back per frame (round 5) -----------
-def _loop_worker(rank, world, port, H, W, ret):
+def _loop_worker(rank, world, port, H, W, ret, device="cpu"):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -260,6 +260,9 @@ def _loop_worker(rank, world, port, H, W, ret):
         g = torch.Generator().manual_seed(11)
         sky = torch.empty((H, W, 3), dtype=torch.float32)
         sky[...] = torch.tensor([0.25, -0.0, 0.75])
+        dev = torch.device(device)
+        if dev.type == "cuda":
+            torch.cuda.set_device(dev)
 
         def frame(kind, k):
             f = sky.clone()
@@ -276,22 +279,35 @@ def _loop_worker(rank, world, port, H, W, ret):
         frames = [frame(kind, k) for k, kind in enumerate(kinds)]  # (same generator on every rank: the same frames)
         rows = ptdist.shard_rows(H, 8, world, rank)
         state = ptdist.SparseGatherState()
-        outs = [torch.zeros((H, W, 3), dtype=torch.float32) for _ in frames] if rank == 0 else [None] * len(frames)
+        outs = [torch.zeros((H, W, 3), dtype=torch.float32, device=dev) for _ in frames] if rank == 0 else [None] * len(frames)
         sent = []
         for k, f in enumerate(frames):
-            shard = f[rows].contiguous() if rows else torch.zeros((1, W, 3), dtype=f.dtype)
+            shard = (f[rows].contiguous() if rows else torch.zeros((1, W, 3), dtype=f.dtype)).to(dev)
             out = ptdist.gather_image(shard, H, 8, sparse=True, out=outs[k], state=state)
             assert (out is outs[k]) if rank == 0 else out is None
             sent.append(int(ptdist.last_gather.get("bytes", -1)) if rank == 0 else 0)
         ptdist.confirm_sparse(state)  # (what ShardedFrameLoop.finish does: the last frame's counts, and its repair if need be)
         assert not state.pending
         if rank == 0:
-            ret["ok"] = [bool(torch.equal(o.view(torch.int32), f.view(torch.int32))) for o, f in zip(outs, frames)]
+            ret["ok"] = [bool(torch.equal(o.cpu().view(torch.int32), f.view(torch.int32))) for o, f in zip(outs, frames)]
             ret["sent"] = sent
         ret[f"stats{rank}"] = (state.frames, state.blocking, state.overflows)
         dist.barrier()
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_frame_loop_gather_on_the_device_under_gloo():
+    """The same nine frames with the shards in HBM (two ranks sharing cuda:0, gloo carrying the MESSAGES through the host): the
+    device encode without its read-back (pt_image_sparse_encode into a full-capacity payload), the asynchronous copy of the
+    counts into page-locked memory, the one-launch decode out of full-capacity receive buffers and the single-shard decode of
+    the overflow repair -- the pieces of the protocol a CPU run cannot reach."""
+    ret = mp.Manager().dict()
+    port = _free_port()
+    mp.spawn(_loop_worker, args=(2, port, 64, 1280, ret, "cuda:0"), nprocs=2, join=True)
+    assert ret["ok"] == [True] * 9, ret["ok"]
+    assert ret["stats0"][:2] == (9, 1) and ret["stats0"][2] >= 1 and ret["stats1"][2] >= 1
 
 
 @pytest.mark.parametrize("world,H,W", [(2, 64, 1280), (3, 50, 1280), (8, 2160, 96)])
