@@ -656,6 +656,11 @@ def run_single(args, local_rank):
     repeats = max(1, args.repeats, min(400, int(np.ceil(args.min_timed_ms * 1e-3 / est_loop_s))))
     elapsed_all = [timed_loop(ds, loop, args.steps, None, False, events=False)[0] for _ in range(repeats)]
     elapsed = float(np.median(elapsed_all))
+    # the same loop with TEN TIMES the steps (a few repeats): what a timed region costs beyond its frames -- the first launch's
+    # way to the GPU and the last synchronisation's way back, ~16 us per region -- divides by K: at the driver's K = 20 it is
+    # 0.8 us of every step, at K = 200 a tenth of that.  Reported so that the line explains its own K.
+    k10 = 10 * args.steps
+    el10 = float(np.median([timed_loop(ds, loop, k10, None, False, events=False)[0] for _ in range(max(3, min(repeats, 400 // max(1, args.steps))))]))
     parity = parity_check(flat, cam, par, loop.image())  # the frame those loops left in HBM, against the oracle's
     elapsed_ev, kernel_total_ms, launches = timed_loop(ds, loop, args.steps, None, False, events=True)  # the same, every launch with its own event pair
     per_launch_pair_s = kernel_total_ms / max(launches, 1) * 1e-3
@@ -773,6 +778,10 @@ def run_single(args, local_rank):
                     "timed_ms_total": sum(elapsed_all) * 1e3,
                     "pre_roll": {"launches": pre_n, "ms": pre_ms, "note": "untimed launches of the same kernel before the first timed loop (clock ramp)"},
                     "note": "the K-step timed loop run `n` times back to back (until >= 20 ms are timed); value and ms_per_step are the median repeat"},
+        "same_loop_at_10x_steps": {"steps": k10, "ms_per_step": el10 / k10 * 1e3,
+                                   "fixed_cost_per_timed_region_us": (elapsed - el10 / 10.0) / 0.9 * 1e6,
+                                   "note": "the identical timed loop with 10 x K steps: ms_per_step(K) - ms_per_step(10 K) is the timed region's "
+                                           "fixed cost (first launch in, last synchronisation out) spread over K steps, not kernel time"},
         "hip_force_dev_kernarg": os.environ.get("HIP_FORCE_DEV_KERNARG"),
         "code_hash": loaded_code_hash(),
         "parity_check": parity,

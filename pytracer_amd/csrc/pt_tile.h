@@ -970,8 +970,11 @@ PT_DEV void sphere_roots1(const PtKArgs &a, int slot, bool active, double tmin, 
 //   gathers from there instead of through the vector memory path (C2: 14.4 -> 13.9 us per frame).
 // NPX = 4: 16x16 tiles, four pixels per lane.  NPX = 2: 16x8 tiles, two pixels per lane (the upper two quadrants only) --
 //   twice the waves with half the pixels each, for frames whose 16x16 tiles would not fill the chip.
+#ifndef PT_TILE4_WAVES
+#define PT_TILE4_WAVES 4  // waves per SIMD the register allocation aims at (5 / 6 measured: profiles/DROPPED_VARIANTS.md)
+#endif
 template <int RENDERER, bool SLDS = false, int NPX = 4>
-__global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8))) void pt_tile4_kernel(const PtKArgs a) {
+__global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_TILE4_WAVES, 8))) void pt_tile4_kernel(const PtKArgs a) {
   static_assert(NPX == 2 || NPX == 4, "two or four pixels per lane");
   constexpr int TH = NPX == 4 ? 16 : 8;  // tile height
   constexpr bool ANYHIT = RENDERER == PT_RENDERER_ONOFF;
