@@ -354,6 +354,10 @@ def extra_rows(device: int):
                 "valu_issue_utilisation": pr["frac"] if pr else None, "fp64_pipe_frac": pr["fp64_pipe_frac"] if pr else None,
                 "frac_counter_active_inst_valu_x4": pr.get("frac_counter_active_inst_valu_x4") if pr else None,
                 "unclassed_share": pr["unclassed_share"] if pr else None,
+                # (tools/isa_mix.py on the same file: the disassembly priced per instruction, block counts bounded by the counters)
+                "valu_issue_utilisation_bounds_from_disassembly": (
+                    [b / simd_cycles for b in pmc["static_mix"]["valu_issue_cycles_bounds"]]
+                    if pmc.get("static_mix", {}).get("valu_issue_cycles_bounds") and pmc["static_mix"].get("code_hash") == loaded_code_hash() else None),
                 "code_hash": pmc.get("code_hash"), "kernel_resources": pmc.get("kernel_resources"),
                 "source": pmc.get("source")}
     # C5: HBM bytes per frame of its two kernels (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 passes, medians

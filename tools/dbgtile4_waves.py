@@ -39,6 +39,25 @@ wg = tot.reshape(-1, 4)
 print(f"kernel {st.kernel_ms * 1e3:.1f} us (debug build), {n} waves, {live.sum()} with a tile")
 print(f"wave cycles: mean {tot[live].mean():.0f}  p50 {np.median(tot[live]):.0f}  p90 {np.percentile(tot[live], 90):.0f}  p99 {np.percentile(tot[live], 99):.0f}  max {tot.max()}")
 print(f"  of which per tile (prologue, cone, cull, dome check): mean {per_tile[live].mean():.0f}")
+# the histogram of wave cycles, and per tile ROW of the frame the longest wave: where the heavy tiles are
+edges = np.arange(0, int(tot.max()) + 2048, 2048)
+hist, _ = np.histogram(tot[live], bins=edges)
+print("wave-cycle histogram (2 048-cycle bins: waves | share of the waves' summed cycles):")
+for k, h in enumerate(hist):
+    if h:
+        sel = live & (tot >= edges[k]) & (tot < edges[k + 1])
+        print(f"  {edges[k]:6d} .. {edges[k + 1]:6d}  {h:5d}  {'#' * int(round(60 * h / hist.max()))}  {100 * tot[sel].sum() / tot[live].sum():4.1f} %")
+rows = {}
+for i in range(n // 4):
+    for wv in range(4):
+        t = int(wg[i, wv])
+        if t:
+            ty = i // 40 * 2 + (wv >> 1)
+            rows.setdefault(ty, []).append(t)
+print("per tile row (16 pixel rows each, top = 0): waves, mean, max cycles")
+for ty in sorted(rows):
+    r = np.array(rows[ty])
+    print(f"  row {ty:2d}: {len(r):3d} waves  mean {r.mean():7.0f}  max {r.max():6d}")
 wmax = wg.max(axis=1)
 wmean = wg.sum(axis=1) / np.maximum(1, (wg > 0).sum(axis=1))
 print(f"workgroups: max of the four waves: mean {wmax.mean():.0f}  max {wmax.max()};  mean of the four: max over workgroups {wmean.max():.0f}")

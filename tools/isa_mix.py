@@ -44,6 +44,7 @@ TABLE = [  # (regex on the mnemonic, class, cycles or (low, high), rocprofv3 cla
     (r"v_fma_f64|v_fmac_f64", "fma_f64", 4, "SQ_INSTS_VALU_FMA_F64"),
     (r"v_(rcp|rsq|sqrt)_f64", "trans_f64", 16, "SQ_INSTS_VALU_TRANS_F64"),
     (r"v_div_(scale|fmas|fixup)_f64|v_ldexp_f64|v_(floor|trunc|ceil|rndne|fract)_f64|v_frexp_(mant|exp_i32)_f64|v_(min|max)_f64", "misc_f64", 4, None),
+    (r"v_trig_preop_f64", "trig_preop_f64", (4, 16), None),  # (ocml's large-argument reduction; not measured)
     (r"v_cmp[x]?_class_f64", "cmp", 4, None),
     # (integer compares and 32-bit bit operations land in SQ_INSTS_VALU_INT32: calibrated -- of nine candidate mappings of that
     #  counter only "add/sub/mul + bit operations + 32-bit integer compares" leaves the programme feasible on pt_tile4_kernel)

@@ -42,6 +42,9 @@ while IFS='|' read -r name cfg kern json what; do
   rocprofv3 --pmc $P3 --output-format csv -d $OUT/pmc_${name}_3 -- $KB > $OUT/pmc_${name}_3.log 2>&1
   ( cd $ROOT && python3 tools/pmc_summary.py $OUT/pmc_$name $OUT/pmc_${name}_2 $OUT/pmc_${name}_3 --kernel "$kern" --json $OUT/$json \
       --source "rocprofv3 --pmc (three passes) on '$KB' ($what); medians over the launches; tools/prof_bench.sh $TAG" > /dev/null ) || echo "no summary for $name"
+  # the kernel's disassembly priced per instruction, block counts bounded by these counters (tools/isa_mix.py)
+  ( cd $ROOT && K=$(python3 -c "import json,sys; print(json.load(open('$OUT/$json'))['kernel'].replace('void ','').split('(')[0])") && \
+      timeout -k 5 300 python3 tools/isa_mix.py "$K" --pmc $OUT/$json --update > $OUT/isa_mix_$name.txt 2>&1 ) || echo "no disassembly bounds for $name"
 done <<'CFG'
 c3|c3|pt_path_regions_kernel|pmc_c3_second_pass.json|C3, PT_PCG_PIXEL
 c3s|c3:sample|pt_path_regions_kernel|pmc_c3_second_pass_sample.json|C3, PT_PCG_SAMPLE
