@@ -36,6 +36,30 @@ PT_DEV uint64_t pcg_advance(uint64_t state, uint64_t inc, unsigned delta) {
   }
   return acc_mul * state + acc_add;
 }
+// The same jump with the increment factored out: state -> A * state + inc * G for ANY generator of the family, so the two
+// coefficients of a distance that is known in advance are computed once (the 2 N scatter draws of N children beyond
+// max_depth, render.py:100-101 / 128: path_trace, path_tree; the leaf rounds' hypotheses: path_tree's table).
+struct PcgJump {
+  uint64_t A, G;
+};
+PT_DEV PcgJump pcg_jump_coeffs(unsigned delta) {
+  uint64_t acc_mul = 1ULL, acc_g = 0ULL, cur_mul = 6364136223846793005ULL, cur_g = 1ULL;
+  while (delta) {
+    if (delta & 1u) {
+      acc_mul *= cur_mul;
+      acc_g = acc_g * cur_mul + cur_g;
+    }
+    cur_g = (cur_mul + 1ULL) * cur_g;
+    cur_mul *= cur_mul;
+    delta >>= 1;
+  }
+  PcgJump j = {acc_mul, acc_g};
+  return j;
+}
+PT_DEV void pcg_jump(Pcg &p, PcgJump j, unsigned delta) {  // == `delta` calls of pcg_next whose outputs nobody reads
+  p.state = j.A * p.state + p.inc * j.G;
+  p.n += delta;
+}
 // ... with a 64-bit distance: where sample k of pixel i starts in ONE sequential stream that every sample draws the same
 // count from (PT_PCG_SEQ: ImageTracer.pcg, two jitter numbers per sample, imagetracer.py:84-101) -- a 4K frame at 256
 // samples per pixel is 4.2e9 draws in.

@@ -302,6 +302,7 @@ PT_DEV void path_trace(const PtKArgs &a) {
   }
   nsamp = S > 0 ? S * S : 1;
   const double invN = 1.0 / (double)N;
+  const PcgJump j2n = pcg_jump_coeffs(2u * (unsigned)N);  // (wave-uniform: the scatter draws of N children beyond max_depth)
   const int lane = threadIdx.x & 63;
   const int mbase = (threadIdx.x >> 6) * npass;
   const int regions_x = (W + PT_REGION - 1) / PT_REGION;
@@ -438,17 +439,12 @@ PT_DEV void path_trace(const PtKArgs &a) {
       // (consuming its draws: 2 for a diffuse BRDF, none for a mirror) and each child returns black at
       // render.py:100-101 without a world query.  No ray, no frame, no geometry is needed: advance the
       // generator and accumulate hit_color * 0 exactly as render.py:135-139 does.
+      // (Round 5: the N x 2 draws are ONE jump of the generator -- nobody reads their outputs --, and the N additions of
+      //  hit_color * 0 are one: 0 + z + z + ... = 0 + z for z = +-0 and for a NaN, whatever N >= 1.  Exact, and a fifth of
+      //  what a leaf hit used to cost: 2 N dependent 64-bit multiply-adds and 3 N dependent additions.)
       const bool diffuse = ax->brdf_kind == PT_BRDF_DIFFUSE;
-      V3 fc = {0.0, 0.0, 0.0};
-      for (int i = 0; i < N; ++i) {
-        if (diffuse) {
-          pcg_next(pcg);
-          pcg_next(pcg);
-        }
-        fc.x = fc.x + hc.x * 0.0;
-        fc.y = fc.y + hc.y * 0.0;
-        fc.z = fc.z + hc.z * 0.0;
-      }
+      if (diffuse) pcg_jump(pcg, j2n, 2u * (unsigned)N);
+      const V3 fc = {0.0 + hc.x * 0.0, 0.0 + hc.y * 0.0, 0.0 + hc.z * 0.0};
       ret.x = em.x + fc.x * invN;
       ret.y = em.y + fc.y * invN;
       ret.z = em.z + fc.z * invN;

@@ -46,6 +46,8 @@
   X(spec_draws, "PTRACE_SPEC_DRAWS", -1)          /* PT_PCG_PIXEL: draws assumed per sample of an unknown pixel */          \
   X(tree_uniform_max, "PTRACE_TREE_UNIFORM_MAX", 0)                                                                         \
   X(tree_fuse, "PTRACE_TREE_FUSE", 1)                                                                                       \
+  X(tree_scene_lds, "PTRACE_TREE_SCENE_LDS", 1)   /* tree kernel (small worlds): the shapes' records staged in LDS */       \
+  X(tree_jump, "PTRACE_TREE_JUMP", 1)             /* tree kernel: leaf rounds' state jumps from a table in LDS */           \
   X(trace_unit, "PTRACE_TRACE_UNIT", 0)                                                                                     \
   X(pixel_dome, "PTRACE_PIXEL_DOME", 1)           /* first pass: per-pixel dome classification */                           \
   X(hier_min, "PTRACE_HIER_MIN", 256)             /* shapes above which tiles cull cell lists (< 0: never) */               \
@@ -111,6 +113,7 @@ enum PtSecondPass {  // the path tracer's second-pass kernel
   PT_SECOND_REGIONS_HBM,              // <false, false, 0>
   PT_SECOND_TREE_LEAN,                // pt_path_tree_kernel<true>
   PT_SECOND_TREE,                     // pt_path_tree_kernel<false>
+  PT_SECOND_TREE_LEAN_SCENE,          // pt_path_tree_kernel<true, true>: the shapes' records staged in LDS
 };
 enum PtAltPass {  // the one-queue alternative enqueued behind the tree kernel (PT_Q_CHOICE)
   PT_ALT_NONE = 0,
@@ -156,6 +159,7 @@ struct PtPlan {
   int frame_doubles = 6;
   int diag_lds = -1, grid_occ_lds = -1, scene_lds = -1;  // offsets as the kernels take them (PtKArgs)
   int q_diag_lds = -1;
+  int tree_jump_lds = -1;   // tree kernel: the leaf rounds' jump table (8-byte words), -1 = none
   int wg_per_cu = 0;
   int p_max_path = 0, s_min_path = 0, q_p_max_path = 48, q_s_min_path = 16;
   size_t ws_bytes = 0;    // frame stack in HBM (0: none needed)
@@ -429,6 +433,23 @@ static inline void pt_make_plan(const PtSceneFacts &s, const pt_camera *cam, con
     if (pl.tree) {
       pl.kernel = PT_KERNEL_PATH_TREE;
       pl.second = small_world ? PT_SECOND_TREE_LEAN : PT_SECOND_TREE;
+      if (t.tree_jump != 0 && p->num_of_rays <= 63) {  // the leaf rounds' jump coefficients: 2 x 4 x 64 pairs of 64-bit words
+        const size_t at = (pl.lds_main + 7) / 8 * 8;
+        if (at + 8192 <= PT_LDS_BUDGET / 2) {
+          pl.tree_jump_lds = (int)(at / 8);
+          pl.lds_main = at + 8192;
+        }
+      }
+      // small worlds: the shapes' records ride in LDS for shading (a round is one dependent chain: every trip to L2 is in it)
+      if (small_world && t.tree_scene_lds != 0) {
+        const size_t at = (pl.lds_main + 255) / 256 * 256;
+        const size_t scene_bytes = (size_t)s.n_shapes * (PT_PLAN_REC_BYTES + PT_PLAN_AUX_BYTES);
+        if (scene_bytes <= 32 * 1024 && at + scene_bytes <= PT_LDS_BUDGET / 2) {
+          pl.scene_lds = (int)(at / 8);
+          pl.lds_main = at + scene_bytes;
+          pl.second = PT_SECOND_TREE_LEAN_SCENE;
+        }
+      }
     } else if (pl.lds_frames && pl.scene_lds >= 0 && small_world) {
       pl.second = PT_SECOND_REGIONS_LDS_SCENE_LEAN;
     } else if (pl.lds_frames && pl.scene_lds >= 0) {
@@ -482,9 +503,9 @@ static inline const char *pt_plan_kernel_name(const PtPlan &pl, int renderer, in
     else if (pl.tile4)
       snprintf(buf, n, "pt_tile4_kernel<%s, %s, %d>", r, pl.t4lds ? "LDS" : "noLDS", pl.npx);
     else if (pl.path_tiled) {
-      static const char *S2[8] = {"", "pt_path_regions_kernel<LDS, SCENE, LEAN>", "pt_path_regions_kernel<LDS, SCENE>",
+      static const char *S2[9] = {"", "pt_path_regions_kernel<LDS, SCENE, LEAN>", "pt_path_regions_kernel<LDS, SCENE>",
                                   "pt_path_regions_kernel<LDS, NOGRID>", "pt_path_regions_kernel<LDS>", "pt_path_regions_kernel<HBM>",
-                                  "pt_path_tree_kernel<LEAN>", "pt_path_tree_kernel"};
+                                  "pt_path_tree_kernel<LEAN>", "pt_path_tree_kernel", "pt_path_tree_kernel<LEAN, SCENE>"};
       snprintf(buf, n, "%s", S2[pl.second]);
     } else if (pl.tile)
       snprintf(buf, n, "pt_tile_kernel<%s%s>", r, TM[pl.tile_mode]);

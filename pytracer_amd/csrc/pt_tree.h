@@ -41,7 +41,10 @@ PT_DEV V3 rl_v3(V3 v, int lane) {
   return r;
 }
 
-template <bool SMALL>
+// SLDS (round 5): the shapes' records (128 B + 256 B each) staged in LDS by the workgroup, as the second pass by regions does:
+// shading gathers ~25 values of the hit shape per lane through dependent loads (needs_uv -> pigments -> matrices), and a
+// round of this kernel is one dependent chain: every trip to L2 is in it.
+template <bool SMALL, bool SLDS = false>
 PT_DEV void path_tree(const PtKArgs &a) {
   int S, nsamp, N, W, rows_local, npass, D, rr, diag_lds, pcg_mode, frames_lds;
   bool ortho;
@@ -72,6 +75,47 @@ PT_DEV void path_tree(const PtKArgs &a) {
     for (int k = threadIdx.x; k < a.n_diag * 8; k += PT_BLOCK) pt_lds_masks[diag_lds + k] = src[k];
     __syncthreads();
   }
+  // Leaf rounds start every lane a FIXED number of draws ahead of the sequential state -- row * c0 + column * 2N for the
+  // hypothesis lanes, N * c0 + 2N * b for the lanes that trace the parent's next child -- so the jump's coefficients
+  // (state' = A * state + inc * G, both powers of the multiplier) are tabulated once per workgroup for the four values c0
+  // can take, instead of ~8 rounds of 64-bit multiplications by repeated squaring in every lane and round.
+  const int jump_lds = cold_args(a)->tree_jump_lds;
+  if (jump_lds >= 0) {
+    const int Nn = cold_args(a)->N;
+    for (int e = threadIdx.x; e < 2 * 4 * 64; e += PT_BLOCK) {
+      const int which = e >> 8, c0e = (e >> 6) & 3, idx = e & 63;
+      unsigned delta;
+      if (which == 0) {
+        int row = 0;
+        while ((row + 1) * (row + 2) / 2 <= idx) ++row;
+        delta = (unsigned)row * (unsigned)c0e + (unsigned)(idx - row * (row + 1) / 2) * 2u * (unsigned)Nn;
+      } else {
+        delta = (unsigned)Nn * (unsigned)c0e + 2u * (unsigned)Nn * (unsigned)idx;
+      }
+      uint64_t acc_mul = 1ULL, acc_g = 0ULL, cur_mul = 6364136223846793005ULL, cur_g = 1ULL;
+      while (delta) {  // (pcg_advance with the increment factored out)
+        if (delta & 1u) {
+          acc_mul *= cur_mul;
+          acc_g = acc_g * cur_mul + cur_g;
+        }
+        cur_g = (cur_mul + 1ULL) * cur_g;
+        cur_mul *= cur_mul;
+        delta >>= 1;
+      }
+      pt_lds_masks[jump_lds + 2 * e] = acc_mul;
+      pt_lds_masks[jump_lds + 2 * e + 1] = acc_g;
+    }
+    __syncthreads();
+  }
+  int scene_lds = 0;
+  if (SLDS) {  // recs[] then aux[] (8-byte words)
+    scene_lds = cold_args(a)->scene_lds;
+    const unsigned long long *src = (const unsigned long long *)a.recs;
+    for (int k = threadIdx.x; k < a.n_shapes * 16; k += PT_BLOCK) pt_lds_masks[scene_lds + k] = src[k];
+    src = (const unsigned long long *)a.aux;
+    for (int k = threadIdx.x; k < a.n_shapes * 32; k += PT_BLOCK) pt_lds_masks[scene_lds + a.n_shapes * 16 + k] = src[k];
+    __syncthreads();
+  }
   {  // the grid's occupancy bits into LDS: the cell walk of world_query_lanes reads one per step
     pt_kargs c = cold_args(a);
     const int occ_lds = c->grid_occ_lds;
@@ -84,6 +128,7 @@ PT_DEV void path_tree(const PtKArgs &a) {
   }
   nsamp = S > 0 ? S * S : 1;
   const double invN = 1.0 / (double)N;
+  const PcgJump j2n = pcg_jump_coeffs(2u * (unsigned)N);  // (wave-uniform: the scatter draws of N children beyond max_depth)
   const int lane = threadIdx.x & 63;
   const int mbase = (threadIdx.x >> 6) * npass;
   const int regions_x = (W + PT_REGION - 1) / PT_REGION;
@@ -120,15 +165,7 @@ PT_DEV void path_tree(const PtKArgs &a) {
   ray.o = {0.0, 0.0, 0.0};
   ray.d = {1.0, 0.0, 0.0};
   ray.tmin = 1e-5;
-  auto shade_ray = [&](int hit, double best_t, int depth) {
-    o_term = true;
-    if (hit < 0) {  // render.py:103-105
-      pt_kargs c = cold_args(a);
-      o_ret = {c->bg[0], c->bg[1], c->bg[2]};
-      return;
-    }
-    const PtShapeRec *rec = a.recs + hit;
-    const PtShapeAux *ax = cold_args(a)->aux + hit;
+  auto shade_hit = [&](auto rec, auto ax, double best_t, int depth) {
     Hit h;
     h.u = 0.0;
     h.v = 0.0;
@@ -157,17 +194,10 @@ PT_DEV void path_tree(const PtKArgs &a) {
       return;
     }
     if (depth + 1 > D) {  // every child is beyond max_depth: its scatter draws are consumed, it returns black (render.py:100-101)
+      // (one jump of 2 N draws, one addition of hit_color * 0: see path_trace)
       const bool diffuse = ax->brdf_kind == PT_BRDF_DIFFUSE;
-      V3 fc = {0.0, 0.0, 0.0};
-      for (int i = 0; i < N; ++i) {
-        if (diffuse) {
-          pcg_next(pcg);
-          pcg_next(pcg);
-        }
-        fc.x = fc.x + hc.x * 0.0;
-        fc.y = fc.y + hc.y * 0.0;
-        fc.z = fc.z + hc.z * 0.0;
-      }
+      if (diffuse) pcg_jump(pcg, j2n, 2u * (unsigned)N);
+      const V3 fc = {0.0 + hc.x * 0.0, 0.0 + hc.y * 0.0, 0.0 + hc.z * 0.0};
       o_ret = {em.x + fc.x * invN, em.y + fc.y * invN, em.z + fc.z * invN};
       return;
     }
@@ -178,6 +208,19 @@ PT_DEV void path_tree(const PtKArgs &a) {
     o_wp = h.wp;
     o_n = h.n;
     o_brdf = ax->brdf_kind;
+  };
+  auto shade_ray = [&](int hit, double best_t, int depth) {
+    o_term = true;
+    if (hit < 0) {  // render.py:103-105
+      pt_kargs c = cold_args(a);
+      o_ret = {c->bg[0], c->bg[1], c->bg[2]};
+      return;
+    }
+    if constexpr (SLDS)
+      shade_hit((pt_lds_rec)(const void *)(pt_lds_f64 + scene_lds) + hit,
+                (pt_lds_aux)(const void *)(pt_lds_f64 + scene_lds + a.n_shapes * 16) + hit, best_t, depth);
+    else
+      shade_hit(a.recs + hit, cold_args(a)->aux + hit, best_t, depth);
   };
 
 #ifdef PT_DEBUG_TIME
@@ -379,7 +422,13 @@ PT_DEV void path_tree(const PtKArgs &a) {
         o_ret = o_hc = o_em = o_wp = {0.0, 0.0, 0.0};
         o_n = {0.0, 0.0, 1.0};
         o_brdf = 0;
-        pcg.state = act ? pcg_advance(gstate, ginc, ahead) : gstate;
+        if (leaf && jump_lds >= 0 && c0 < 4u) {
+          const int e = sib ? 256 + (int)c0 * 64 + (bmin + lane - leaf_lanes) : (int)c0 * 64 + lane;
+          const uint64_t A = pt_lds_masks[jump_lds + 2 * (act ? e : 0)], G = pt_lds_masks[jump_lds + 2 * (act ? e : 0) + 1];
+          pcg.state = act ? A * gstate + ginc * G : gstate;
+        } else {
+          pcg.state = act ? pcg_advance(gstate, ginc, ahead) : gstate;
+        }
         pcg.inc = ginc;
         pcg.n = 0;
         const unsigned long long st_start = pcg.state;
@@ -425,10 +474,46 @@ PT_DEV void path_tree(const PtKArgs &a) {
             pushed = true;
           }
         };
-        for (int r = 0; r < nrows && !pushed; ++r) {
-          const unsigned long long m = __ballot(act && row == r && st_start == expect);
-          if (!m) break;  // nobody traced child r from the right state: next round
-          commit_child(__ffsll((long long)m) - 1);
+        if (leaf) {
+          // A leaf family commits along ONE path through the triangle of hypotheses: child r was traced by lane (r, b) from
+          // the state r * c0 + b * 2N draws on, and the state it ends in is the start state of (r + 1, b) if it drew c0
+          // numbers, of (r + 1, b + 1) if it drew c0 + 2N (a diffuse hit that survives roulette), of nobody otherwise (a
+          // miss draws c0 - 1: the chain resumes next round).  So every lane knows its successor from its own draw count
+          // (no states compared, no ballots), the wave follows the path with one lane read per child, and the products
+          // hit_color * value (render.py:137) are formed by all lanes at once and only ADDED in child order.  (Leaf
+          // children never need children of their own: render.py:100-101.)  Round 5: the commit was 5 200 of a round's
+          // 32 000 cycles as a loop of ballot, find-first, ten lane reads and three dependent multiply-adds per child.
+          int nxt = -1;  // successor hypothesis lane; -2: the family ends with this child; -1: no lane traced the next child from here
+          {
+            const unsigned extra = pcg.n - c0;
+            if (act && !sib && (extra == 0u || extra == 2u * (unsigned)N)) {
+              const int r2 = tri_row + 1, b2 = tri_col + (extra ? 1 : 0);
+              nxt = r2 < nrows ? r2 * (r2 + 1) / 2 + b2 : -2;
+            }
+          }
+          const V3 prod = {t_hc.x * o_ret.x, t_hc.y * o_ret.y, t_hc.z * o_ret.z};
+          int cur = 0, k = 0;  // (wave-uniform) the lane of the child being committed; children committed
+          for (;;) {
+            const V3 pv = rl_v3(prod, cur);
+            t_cum.x = t_cum.x + pv.x;
+            t_cum.y = t_cum.y + pv.y;
+            t_cum.z = t_cum.z + pv.z;
+            ++k;
+            const int nx = __builtin_amdgcn_readlane(nxt, cur);
+            if (nx < 0) break;
+            cur = nx;
+          }
+          prays += (unsigned long long)k;
+          t_next += k;
+          expect = rl_u64(pcg.state, cur);
+          cpred = (unsigned)__builtin_amdgcn_readlane((int)pcg.n, cur);
+          fam_draws = (unsigned)__builtin_amdgcn_readlane((int)ahead, cur) + cpred;
+        } else {
+          for (int r = 0; r < nrows && !pushed; ++r) {
+            const unsigned long long m = __ballot(act && row == r && st_start == expect);
+            if (!m) break;  // nobody traced child r from the right state: next round
+            commit_child(__ffsll((long long)m) - 1);
+          }
         }
         if (leaf && t_next == N && nrows == N && fam_draws >= (unsigned)N * c0)
           b_last = (int)((fam_draws - (unsigned)N * c0) / (2u * (unsigned)N));
@@ -486,7 +571,7 @@ PT_DEV void path_tree(const PtKArgs &a) {
 #ifndef PT_TREE_WAVES
 #define PT_TREE_WAVES 2
 #endif
-template <bool SMALL = false>
+template <bool SMALL = false, bool SLDS = false>
 __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_TREE_WAVES, 8))) void pt_path_tree_kernel(const PtKArgs a) {
-  path_tree<SMALL>(a);
+  path_tree<SMALL, SLDS>(a);
 }

@@ -1186,6 +1186,7 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
     a.spec_draws = pl.spec_draws;
     a.tree_uniform_max = (int)tn.tree_uniform_max;  // (measured on C3, N = 10: the uniform loop 2.48 ms, candidate lists 1.92)
     a.tree_fuse = (int)tn.tree_fuse;
+    a.tree_jump_lds = pl.tree_jump_lds;
     a.dbg_trace_unit = (int)tn.trace_unit;
     // The sphere the camera is deepest inside (object-space |o'|^2 - 1 most negative, and below -0.5): the
     // first pass settles, per pixel, what can only hit that sphere (pt_tile_kernel re-checks every condition
@@ -1319,6 +1320,7 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
   } while (0)
       switch (pl.second) {
         case PT_SECOND_TREE_LEAN: PT_SECOND((pt_path_tree_kernel<true>)); break;
+        case PT_SECOND_TREE_LEAN_SCENE: PT_SECOND((pt_path_tree_kernel<true, true>)); break;
         case PT_SECOND_TREE: PT_SECOND((pt_path_tree_kernel<false>)); break;
         case PT_SECOND_REGIONS_LDS_SCENE_LEAN: PT_SECOND((pt_path_regions_kernel<true, true, 1>)); break;
         case PT_SECOND_REGIONS_LDS_SCENE: PT_SECOND((pt_path_regions_kernel<true, true>)); break;

@@ -73,9 +73,11 @@ def test_c3_two_passes_frame_stack_and_scene_in_lds():
 
 def test_cli_defaults_enqueue_the_tree_kernel_and_the_one_queue_alternative():
     p = plan(world(32), 1280, 720, **CLI)
-    assert p.kernels == ["pt_tile_kernel<PATHTRACER>", "pt_path_tree_kernel<LEAN>", "pt_path_flagged_kernel<LEAN, LDS>"]
+    assert p.kernels == ["pt_tile_kernel<PATHTRACER>", "pt_path_tree_kernel<LEAN, SCENE>", "pt_path_flagged_kernel<LEAN, LDS>"]
     assert p.kernel == abi.KERNEL_PATH_TREE and p.frame_doubles == 20 and p.frame_stack == "LDS" and p.alt_frame_stack == "LDS"
-    assert p.lds_main == 32 + 3 * 20 * 4 * 8 + 32 * 64  # per WAVE and node, not per lane; + the 32 scale+translate records
+    # node records per WAVE and depth (not per lane) + the 32 scale+translate records, then the leaf rounds' jump table
+    # (2 x 4 x 64 pairs of 64-bit words), then -- at a 256-byte boundary -- the shapes' records for shading
+    assert p.lds_main == (32 + 3 * 20 * 4 * 8 + 32 * 64 + 8192 + 255) // 256 * 256 + 32 * 384
     assert p.lds_alt == 3 * 20 * 256 * 8 + 32 * 64 and p.grid_alt == 256 and p.workspace_bytes == 0  # 120 KB of frames: one workgroup per CU
     assert 250_000 < p.q_min_flagged < 400_000  # C3's 29 k flagged pixels: tree; C2 + plane's 490 k: one queue
     deep = plan(world(32), 1280, 720, **dict(CLI, num_of_rays=3, max_depth=5))
@@ -105,7 +107,7 @@ def test_c1_demo_scene():
     p = device.plan(flat, flatten.flatten_camera(camera), abi.make_params(160, 120, abi.RENDERER_ONOFF))
     assert p.kernels == ["pt_simple_kernel<ONOFF, HOIST>"]  # three shapes: below the tile kernels' four
     q = device.plan(flat, flatten.flatten_camera(camera), abi.make_params(1280, 960, **CLI))
-    assert q.kernels == ["pt_tile_kernel<PATHTRACER>", "pt_path_tree_kernel<LEAN>", "pt_path_flagged_kernel<LEAN, LDS>"]
+    assert q.kernels == ["pt_tile_kernel<PATHTRACER>", "pt_path_tree_kernel<LEAN, SCENE>", "pt_path_flagged_kernel<LEAN, LDS>"]
 
 
 # ---- the families' borders --------------------------------------------------------------------------------------------------
@@ -143,7 +145,8 @@ def test_frame_stack_leaves_the_lds_when_it_no_longer_fits():
     assert deep.frame_stack == "HBM" and deep.main_kernel == "pt_path_regions_kernel<HBM>"
     assert deep.workspace_bytes == 14 * 6 * 8 * deep.grid * 256
     # the tree kernel's per-wave node stack: LDS while D x 20 x 4 x 8 fits half the budget, else back to regions
-    assert plan(w, 640, 360, **dict(CLI, max_depth=100)).main_kernel == "pt_path_tree_kernel<LEAN>"
+    assert plan(w, 640, 360, **dict(CLI, max_depth=100)).main_kernel == "pt_path_tree_kernel<LEAN>"  # (64 KB of node records: no room left for the scene)
+    assert plan(w, 640, 360, **dict(CLI, max_depth=40)).main_kernel == "pt_path_tree_kernel<LEAN, SCENE>"
     assert plan(w, 640, 360, **dict(CLI, max_depth=200)).main_kernel.startswith("pt_path_regions_kernel")
     # frames beyond 2.1 M pixels never take the tree kernel
     assert plan(w, 3840, 2160, **CLI).main_kernel.startswith("pt_path_regions_kernel")
@@ -199,6 +202,12 @@ def test_switches_select_the_documented_variants(tuning):
     tuning("hier_min", 256)
     tuning("small_query", 0)
     assert plan(world(32), 1280, 720, **C3).main_kernel == "pt_path_regions_kernel<LDS, SCENE>"
+    assert plan(world(32), 1280, 720, **CLI).main_kernel == "pt_path_tree_kernel"
+    tuning("small_query", 1)
+    tuning("tree_scene_lds", 0)
+    tuning("tree_jump", 0)
+    lean = plan(world(32), 1280, 720, **CLI)
+    assert lean.main_kernel == "pt_path_tree_kernel<LEAN>" and lean.lds_main == 32 + 3 * 20 * 4 * 8 + 32 * 64
     with pytest.raises(Exception, match="unknown tuning switch"):
         device.set_tuning("no_such_switch", 1)
 
