@@ -88,8 +88,17 @@ PT_DEV void pcg_seed_pixel(Pcg &p, int pcg_mode, uint64_t s0, uint64_t q0, unsig
     p.state = pcg_advance64(p.state, p.inc, 2ULL * (unsigned long long)nsamp * gpix);
   }
 }
-// pcg.py:60-62: random() / 0xFFFFFFFF, an fp64 division (inclusive 1.0)
-PT_DEV double pcg_float(Pcg &p) { return (double)pcg_next(p) / 4294967295.0; }
+// pcg.py:60-62: random() / 0xFFFFFFFF, an fp64 division (inclusive 1.0) -- of a 32-bit integer by a CONSTANT: the quotient is
+// formed from the constant's correctly rounded reciprocal and one correction step (a multiplication and two explicit fused
+// multiply-adds -- not a contraction: the expression is not the reference's, its VALUE is, for every one of the 2^32 possible
+// inputs: tests/proofs/pcg_float_div.c checks them all) instead of the dozen dependent instructions of a general division.
+PT_DEV double pcg_float(Pcg &p) {
+  const double x = (double)pcg_next(p);
+  const double r = 0x1.00000001p-32;  // RN(1 / 4294967295.0)
+  const double q0 = x * r;
+  const double e = __builtin_fma(-4294967295.0, q0, x);
+  return __builtin_fma(e, r, q0);
+}
 
 // ---- transformations.py:58-86 ----------------------------------------------------------------------
 template <typename P>
