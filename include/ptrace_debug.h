@@ -61,7 +61,7 @@ typedef struct pt_plan_info {
   char pre_kernel[48];       /* "pt_cell_kernel" for worlds of more than 256 shapes, else "" */
   char first_kernel[64];     /* path tracer: the first pass */
   char main_kernel[64];      /* the render kernel proper / the path tracer's second pass */
-  char alt_kernel[64];       /* num_of_rays > 1: the one-queue kernel enqueued behind the tree kernel (the device picks) */
+  char alt_kernel[64];       /* num_of_rays > 1: the one-queue kernel enqueued in front of the tree kernel (the device picks; pixels over alt_budget go to the tree kernel) */
   int32_t grid, grid_first, grid_alt;         /* workgroups of 256 threads */
   int32_t grid4_x, grid4_y, npx;              /* pt_tile4_kernel: its 2-D grid and pixels per lane */
   int64_t lds_first, lds_main, lds_alt;       /* dynamic LDS per workgroup, bytes */
@@ -73,7 +73,8 @@ typedef struct pt_plan_info {
   int32_t wg_per_cu, block_h, hier, ortho, hoist, tile4_lds;
   int32_t n_spheres, n_diag, has_grid, ball_levels;  /* the scene facts the plan was made from */
   int32_t units_need, nregions, min_rounds, spec_draws;
-  int32_t _reserved[8];
+  int32_t alt_budget;        /* rays after which the one-queue kernel hands a pixel over to the tree kernel behind it (0: never) */
+  int32_t _reserved[7];
 } pt_plan_info;
 int pt_debug_plan(const pt_scene_desc *desc, const pt_camera *cam, const pt_params *params, int n_cu, int dome_shortcut,
                   pt_plan_info *out);

@@ -600,6 +600,11 @@ static v3 trace_pixel(rctx_t *ctx, const pt_camera *cam, int col, int row, pcg_t
   return radiance(ctx, &ray);
 }
 
+/* diagnostics (tools/ray_histogram.py): when set, pto_render also writes every pixel's ray count (PT_PCG_PIXEL / SAMPLE
+ * frames, local row-major like `out`) */
+static uint32_t *g_ray_image = 0;
+void pto_set_ray_image(uint32_t *buf) { g_ray_image = buf; }
+
 /* imagetracer.py:60-110.  out holds this rank's rows compactly. */
 int pto_render(const pt_scene_desc *s, const pt_camera *cam, const pt_params *p, void *out,
                size_t out_bytes, int n_threads, uint64_t *n_rays_out) {
@@ -647,6 +652,7 @@ int pto_render(const pt_scene_desc *s, const pt_camera *cam, const pt_params *p,
         rctx_t ctx = {s, p, &pcg, 0};
         v3 c = trace_pixel(&ctx, cam, col, row, &pcg, pix);
         store_px(out, p->out_format, (size_t)lr * W + col, c);
+        if (g_ray_image) g_ray_image[(size_t)lr * W + col] = (uint32_t)ctx.n_rays;
         total_rays += ctx.n_rays;
       }
     }

@@ -163,7 +163,8 @@ class PlanInfo(C.Structure):
         ("nregions", C.c_int32),
         ("min_rounds", C.c_int32),
         ("spec_draws", C.c_int32),
-        ("_reserved", C.c_int32 * 8),
+        ("alt_budget", C.c_int32),
+        ("_reserved", C.c_int32 * 7),
     ]
 
     STACK_HOMES = {0: None, 1: "LDS", 2: "HBM", 3: "SPLIT"}

@@ -82,8 +82,16 @@ PT_DEV pt_kargs cold_args(const PtKArgs &a) {
 // frame's queue block, written by pt_unit_scatter from F (the flagged pixels the first pass counted), says which of
 // them works -- 0: pt_path_tree_kernel (one pixel per wave: few flagged pixels, the frame waits for its deepest tree),
 // 1: pt_path_kernel<., true> (a lane per flagged pixel, refilled from one queue: frames full of flagged pixels are
-// throughput-bound).  The other one returns at once.
+// throughput-bound).  The other one returns at once -- unless the one-queue kernel hands pixels over (round 5): a lane per
+// pixel walks a pixel's rays one after the other, so a frame would wait for its heaviest pixels' chains (1 111 rays at the
+// CLI's N = 10, D = 3) while the lanes that have finished idle.  Such a lane writes its pixel's state into a record and
+// appends the pixel to the unit list (PT_Q_HEAVY units, from unit 0: pt_unit_scatter's units are not read in such a frame;
+// path_trace says when), and the tree kernel, enqueued BEHIND the one-queue kernel, finishes those pixels from where they
+// stand with a node's children on lanes.
 #define PT_Q_CHOICE 200
+#define PT_Q_HEAVY 201
+#define PT_Q_BUDGET 202  // rays after which a lane hands its pixel over, from the flagged pixels the first pass counted (pt_unit_scatter)
+#define PT_HANDOVER_HEADER 8  // doubles in front of a record's nodes: generator state and increment, sample, nodes, rays, the pixel's sum
 #ifndef PT_UNIT_SHARDS
 #define PT_UNIT_SHARDS 8
 #endif

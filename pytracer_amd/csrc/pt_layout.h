@@ -120,6 +120,11 @@ struct PtKArgs {
   int dome_slot;                   // path tracer, first pass: the sphere the camera is deepest inside (uniform pigments), or -1
   int dome_shortcut;               // 0: every tile goes through rays (pt_set_dome_shortcut; a measurement switch)
   int tree_fuse;                   // pt_path_tree_kernel: spare lanes of a leaf round trace the parent's next child (1) or idle (0)
+  double *handover;                // num_of_rays > 1: records of the pixels the one-queue kernel hands to the tree kernel (PT_Q_HEAVY)
+  int handover_cap;                // ... how many fit
+  int q_budget;                    // one-queue kernel of num_of_rays > 1: a pixel that has traced this many rays is handed to the tree kernel (0: never)
+  int q_tail_budget;               // ... or this many rays after the pixel queue has run dry (0: never)
+  int q_few_lanes;                 // ... or when, the queue dry, this many lanes of its wave or fewer still hold a pixel (0: never)
   int tree_jump_lds;               // pt_path_tree_kernel: where the leaf rounds' state-jump coefficients live in LDS (8-byte words; 2 x 4 x 64 pairs), -1 = none
   int tree_uniform_max;            // pt_path_tree_kernel: worlds up to this many shapes are queried by the wave-uniform loop
   int dbg_trace_unit;              // -DPT_DEBUG_TIME builds: the unit whose steps are traced (PTRACE_TRACE_UNIT)

@@ -92,13 +92,14 @@ PT_DEV void pcg_seed_pixel(Pcg &p, int pcg_mode, uint64_t s0, uint64_t q0, unsig
 // formed from the constant's correctly rounded reciprocal and one correction step (a multiplication and two explicit fused
 // multiply-adds -- not a contraction: the expression is not the reference's, its VALUE is, for every one of the 2^32 possible
 // inputs: tests/proofs/pcg_float_div.c checks them all) instead of the dozen dependent instructions of a general division.
-PT_DEV double pcg_float(Pcg &p) {
-  const double x = (double)pcg_next(p);
+PT_DEV double pcg_unit(uint32_t v) {
+  const double x = (double)v;
   const double r = 0x1.00000001p-32;  // RN(1 / 4294967295.0)
   const double q0 = x * r;
   const double e = __builtin_fma(-4294967295.0, q0, x);
   return __builtin_fma(e, r, q0);
 }
+PT_DEV double pcg_float(Pcg &p) { return pcg_unit(pcg_next(p)); }
 
 // ---- transformations.py:58-86 ----------------------------------------------------------------------
 template <typename P>
@@ -138,6 +139,10 @@ PT_DEV V3 normalize3(V3 a) {
 #define PT_NOINLINE static __device__ __attribute__((noinline))
 PT_NOINLINE double pt_sin(double x) { return sin(x); }
 PT_NOINLINE double pt_cos(double x) { return cos(x); }
+// sin and cos of ONE angle share their argument reduction and both polynomial kernels in ocml (sincos): 198 instructions
+// against 348 for the two calls, whose common part the compiler does not merge.  The VALUES are those of sin() and cos() --
+// op 11 of pt_probe_kernel compares them over every angle scatter_ray can form (tests/test_gpu_probes.py).
+PT_NOINLINE void pt_sincos(double x, double *s, double *c) { sincos(x, s, c); }
 PT_NOINLINE double pt_atan2(double y, double x) { return atan2(y, x); }
 PT_NOINLINE double pt_acos(double x) { return acos(x); }
 

@@ -41,7 +41,8 @@ PT_DEV int unit_ppu(const unsigned long long *queue, long long lanes_cap, int ns
 #define PT_SCATTER_BLOCK 256
 #endif
 __global__ void pt_unit_scatter(const unsigned char *keys, const unsigned long long *masks, int n, int4 *units, int units_cap,
-                                unsigned long long *queue, long long lanes_cap, int nsamp, int min_rounds, long long q_min_flagged = -1) {
+                                unsigned long long *queue, long long lanes_cap, int nsamp, int min_rounds, long long q_min_flagged = -1,
+                                double q_budget_per_flagged = 0.0, int q_budget_min = 0) {
   __shared__ int cnt[65], offs[65];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int k = i < n ? keys[i] : 0;
@@ -74,6 +75,11 @@ __global__ void pt_unit_scatter(const unsigned char *keys, const unsigned long l
       queue[10] = (unsigned long long)ppu;
       // num_of_rays > 1: which second-pass kernel works on this frame (PT_Q_CHOICE); < 0: the tree kernel, always
       queue[PT_Q_CHOICE] = (q_min_flagged >= 0 && (long long)queue[11] >= q_min_flagged) ? 1ULL : 0ULL;
+      // ... and after how many rays a lane of the one-queue kernel hands its pixel to the tree kernel: about what a lane
+      // traces in the whole frame if the work were spread evenly (F x mean rays of a pixel / lanes) -- a pixel's own chain
+      // should not outlast that by much
+      const double qb = (double)queue[11] * q_budget_per_flagged;
+      queue[PT_Q_BUDGET] = (unsigned long long)(qb > (double)q_budget_min ? (qb < 1e9 ? qb : 1e9) : (double)q_budget_min);
     }
   }
   __syncthreads();
@@ -307,6 +313,12 @@ PT_DEV void path_trace(const PtKArgs &a) {
   const int mbase = (threadIdx.x >> 6) * npass;
   const int regions_x = (W + PT_REGION - 1) / PT_REGION;
   bool exhausted = false;           // !TILED: the global queue is empty
+  // (q_budget < 0 in the argument block: the budget pt_unit_scatter derived from the frame's flagged pixels)
+  const int q_budget = !FLAGGED ? 0 : (cold_args(a)->q_budget >= 0 ? cold_args(a)->q_budget : (int)pt_queue(a)[PT_Q_BUDGET]), q_tail = FLAGGED ? cold_args(a)->q_tail_budget : 0,
+            q_few = FLAGGED ? cold_args(a)->q_few_lanes : 0;
+  unsigned qtail = 0;               // FLAGGED: rays of the lane's pixel since the queue ran dry
+  bool q_full = false;              // FLAGGED: the record table was full when this lane last asked
+  unsigned qrays = 0;               // FLAGGED: rays of the lane's pixel so far (counted when the pixel is done: a pixel over budget is the tree kernel's)
   bool first_unit = true;           // TILED (wave-uniform)
   // TILED: units of the frame (written by pt_unit_scatter before this kernel started; read once -- not from the heads' lines)
   const int n_units = TILED ? (int)pt_queue(a)[9] : 0;
@@ -532,6 +544,11 @@ PT_DEV void path_trace(const PtKArgs &a) {
         cum.z = cum.z * k;
       }
       store_pixel(a, pix, cum);
+      if (FLAGGED) {
+        nrays += qrays;
+        qrays = 0;
+        qtail = 0;
+      }
       cum.x = 0.0;
       cum.y = 0.0;
       cum.z = 0.0;
@@ -917,6 +934,10 @@ PT_DEV void path_trace(const PtKArgs &a) {
     if (work) {
       if (TILED)
         srays++;
+      else if (FLAGGED) {
+        qrays++;
+        if (exhausted) qtail++;
+      }
       else
         nrays++;
       shade(hit, best_t);
@@ -924,21 +945,10 @@ PT_DEV void path_trace(const PtKArgs &a) {
     }
     bool unwinding = work;
     while (unwinding) {
-      if (spawn) {
-        // scatter_ray consumes its draws even when the child is beyond max_depth
-        if (INL)
-          ray = scatter_ray<true>(f_brdf, pcg, f_in, f_wp, f_n);
-        else
-          scatter_ray_call(f_brdf, &pcg, &f_in, &f_wp, &f_n, &ray);
-        spawn = false;
-        if (sp > D) {  // render.py:100-101: the child returns black without a world query
-          ret.x = 0.0;
-          ret.y = 0.0;
-          ret.z = 0.0;
-          continue;
-        }
-        break;  // mode 1: queried at the next S-step
-      }
+      // (a lane with a child to scatter leaves the loop; the scatter itself -- two draws, sin / cos, two square roots -- runs
+      //  ONCE behind the loop for every lane of the wave that spawns in this step, whether its node was pushed by shade() or
+      //  reached by a child's return: inside the loop the wave ran it once per turn that any lane spawned in)
+      if (spawn) break;
       if (sp == 0) {
         finish_sample();  // mode 0 (next sample), 2 (pixel done) or 3 (TILED: wait for the round's end)
         break;
@@ -989,6 +999,75 @@ PT_DEV void path_trace(const PtKArgs &a) {
       ret.y = fget(4) + fc.y * invN;
       ret.z = fget(5) + fc.z * invN;
       sp = fs;
+    }
+    if constexpr (FLAGGED) {
+      // A lane walks its pixel's rays one after the other: a tree of 1 111 rays (the CLI's N = 10, D = 3) is 1 111 turns of
+      // this loop, ~6 us each, and once the pixel queue has run dry nothing fills the lanes that finish: the frame waits for
+      // its heaviest pixels while most of the chip idles.  The tree kernel behind this one traces a node's children at the
+      // same time, so a pixel's remaining rays take a sixth of the time there.  A lane therefore HANDS ITS PIXEL OVER, at the
+      // point where its next ray would be scattered: the node stack, the generator, the sums and the ray count go into a
+      // record (PT_HANDOVER_HEADER + 20 doubles per node, in the tree kernel's node layout) and the pixel becomes a unit of the
+      // tree kernel (PT_Q_HEAVY), which goes on exactly where the lane stopped -- nothing is traced twice, and every draw
+      // happens at the state the sequential program has there.  When: the queue dry and `q_few` or fewer lanes of the wave
+      // still hold a pixel (the plan's default); or the pixel has traced q_budget rays, or q_tail rays since the queue ran
+      // dry (measurement switches).  A full record table leaves the pixel with its lane.
+      const bool few = q_few > 0 && exhausted && __popcll(__ballot(mode != 2)) <= q_few;  // (wave-uniform)
+      if (spawn && !q_full && (few || (q_budget > 0 && qrays >= (unsigned)q_budget) || (q_tail > 0 && qtail >= (unsigned)q_tail))) {
+        pt_kargs ca = cold_args(a);
+        const unsigned long long k = atomicAdd(pt_queue(a) + PT_Q_HEAVY, 1ULL);
+        q_full = k >= (unsigned long long)ca->handover_cap;  // (the lane keeps this pixel and asks no more)
+        if (!q_full) {
+          const int lr = (int)(pix / W), c0 = (int)(pix - (long long)lr * W);
+          const int region = (lr / PT_REGION) * regions_x + c0 / PT_REGION;
+          const unsigned long long m = ca->region_mask[region];
+          const int bit = (lr % PT_REGION) * PT_REGION + (c0 % PT_REGION);
+          const int first = __popcll(m & ((1ULL << bit) - 1ULL));
+          ((int4 *)ca->units)[k] = make_int4(region, first | (1 << 8) | (1 << 16), (int)(unsigned)m, (int)(unsigned)(m >> 32));
+          double *rec = ca->handover + (size_t)k * (size_t)(PT_HANDOVER_HEADER + 20 * (D > 1 ? D : 1));
+          rec[0] = __longlong_as_double((long long)pcg.state);
+          rec[1] = __longlong_as_double((long long)pcg.inc);
+          rec[2] = (double)samp;
+          rec[3] = (double)sp;
+          rec[4] = (double)qrays;
+          rec[5] = cum.x;
+          rec[6] = cum.y;
+          rec[7] = cum.z;
+          for (int d = 0; d < sp; ++d) {
+            FrameRef fr = {nullptr, 0};
+            if constexpr (LDSF == 2) fr = frame_ref_split(w, d);
+            auto fget = [&](int field) -> double {
+              if constexpr (LDSF == 2)
+                return fr.p[(size_t)field * fr.fstride];
+              else
+                return ws_get<LDSF>(w, d, field);
+            };
+            double *t = rec + PT_HANDOVER_HEADER + 20 * d;
+            for (int f = 0; f < 9; ++f) t[f] = fget(f);           // hit_color, emitted radiance, the children's sum so far
+            for (int f = 0; f < 9; ++f) t[9 + f] = fget(10 + f);  // hit point, normal, incoming direction
+            t[18] = fget(19);                                     // BRDF
+            // children traced: the tree kernel counts the one whose subtree is being walked (every node but the innermost)
+            t[19] = fget(9) + (d < sp - 1 ? 1.0 : 0.0);
+          }
+          spawn = false;
+          qrays = 0;
+          qtail = 0;
+          cum.x = 0.0;
+          cum.y = 0.0;
+          cum.z = 0.0;
+          samp = 0;
+          sp = 0;
+          mode = 2;
+        }
+      }
+    }
+    if (spawn) {
+      // scatter_ray (materials.py:132-152, 175-196); the child is at depth sp <= max_depth (a hit whose children would lie
+      // beyond it never pushes a frame: shade_hit), so it is queried at the next S-step (mode 1)
+      if (INL)
+        ray = scatter_ray<true>(f_brdf, pcg, f_in, f_wp, f_n);
+      else
+        scatter_ray_call(f_brdf, &pcg, &f_in, &f_wp, &f_n, &ray);
+      spawn = false;
     }
     PT_STAMP(5);
   }

@@ -35,9 +35,13 @@
   X(tile4_npx, "PTRACE_TILE4_NPX", 0)             /* 2 / 4: pixels per lane of pt_tile4_kernel (0: by frame size) */        \
   X(tile4_lds, "PTRACE_TILE4_LDS", 1)             /* pt_tile4_kernel<FLAT>: records staged in LDS for shading */            \
   X(qchoice, "PTRACE_QCHOICE", 1)                 /* 0: never the one-queue alternative, 2: always (measurement) */         \
+  X(q_wg_per_cu, "PTRACE_Q_WG_PER_CU", 0)         /* the one-queue kernel: workgroups per CU (0: what its LDS frames allow) */  \
   X(q_lds_frames, "PTRACE_Q_LDS_FRAMES", 1)       /* 0: the one-queue kernel's frame stack always in HBM */                 \
   X(q_frames_home, "PTRACE_Q_FRAMES_HOME", -1)    /* ... 0 HBM, 1 LDS, 2 split (deepest slot in LDS); -1: by the plan */    \
   X(q_min_flagged, "PTRACE_Q_MIN_FLAGGED", -1)    /* >= 0: the flagged-pixel count from which the one-queue kernel works */ \
+  X(q_budget, "PTRACE_Q_BUDGET", -1)              /* rays after which the one-queue kernel hands a pixel to the tree kernel (0: never; -1: by the plan) */ \
+  X(q_tail_budget, "PTRACE_Q_TAIL_BUDGET", -1)    /* ... the same counted from the moment the pixel queue runs dry (0: never; -1: by the plan) */ \
+  X(q_few_lanes, "PTRACE_Q_FEW_LANES", -1)        /* ... or when, the queue dry, a wave holds this many pixels or fewer (0: never; -1: by the plan) */ \
   X(q_lanes, "PTRACE_Q_LANES", 1)                 /* 0: the one-queue alternative is pt_path_kernel<true, true> */          \
   X(p_maxpath, "PTRACE_P_MAXPATH", 0)             /* step batching of path_trace (0: by kernel) */                          \
   X(s_min, "PTRACE_S_MIN", 0)                                                                                               \
@@ -115,6 +119,19 @@ enum PtSecondPass {  // the path tracer's second-pass kernel
   PT_SECOND_TREE,                     // pt_path_tree_kernel<false>
   PT_SECOND_TREE_LEAN_SCENE,          // pt_path_tree_kernel<true, true>: the shapes' records staged in LDS
 };
+#define PT_PLAN_HANDOVER_HEADER 8  // (pt_kernels.h: PT_HANDOVER_HEADER; asserted equal in ptrace.hip)
+#ifndef PT_HANDOVER_CAP
+#define PT_HANDOVER_CAP 65536      // records; a full table leaves a pixel with its lane
+#endif
+#ifndef PT_Q_BUDGET_DEFAULT
+#define PT_Q_BUDGET_DEFAULT -1
+#endif
+#ifndef PT_Q_TAIL_BUDGET_DEFAULT
+#define PT_Q_TAIL_BUDGET_DEFAULT 50
+#endif
+#ifndef PT_Q_FEW_LANES_DEFAULT
+#define PT_Q_FEW_LANES_DEFAULT 16
+#endif
 enum PtAltPass {  // the one-queue alternative enqueued behind the tree kernel (PT_Q_CHOICE)
   PT_ALT_NONE = 0,
   PT_ALT_FLAGGED_LEAN_HBM,  // pt_path_flagged_kernel<1, false>
@@ -155,6 +172,14 @@ struct PtPlan {
   size_t lds_q = 0;       // the one-queue alternative
   // path tracer
   bool lds_frames = false, q_lds_frames = false;
+  int q_tail_budget = 0;  // ... or this many rays after the pixel queue ran dry
+  int handover_cap = 0;   // records of pixels handed from the one-queue kernel to the tree kernel (PT_HANDOVER_HEADER + 20 doubles per node each)
+  size_t handover_doubles = 0;
+  int q_few_lanes = 0;    // ... or when a wave of the dry queue holds this many pixels or fewer
+  int q_budget = 0;       // the one-queue alternative hands a pixel to the tree kernel once it has traced this many rays (0: never;
+                          // -1: q_budget_per_flagged x the frame's flagged pixels, at least q_budget_min -- pt_unit_scatter)
+  double q_budget_per_flagged = 0.0;
+  int q_budget_min = 0;
   int q_home = 0;         // the one-queue alternative's frame stack: 0 HBM, 1 LDS, 2 split (deepest slot in LDS, the rest in HBM)
   int frame_doubles = 6;
   int diag_lds = -1, grid_occ_lds = -1, scene_lds = -1;  // offsets as the kernels take them (PtKArgs)
@@ -314,8 +339,31 @@ static inline void pt_make_plan(const PtSceneFacts &s, const pt_camera *cam, con
   const size_t q_frame_lds = pl.q_home == 1 ? q_frame_bytes : (pl.q_home == 2 ? (size_t)20 * B * sizeof(double) : 0);
   pl.q_alt = pl.tree && t.qchoice != 0;
   if (pl.q_alt) {
-    const int wgq = pl.q_home == 1 ? std::min<int>(3, (int)(PT_LDS_BUDGET / q_frame_bytes)) : 2;
+    pl.q_tail_budget = t.q_tail_budget >= 0 ? (int)t.q_tail_budget : PT_Q_TAIL_BUDGET_DEFAULT;
+    pl.q_few_lanes = t.q_few_lanes >= 0 ? (int)t.q_few_lanes : PT_Q_FEW_LANES_DEFAULT;
+    pl.handover_cap = (int)std::min<long long>(pl.npix, PT_HANDOVER_CAP);
+    pl.handover_doubles = (size_t)pl.handover_cap * (size_t)(PT_PLAN_HANDOVER_HEADER + 20 * std::max(p->max_depth, 1));
+    int wgq = pl.q_home == 1 ? std::min<int>(3, (int)(PT_LDS_BUDGET / q_frame_bytes)) : 2;
+    if (t.q_wg_per_cu > 0) wgq = (int)t.q_wg_per_cu;
     pl.grid_q = (int)std::max<long long>(1, std::min<long long>(want, (long long)s.n_cu * wgq));
+    // The budget: what a lane traces in the whole frame were the work spread evenly -- F flagged pixels x nsamp samples x the
+    // mean rays of a sample's tree / the kernel's lanes: a pixel's own chain should not outlast the frame's throughput time.
+    // The mean tree: 1 + N (1 + pN + (pN)^2 + ... ), p = the share of rays that hit and scatter on: 0.13 on the three N = 10,
+    // D = 3 frames of tools/ray_histogram.py (26 - 43 rays per flagged pixel of a full tree's 1 111).  The swept optimum of a
+    // FIXED budget on those frames (300 - 400 at F = 470 - 630 k, profiles/r05_handover_sweep.txt) is this number; smaller
+    // frames need a smaller one, shallow or narrow trees (budget > a full tree) none at all.
+    pl.q_budget = t.q_budget >= 0 ? (int)t.q_budget : PT_Q_BUDGET_DEFAULT;
+    {
+      const double pn = 0.13 * (double)p->num_of_rays;
+      double mean = 1.0, pw = 1.0;
+      for (int d = 0; d < p->max_depth && mean < 1e9; ++d) {
+        mean += (double)p->num_of_rays * pw;
+        pw *= pn;
+      }
+      const int ns = p->samples_per_side > 0 ? p->samples_per_side * p->samples_per_side : 1;
+      pl.q_budget_per_flagged = mean * (double)ns / ((double)pl.grid_q * B);
+      pl.q_budget_min = 32;
+    }
   }
   if (pl.path_tiled) {  // first pass (pt_tile_kernel<PATHTRACER>): one wave per 8x8 region
     const long long nreg = (long long)((p->width + PT_PLAN_REGION - 1) / PT_PLAN_REGION) * ((rows + PT_PLAN_REGION - 1) / PT_PLAN_REGION);
@@ -403,12 +451,15 @@ static inline void pt_make_plan(const PtSceneFacts &s, const pt_camera *cam, con
     const int pcg_mode = p->pcg_mode == PT_PCG_SEQ ? PT_PCG_PIXEL : p->pcg_mode;  // (SEQ is refused for the path tracer)
     pl.min_rounds = t.unit_min_rounds != 0 ? (int)t.unit_min_rounds : (pcg_mode == PT_PCG_SAMPLE ? -2 : 16);  // (< 0: see unit_ppu)
     // The flagged pixels from which the one-queue kernel takes the frame (q_alt): where its estimate falls below the tree
-    // kernel's.  Both fitted to measurements on the MI355X (tools/tree_vs_queue.py, profiles/r04_tree_vs_queue.txt: 25 frames
-    // of three scenes, N = 2 ... 20, D = 2 ... 8; ns per flagged pixel and sample):
+    // kernel's.  Both fitted to measurements on the MI355X (tools/tree_vs_queue.py: 25 frames of three scenes, N = 2 ... 20,
+    // D = 2 ... 8; ns per flagged pixel and sample; round 4: profiles/r04_tree_vs_queue.txt, round 5 with the hand-over of
+    // heavy pixels: profiles/r05_tree_vs_queue.txt):
     //   tree kernel       F x tT,  tT = 4.5 + 0.045 min(R, 500)   (R = sum of N^d, the rays of a full tree: one pixel at a
     //                     time on each of the 8 n_cu resident waves, a handful of rounds per family of children)
-    //   one-queue kernel  R x step + F x tQ,  step = 6 + 0.02 n_shapes us (its deepest lane: R dependent steps, scattered
-    //                     rays on per-lane candidate lists),  tQ = (0.5 + 0.01 n_shapes)(1 + R / 800)
+    //   one-queue kernel  min(R, 250) x step + F x tQ,  step = 6 + 0.02 n_shapes us: the chain of its deepest lane -- which,
+    //                     since round 5, ends at the budget and goes on in the tree kernel at a sixth of the time per ray: a
+    //                     frame of full trees (R = 1 111) costs 1.5 - 1.9 ms on top of its throughput, where round 4 paid
+    //                     R x step = 7 ms --, tQ = (2 + 0.01 n_shapes)(1 + R / 800)
     // FITTED RANGE: 2 <= N <= 20, D <= 8 (D > 3 with the stack in HBM: x 1.3), <= 300 shapes; outside it the
     // estimate is clamped to that range's corner instead of extrapolated.
     pl.q_min = -1;
@@ -422,8 +473,8 @@ static inline void pt_make_plan(const PtSceneFacts &s, const pt_camera *cam, con
       }
       const double step_ns = (6.0 + 0.02 * fit_shapes) * 1e3 * (pl.q_home != 0 ? 1.0 : 1.3);  // (all frames in HBM: measured on D = 4 ... 8)
       const double t_tree = (4.5 + 0.045 * std::min(tree_rays, 500.0)) * (2048.0 / (8.0 * s.n_cu));
-      const double t_queue = (0.5 + 0.01 * fit_shapes) * (1.0 + tree_rays / 800.0);
-      if (t_tree > t_queue) pl.q_min = (long long)std::min(1e15, 1.1 * tree_rays * step_ns / (t_tree - t_queue));
+      const double t_queue = (2.0 + 0.01 * fit_shapes) * (1.0 + tree_rays / 800.0);
+      if (t_tree > t_queue) pl.q_min = (long long)std::min(1e15, 1.1 * std::min(tree_rays, 250.0) * step_ns / (t_tree - t_queue));
       if (t.q_min_flagged >= 0) pl.q_min = t.q_min_flagged;
       if (t.qchoice == 2) pl.q_min = 0;
     }

@@ -141,6 +141,19 @@ __global__ void pt_probe_kernel(int op, const double *x, const double *y, double
       r = (pcg_advance(q.state, q.inc, nsteps) == p.state) ? 1.0 : 0.0;
       break;
     }
+    case 11: {  // sincos(phi) against sin(phi), cos(phi) for phi = 2 pi pcg_unit(v), v in [x[i], x[i] + y[i]): the mismatches
+      const uint64_t v0 = (uint64_t)x[i], cnt = (uint64_t)y[i];
+      uint64_t bad = 0;
+      for (uint64_t v = v0; v < v0 + cnt && v <= 0xFFFFFFFFULL; ++v) {
+        const double phi = 2.0 * PT_PI * pcg_unit((uint32_t)v);
+        double s1, c1;
+        sincos(phi, &s1, &c1);
+        const double s2 = sin(phi), c2 = cos(phi);
+        bad += (__double_as_longlong(s1) != __double_as_longlong(s2)) || (__double_as_longlong(c1) != __double_as_longlong(c2));
+      }
+      r = (double)bad;
+      break;
+    }
     default: break;
   }
   out[i] = r;

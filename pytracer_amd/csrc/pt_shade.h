@@ -105,7 +105,11 @@ PT_DEV Ray scatter_ray(int brdf_kind, Pcg &pcg, V3 incoming, V3 point, V3 n) {
     const double cts = pcg_float(pcg);
     const double ct = sqrt(cts), st = sqrt(1.0 - cts);
     const double phi = 2.0 * PT_PI * pcg_float(pcg);
-    const double cp = INL ? cos(phi) : pt_cos(phi), sp = INL ? sin(phi) : pt_sin(phi);
+    double cp, sp;
+    if (INL)
+      sincos(phi, &sp, &cp);
+    else
+      pt_sincos(phi, &sp, &cp);
     r.d.x = ct * (cp * e1.x) + ct * (sp * e2.x) + st * n.x;
     r.d.y = ct * (cp * e1.y) + ct * (sp * e2.y) + st * n.y;
     r.d.z = ct * (cp * e1.z) + ct * (sp * e2.z) + st * n.z;

@@ -66,7 +66,12 @@ PT_DEV void path_tree(const PtKArgs &a) {
     unsigned long long *qn = pt_queue_next(a);
     for (int k = threadIdx.x; k < PT_QUEUE_WORDS; k += PT_BLOCK) qn[k] = 0ULL;
   }
-  if (pt_queue(a)[PT_Q_CHOICE] != 0ULL) {  // (uniform over the grid) a frame full of flagged pixels: pt_path_kernel<., true> renders it
+  // (uniform over the grid) a frame full of flagged pixels: pt_path_flagged_kernel rendered it, except the pixels it
+  // handed over (PT_Q_HEAVY units from unit 0 of the list)
+  const bool handed = pt_queue(a)[PT_Q_CHOICE] != 0ULL;
+  int n_units = (int)pt_queue(a)[handed ? PT_Q_HEAVY : 9];
+  if (handed && n_units > cold_args(a)->handover_cap) n_units = cold_args(a)->handover_cap;  // (a full table: the lane kept its pixel)
+  if (handed && n_units == 0) {
     add_ray_count(a, 0ULL);
     return;
   }
@@ -132,7 +137,6 @@ PT_DEV void path_tree(const PtKArgs &a) {
   const int lane = threadIdx.x & 63;
   const int mbase = (threadIdx.x >> 6) * npass;
   const int regions_x = (W + PT_REGION - 1) / PT_REGION;
-  const int n_units = (int)pt_queue(a)[9];
   bool first_unit = true;
   unsigned long long nrays = 0;  // (wave-uniform: committed rays of this wave's pixels)
   // small worlds: the wave-uniform loop over every shape (records through the scalar cache) has a shorter critical
@@ -250,6 +254,8 @@ PT_DEV void path_tree(const PtKArgs &a) {
     pt_kargs ca = cold_args(a);
     const int4 unit = ca->units[seq];
     const int region = __builtin_amdgcn_readfirstlane(unit.x), first = __builtin_amdgcn_readfirstlane(unit.y) & 0xff;
+    // a pixel the one-queue kernel handed over in the middle of its tree (path_trace): record `seq` says where it stands
+    const bool resumed = ((__builtin_amdgcn_readfirstlane(unit.y) >> 16) & 1) != 0;
     const unsigned long long todo = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(unit.z) |
                                     ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(unit.w) << 32);
     const int ry = region / regions_x, rx = region - ry * regions_x;
@@ -284,39 +290,60 @@ PT_DEV void path_tree(const PtKArgs &a) {
     }
     V3 cum_pix = {0.0, 0.0, 0.0};
     unsigned long long prays = 0;
+    int samp0 = 0, resume_sp = 0;  // (resume_sp > 0: the first sample of this unit goes on in the middle of its tree)
+    if (resumed) {
+      // what the lane had: the samples it finished and their sum, the rays it traced, the generator where the sequential
+      // program's is, and the node stack as the lane left it (its records are in this kernel's node layout) -- the next
+      // thing the sequential program does is scatter child `next` of the innermost node
+      const double *hrec = ca->handover + (size_t)seq * (size_t)(PT_HANDOVER_HEADER + PT_TREE_FRAME * (D > 1 ? D : 1));
+      gstate = (unsigned long long)__double_as_longlong(rl_f64(hrec[0], 0));
+      ginc = (unsigned long long)__double_as_longlong(rl_f64(hrec[1], 0));
+      samp0 = (int)rl_f64(hrec[2], 0);
+      resume_sp = (int)rl_f64(hrec[3], 0);
+      prays = (unsigned long long)rl_f64(hrec[4], 0);
+      cum_pix = {rl_f64(hrec[5], 0), rl_f64(hrec[6], 0), rl_f64(hrec[7], 0)};
+      for (int e = lane; e < resume_sp * PT_TREE_FRAME; e += 64) frame(0)[e] = hrec[PT_HANDOVER_HEADER + e];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
 #ifdef PT_DEBUG_TIME
     unsigned long long dbg_rounds_pix = 0;
 #endif
     PT_TT(0);
-    for (int samp = 0; samp < nsamp; ++samp) {
-      if (pcg_mode == PT_PCG_SAMPLE) {
+    for (int samp = samp0; samp < nsamp; ++samp) {
+      const bool resume_now = resume_sp > 0;  // (wave-uniform)
+      if (pcg_mode == PT_PCG_SAMPLE && !resume_now) {
         Pcg g;
         pcg_seed(g, ca->s0, ca->q0 + gpix * (unsigned)nsamp + (unsigned)samp);
         gstate = g.state;
         ginc = g.inc;
       }
       // ---- the sample's primary ray (imagetracer.py:86-97): lane 0 ----
-      pcg.state = gstate;
-      pcg.inc = ginc;
-      pcg.n = 0;
-      double up = 0.5, vp = 0.5;
-      if (S > 0) {
-        const int sr = samp / S, sc = samp - sr * S;
-        up = ((double)sc + pcg_float(pcg)) / (double)S;
-        vp = ((double)sr + pcg_float(pcg)) / (double)S;
+      V3 sample_ret = {0.0, 0.0, 0.0};
+      if (!resume_now) {
+        pcg.state = gstate;
+        pcg.inc = ginc;
+        pcg.n = 0;
+        double up = 0.5, vp = 0.5;
+        if (S > 0) {
+          const int sr = samp / S, sc = samp - sr * S;
+          up = ((double)sc + pcg_float(pcg)) / (double)S;
+          vp = ((double)sr + pcg_float(pcg)) / (double)S;
+        }
+        ray = primary_ray(a, col, grow, up, vp);
+        {
+          double tp = INFINITY;
+          // (an orthogonal camera's rays have no common origin: nothing is hoisted)
+          const int hp = ortho ? world_query_tile<false, false, false>(a, ray, mbase, npass, tp, lane == 0)
+                               : world_query_tile<false, false, true>(a, ray, mbase, npass, tp, lane == 0);
+          shade_ray(hp, tp, 0);
+        }
+        prays += 1ULL;
+        PT_TT(1);
+        sample_ret = rl_v3(o_ret, 0);
+        gstate = rl_u64(pcg.state, 0);
       }
-      ray = primary_ray(a, col, grow, up, vp);
-      {
-        double tp = INFINITY;
-        // (an orthogonal camera's rays have no common origin: nothing is hoisted)
-        const int hp = ortho ? world_query_tile<false, false, false>(a, ray, mbase, npass, tp, lane == 0)
-                             : world_query_tile<false, false, true>(a, ray, mbase, npass, tp, lane == 0);
-        shade_ray(hp, tp, 0);
-      }
-      prays += 1ULL;
-      PT_TT(1);
-      V3 sample_ret = rl_v3(o_ret, 0);
-      gstate = rl_u64(pcg.state, 0);
       int sp = 0;  // nodes on the stack; the innermost one (frame sp - 1) is the node whose children are being traced
       // of that node, in registers (wave-uniform): hit_color, the sum of its children so far, how many are done, its BRDF
       V3 t_hc = {0.0, 0.0, 0.0}, t_cum = {0.0, 0.0, 0.0};
@@ -367,7 +394,16 @@ PT_DEV void path_tree(const PtKArgs &a) {
       auto base_draws = [&]() -> unsigned {  // what a child of the innermost node draws when it needs no children: scatter + roulette
         return (t_brdf == PT_BRDF_DIFFUSE ? 2u : 0u) + (sp >= rr ? 1u : 0u);
       };
-      if (!__builtin_amdgcn_readfirstlane((int)o_term)) {
+      if (resume_now) {
+        sp = resume_sp;
+        resume_sp = 0;
+        const double *g = frame(sp - 1);
+        t_hc = {rfl_f64(g[0]), rfl_f64(g[1]), rfl_f64(g[2])};
+        t_cum = {rfl_f64(g[6]), rfl_f64(g[7]), rfl_f64(g[8])};
+        t_brdf = (int)rfl_f64(g[18]);
+        t_next = (int)rfl_f64(g[19]);
+        cpred = base_draws();
+      } else if (!__builtin_amdgcn_readfirstlane((int)o_term)) {
         push_node(0, ray.d);
         cpred = base_draws();
       }

@@ -92,6 +92,8 @@ struct pt_scene {
   double *tex_data = nullptr;
   double *ws = nullptr;  // path-tracer frame stack, grown on demand
   size_t ws_bytes = 0;
+  double *handover = nullptr;  // num_of_rays > 1: records of the pixels the one-queue kernel hands to the tree kernel
+  size_t handover_doubles = 0;
   void *out_dev = nullptr;  // staging for pt_render (host output)
   size_t out_dev_bytes = 0;
   unsigned long long *ray_counter = nullptr;   // totals: all rays, rays resolved by the dome shortcut
@@ -262,6 +264,7 @@ extern "C" void pt_scene_free(pt_scene *s) {
   (void)hipFree(s->hoist);
   (void)hipFree(s->hoist_diag);
   (void)hipFree(s->ws);
+  (void)hipFree(s->handover);
   (void)hipFree(s->out_dev);
   (void)hipFree(s->ray_counter);
   (void)hipFree(s->ray_partials);
@@ -1022,7 +1025,8 @@ static void fill_scene_args(const pt_scene *s, PtKArgs &a) {
 
 static_assert(PT_PLAN_BLOCK == PT_BLOCK && PT_PLAN_REGION == PT_REGION && PT_PLAN_CELL == PT_CELL && PT_PLAN_CELL_CHUNK == PT_CELL_CHUNK &&
                   PT_PLAN_TREE_FRAME == PT_TREE_FRAME && PT_PLAN_SCATTER_BLOCK == PT_SCATTER_BLOCK && PT_PLAN_DIAG_BYTES == sizeof(PtDiagRec) &&
-                  PT_PLAN_REC_BYTES == sizeof(PtShapeRec) && PT_PLAN_AUX_BYTES == sizeof(PtShapeAux),
+                  PT_PLAN_REC_BYTES == sizeof(PtShapeRec) && PT_PLAN_AUX_BYTES == sizeof(PtShapeAux) && PT_PLAN_HANDOVER_HEADER == PT_HANDOVER_HEADER &&
+                  PT_TREE_FRAME == 20,
               "pt_plan.h sizes the kernels' tiles and records by number: keep them equal to the kernels' own");
 
 // grow-only device buffers of a handle: a launch that needs more lets the stream drain first
@@ -1187,6 +1191,15 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
     a.tree_uniform_max = (int)tn.tree_uniform_max;  // (measured on C3, N = 10: the uniform loop 2.48 ms, candidate lists 1.92)
     a.tree_fuse = (int)tn.tree_fuse;
     a.tree_jump_lds = pl.tree_jump_lds;
+    if (pl.q_alt) {
+      int rc = ensure(&s->handover, &s->handover_doubles, pl.handover_doubles, st);
+      if (rc) return rc;
+    }
+    a.handover = s->handover;
+    a.handover_cap = pl.q_alt ? pl.handover_cap : 0;
+    a.q_budget = 0;  // (the one-queue kernel's block carries these)
+    a.q_tail_budget = 0;
+    a.q_few_lanes = 0;
     a.dbg_trace_unit = (int)tn.trace_unit;
     // The sphere the camera is deepest inside (object-space |o'|^2 - 1 most negative, and below -0.5): the
     // first pass settles, per pixel, what can only hit that sphere (pt_tile_kernel re-checks every condition
@@ -1308,11 +1321,54 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
       // second pass: the pixels the first one flagged, fullest regions first
       if (pl.tree)  // one pixel per unit: "64 lanes per pixel, whatever the number of flagged pixels"
         hipLaunchKernelGGL(pt_unit_scatter, dim3(pl.grid_scatter), dim3(PT_SCATTER_BLOCK), 0, st, s->region_keys, s->region_mask, pl.nregions,
-                           s->units, s->units_cap, s->queue_last, (long long)1 << 60, 64, 1, pl.q_min);
+                           s->units, s->units_cap, s->queue_last, (long long)1 << 60, 64, 1, pl.q_min, pl.q_budget_per_flagged, pl.q_budget_min);
       else
         hipLaunchKernelGGL(pt_unit_scatter, dim3(pl.grid_scatter), dim3(PT_SCATTER_BLOCK), 0, st, s->region_keys, s->region_mask, pl.nregions,
                            s->units, s->units_cap, s->queue_last, pl.lanes_cap, pl.nsamp, (long long)pl.min_rounds);
-      const bool last2 = !pl.q_alt;
+      if (pl.q_alt) {
+        // num_of_rays > 1: the one-queue kernel IN FRONT of the tree kernel, with an argument block of its own (a lane per
+        // pixel: 20 doubles per depth and lane, its own grid, its own slots for the ray counts); it returns at once unless
+        // PT_Q_CHOICE says 1, and then leaves the pixels over its budget to the tree kernel behind it (PT_Q_HEAVY)
+        PtKArgs aq = a;
+        aq.cold = s->args_dev2;
+        aq.nthreads = pl.grid_q * PT_BLOCK;
+        aq.frame_doubles = 20;
+        aq.p_max_path = pl.q_p_max_path;
+        aq.s_min_path = pl.q_s_min_path;
+        aq.count_base = pl.grid + pl.grid_first;
+        aq.q_budget = pl.q_budget;
+        aq.q_tail_budget = pl.q_tail_budget;
+        aq.q_few_lanes = pl.q_few_lanes;
+        aq.scene_lds = -1;
+        aq.grid_occ_lds = -1;
+        aq.diag_lds = pl.q_diag_lds;
+        aq.ws = s->ws;
+        PtKArgs cold2 = aq;
+        cold2.out = nullptr;
+        cold2.qpar = 0;
+        if (!(s->args2_valid && s->args2_stream == st && memcmp(&s->args2_last, &cold2, sizeof cold2) == 0)) {
+          HIP_TRY(hipMemcpyAsync(s->args_dev2, &cold2, sizeof cold2, hipMemcpyHostToDevice, st));
+          s->args2_last = cold2;
+          s->args2_valid = true;
+          s->args2_stream = st;
+        }
+#define PT_ALT(K_)                                              \
+  do {                                                          \
+    HIP_TRY(path_lds_limit((const void *)(K_), pl.lds_q));      \
+    PT_LAUNCH((K_), pl.grid_q, pl.lds_q, false, aq);            \
+  } while (0)
+        switch (pl.alt) {
+          case PT_ALT_FLAGGED_LEAN_HBM: PT_ALT((pt_path_flagged_kernel<1, 0>)); break;
+          case PT_ALT_FLAGGED_HBM: PT_ALT((pt_path_flagged_kernel<0, 0>)); break;
+          case PT_ALT_PATH_UNIFORM: PT_ALT((pt_path_kernel<true, true>)); break;
+          case PT_ALT_FLAGGED_LEAN_LDS: PT_ALT((pt_path_flagged_kernel<1, 1>)); break;
+          case PT_ALT_FLAGGED_LEAN_SPLIT: PT_ALT((pt_path_flagged_kernel<1, 2>)); break;
+          case PT_ALT_FLAGGED_SPLIT: PT_ALT((pt_path_flagged_kernel<0, 2>)); break;
+          default: PT_ALT((pt_path_flagged_kernel<0, 1>)); break;
+        }
+#undef PT_ALT
+      }
+      const bool last2 = true;
 #define PT_SECOND(K_)                                               \
   do {                                                              \
     HIP_TRY(path_lds_limit((const void *)(K_), pl.lds_main));       \
@@ -1329,46 +1385,7 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
         default: PT_SECOND((pt_path_regions_kernel<false>)); break;
       }
 #undef PT_SECOND
-      if (pl.q_alt) {
-        // ... and the one-queue kernel behind it, with an argument block of its own (a lane per pixel: 20 doubles per depth
-        // and lane, its own grid, its own slots for the ray counts); it returns at once unless PT_Q_CHOICE says 1
-        PtKArgs aq = a;
-        aq.cold = s->args_dev2;
-        aq.nthreads = pl.grid_q * PT_BLOCK;
-        aq.frame_doubles = 20;
-        aq.p_max_path = pl.q_p_max_path;
-        aq.s_min_path = pl.q_s_min_path;
-        aq.count_base = pl.grid + pl.grid_first;
-        aq.scene_lds = -1;
-        aq.grid_occ_lds = -1;
-        aq.diag_lds = pl.q_diag_lds;
-        aq.ws = s->ws;
-        PtKArgs cold2 = aq;
-        cold2.out = nullptr;
-        cold2.qpar = 0;
-        if (!(s->args2_valid && s->args2_stream == st && memcmp(&s->args2_last, &cold2, sizeof cold2) == 0)) {
-          HIP_TRY(hipMemcpyAsync(s->args_dev2, &cold2, sizeof cold2, hipMemcpyHostToDevice, st));
-          s->args2_last = cold2;
-          s->args2_valid = true;
-          s->args2_stream = st;
-        }
-        const void *tree_fn = main_fn;
-#define PT_ALT(K_)                                              \
-  do {                                                          \
-    HIP_TRY(path_lds_limit((const void *)(K_), pl.lds_q));      \
-    PT_LAUNCH((K_), pl.grid_q, pl.lds_q, true, aq);             \
-  } while (0)
-        switch (pl.alt) {
-          case PT_ALT_FLAGGED_LEAN_HBM: PT_ALT((pt_path_flagged_kernel<1, 0>)); break;
-          case PT_ALT_FLAGGED_HBM: PT_ALT((pt_path_flagged_kernel<0, 0>)); break;
-          case PT_ALT_PATH_UNIFORM: PT_ALT((pt_path_kernel<true, true>)); break;
-          case PT_ALT_FLAGGED_LEAN_LDS: PT_ALT((pt_path_flagged_kernel<1, 1>)); break;
-          case PT_ALT_FLAGGED_LEAN_SPLIT: PT_ALT((pt_path_flagged_kernel<1, 2>)); break;
-          case PT_ALT_FLAGGED_SPLIT: PT_ALT((pt_path_flagged_kernel<0, 2>)); break;
-          default: PT_ALT((pt_path_flagged_kernel<0, 1>)); break;
-        }
-#undef PT_ALT
-        main_fn = tree_fn;  // (pt_stats.vgprs: the tree kernel's; pt_stats.kernel follows the device's choice, see fold_stats)
+      if (pl.q_alt) {  // (pt_stats.vgprs: the tree kernel's; pt_stats.kernel follows the device's choice, see fold_stats)
         HIP_TRY(hipMemcpyAsync(s->ray_counter_host + 2, s->queue_last + PT_Q_CHOICE, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         s->choice_pending = true;
       }
@@ -1845,6 +1862,7 @@ static void plan_info(const PtPlan &pl, const PtSceneFacts &f, const pt_params *
   out->has_grid = f.has_grid;
   out->ball_levels = pl.bs_levels;
   out->units_need = pl.units_need;
+  out->alt_budget = pl.q_alt ? pl.q_budget : 0;
   out->nregions = pl.nregions;
   out->min_rounds = pl.min_rounds;
   out->spec_draws = pl.spec_draws;

@@ -79,7 +79,12 @@ def test_cli_defaults_enqueue_the_tree_kernel_and_the_one_queue_alternative():
     # (2 x 4 x 64 pairs of 64-bit words), then -- at a 256-byte boundary -- the shapes' records for shading
     assert p.lds_main == (32 + 3 * 20 * 4 * 8 + 32 * 64 + 8192 + 255) // 256 * 256 + 32 * 384
     assert p.lds_alt == 3 * 20 * 256 * 8 + 32 * 64 and p.grid_alt == 256 and p.workspace_bytes == 0  # 120 KB of frames: one workgroup per CU
-    assert 250_000 < p.q_min_flagged < 400_000  # C3's 29 k flagged pixels: tree; C2 + plane's 490 k: one queue
+    # C3's 29 k flagged pixels (65 k at 1920x1080): tree; C2 + plane at 640x360 (123 k) and up: one queue -- which hands its
+    # heavy pixels to the tree kernel behind it: a budget derived on the device from the flagged pixels (-1), 50 rays after
+    # the pixel queue ran dry, or 16 lanes left in a wave
+    assert 70_000 < p.q_min_flagged < 110_000
+    assert p.alt_budget == -1
+    assert all(device.get_tuning(k) == -1 for k in ("q_budget", "q_tail_budget", "q_few_lanes"))  # (the plan's defaults)
     deep = plan(world(32), 1280, 720, **dict(CLI, num_of_rays=3, max_depth=5))
     assert deep.alt_kernel == "pt_path_flagged_kernel<LEAN, SPLIT>" and deep.alt_frame_stack == "SPLIT" and deep.grid_alt == 512
     assert deep.workspace_bytes == 5 * 20 * 256 * 8 * 512
@@ -193,6 +198,11 @@ def test_switches_select_the_documented_variants(tuning):
     tuning("q_lanes", 0)
     assert plan(world(32), 1280, 720, **CLI).alt_kernel == "pt_path_kernel<LDS, FLAGGED>"
     tuning("q_lanes", 1)
+    tuning("q_budget", 5)  # (the GPU suite's way of handing nearly every pixel over in the middle of its tree)
+    assert plan(world(32), 1280, 720, **CLI).alt_budget == 5
+    tuning("q_budget", 0)
+    assert plan(world(32), 1280, 720, **CLI).alt_budget == 0
+    tuning("q_budget", -1)
     tuning("q_frames_home", -1)
     tuning("lds_frames", 0)
     assert plan(world(32), 1280, 720, **C3).main_kernel == "pt_path_regions_kernel<HBM>"

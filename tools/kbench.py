@@ -76,6 +76,8 @@ def main():
         kw = dict(kw)
         if sample:
             kw["pcg_mode"] = abi.PCG_SAMPLE
+        if os.environ.get("KB_DEPTH"):  # (experiments: the same scene at another max_depth)
+            kw["max_depth"] = int(os.environ["KB_DEPTH"])
         demo_cam = None
         if ns == "demo":
             world, demo_cam = scenes.demo_world(clock=150.0)
