@@ -85,8 +85,7 @@ PT_DEV pt_kargs cold_args(const PtKArgs &a) {
 // throughput-bound).  The other one returns at once -- unless the one-queue kernel hands pixels over (round 5): a lane per
 // pixel walks a pixel's rays one after the other, so a frame would wait for its heaviest pixels' chains (1 111 rays at the
 // CLI's N = 10, D = 3) while the lanes that have finished idle.  Such a lane writes its pixel's state into a record and
-// appends the pixel to the unit list (PT_Q_HEAVY units, from unit 0: pt_unit_scatter's units are not read in such a frame;
-// path_trace says when), and the tree kernel, enqueued BEHIND the one-queue kernel, finishes those pixels from where they
+// appends the pixel to a unit list of its own (PT_Q_HEAVY units in `units_handed`; path_trace says when), and the tree kernel, enqueued BEHIND the one-queue kernel, finishes those pixels from where they
 // stand with a node's children on lanes.
 #define PT_Q_CHOICE 200
 #define PT_Q_HEAVY 201

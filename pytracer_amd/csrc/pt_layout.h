@@ -120,6 +120,7 @@ struct PtKArgs {
   int dome_slot;                   // path tracer, first pass: the sphere the camera is deepest inside (uniform pigments), or -1
   int dome_shortcut;               // 0: every tile goes through rays (pt_set_dome_shortcut; a measurement switch)
   int tree_fuse;                   // pt_path_tree_kernel: spare lanes of a leaf round trace the parent's next child (1) or idle (0)
+  int4 *units_handed;              // num_of_rays > 1: the units of the pixels the one-queue kernel hands to the tree kernel (handover_cap of them)
   double *handover;                // num_of_rays > 1: records of the pixels the one-queue kernel hands to the tree kernel (PT_Q_HEAVY)
   int handover_cap;                // ... how many fit
   int q_budget;                    // one-queue kernel of num_of_rays > 1: a pixel that has traced this many rays is handed to the tree kernel (0: never)

@@ -146,4 +146,21 @@ PT_NOINLINE void pt_sincos(double x, double *s, double *c) { sincos(x, s, c); }
 PT_NOINLINE double pt_atan2(double y, double x) { return atan2(y, x); }
 PT_NOINLINE double pt_acos(double x) { return acos(x); }
 
+// ---- one lane's value for the whole wave (v_readlane; `lane` wave-uniform) ----
+PT_DEV double rl_f64(double v, int lane) {  // v_readlane of a double (lane wave-uniform)
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, lane);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), lane);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | (unsigned long long)lo);
+}
+PT_DEV unsigned long long rl_u64(unsigned long long u, int lane) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, lane);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), lane);
+  return ((unsigned long long)hi << 32) | (unsigned long long)lo;
+}
+PT_DEV V3 rl_v3(V3 v, int lane) {
+  V3 r = {rl_f64(v.x, lane), rl_f64(v.y, lane), rl_f64(v.z, lane)};
+  return r;
+}
+
 PT_DEV double max2(double a, double b) { return (b > a) ? b : a; }  // Python max(a, b)

@@ -322,6 +322,9 @@ PT_DEV void path_trace(const PtKArgs &a) {
   bool first_unit = true;           // TILED (wave-uniform)
   // TILED: units of the frame (written by pt_unit_scatter before this kernel started; read once -- not from the heads' lines)
   const int n_units = TILED ? (int)pt_queue(a)[9] : 0;
+  // FLAGGED: flagged pixels of the frame (one unit each: pt_unit_scatter as for the tree kernel) and how the queue deals
+  const int n_flagged = FLAGGED ? (int)pt_queue(a)[9] : 0;
+  const bool deal_units = FLAGGED && 4LL * (long long)n_flagged < a.npix;
   unsigned long long nrays = 0;
 
   // lane state.  mode 0: starts a sample at the next P-step; 1: inside a path (S-steps); 2: nothing to do;
@@ -855,21 +858,35 @@ PT_DEV void path_trace(const PtKArgs &a) {
       for (;;) {
         const bool need = mode == 2 && !exhausted;
         if (!__any(need)) break;
-        const long long np = next_pixel(a, need, a.npix);
+        // FLAGGED: the queue deals out the frame's pixel indices and a lane that draws a settled pixel draws again -- or, where
+        // flagged pixels are few (under a quarter of the frame), the FLAGGED pixels themselves, from pt_unit_scatter's list of
+        // one-pixel units: skipping cost a returning atomic per wave and settled pixel (~1 M atomics on one word for a 4K
+        // frame with 3 % flagged pixels, at ~90 per us: C3 at 4K 10.5 -> 3.0 ms).  Frames FULL of flagged pixels keep the
+        // row-major order: the list's order (fullest regions first) costs them 15 - 30 % (profiles/r05_queue_dealing.txt).
+        const long long np = next_pixel(a, need, deal_units ? (long long)n_flagged : a.npix);
         if (need && np >= 0) {
           bool take = true;
-          if (FLAGGED) {  // pixels the first pass settled are not this kernel's (pt_tile_kernel: rmask)
-            const int lr = (int)(np / W), c0 = (int)(np - (long long)lr * W);
-            const unsigned long long m = cold_args(a)->region_mask[(lr / PT_REGION) * regions_x + c0 / PT_REGION];
-            take = ((m >> ((lr % PT_REGION) * PT_REGION + (c0 % PT_REGION))) & 1ULL) != 0ULL;
+          long long p = np;
+          if (FLAGGED) {
+            if (deal_units) {
+              const int4 unit = cold_args(a)->units[np];
+              const unsigned long long todo = (unsigned long long)(unsigned)unit.z | ((unsigned long long)(unsigned)unit.w << 32);
+              const int bit = nth_set_bit(todo, unit.y & 0xff);
+              const int ry = unit.x / regions_x, rx = unit.x - ry * regions_x;
+              p = (long long)(ry * PT_REGION + (bit >> 3)) * W + (rx * PT_REGION + (bit & 7));
+            } else {  // pixels the first pass settled are not this kernel's (pt_tile_kernel: rmask)
+              const int lr = (int)(np / W), c0 = (int)(np - (long long)lr * W);
+              const unsigned long long m = cold_args(a)->region_mask[(lr / PT_REGION) * regions_x + c0 / PT_REGION];
+              take = ((m >> ((lr % PT_REGION) * PT_REGION + (c0 % PT_REGION))) & 1ULL) != 0ULL;
+            }
           }
           if (take) {
-            pix = np;
+            pix = p;
             mode = 0;
           }
         }
         exhausted = __any(need && np < 0);
-        if (!FLAGGED) break;  // (FLAGGED: lanes that drew a settled pixel draw again)
+        if (!FLAGGED || deal_units) break;  // (dealing indices: lanes that drew a settled pixel draw again)
       }
       if (!__any(mode != 2)) break;
     }
@@ -1022,7 +1039,7 @@ PT_DEV void path_trace(const PtKArgs &a) {
           const unsigned long long m = ca->region_mask[region];
           const int bit = (lr % PT_REGION) * PT_REGION + (c0 % PT_REGION);
           const int first = __popcll(m & ((1ULL << bit) - 1ULL));
-          ((int4 *)ca->units)[k] = make_int4(region, first | (1 << 8) | (1 << 16), (int)(unsigned)m, (int)(unsigned)(m >> 32));
+          ca->units_handed[k] = make_int4(region, first | (1 << 8) | (1 << 16), (int)(unsigned)m, (int)(unsigned)(m >> 32));
           double *rec = ca->handover + (size_t)k * (size_t)(PT_HANDOVER_HEADER + 20 * (D > 1 ? D : 1));
           rec[0] = __longlong_as_double((long long)pcg.state);
           rec[1] = __longlong_as_double((long long)pcg.inc);

@@ -28,7 +28,7 @@
   X(path_wg_per_cu, "PTRACE_PATH_WG_PER_CU", 0)   /* path tracer: workgroups per CU (0: 2 by regions, 3 one queue) */       \
   X(lds_frames, "PTRACE_LDS_FRAMES", 1)           /* 0: the frame stack always in HBM */                                    \
   X(tree, "PTRACE_TREE", 1)                       /* 0: num_of_rays > 1 never takes pt_path_tree_kernel */                  \
-  X(tree_max_pixels, "PTRACE_TREE_MAX_PIXELS", 2100000) /* frames larger than this never take the tree kernel */            \
+  X(tree_max_pixels, "PTRACE_TREE_MAX_PIXELS", 9000000) /* frames larger than this never take the tree kernel (16 B of unit list per pixel) */ \
   X(scene_lds, "PTRACE_SCENE_LDS", 1)             /* second pass: the shapes' records staged in LDS when they fit */        \
   X(tile_wg_per_cu, "PTRACE_TILE_WG_PER_CU", 0)   /* 8x8 tile kernels: cap on resident workgroups per CU (0: 8) */          \
   X(tile4, "PTRACE_TILE4", 1)                     /* 0: never pt_tile4_kernel */                                            \
@@ -456,10 +456,10 @@ static inline void pt_make_plan(const PtSceneFacts &s, const pt_camera *cam, con
     // heavy pixels: profiles/r05_tree_vs_queue.txt):
     //   tree kernel       F x tT,  tT = 4.5 + 0.045 min(R, 500)   (R = sum of N^d, the rays of a full tree: one pixel at a
     //                     time on each of the 8 n_cu resident waves, a handful of rounds per family of children)
-    //   one-queue kernel  min(R, 250) x step + F x tQ,  step = 6 + 0.02 n_shapes us: the chain of its deepest lane -- which,
+    //   one-queue kernel  min(R, 100) x step + F x tQ,  step = 6 + 0.02 n_shapes us: the chain of its deepest lane -- which,
     //                     since round 5, ends at the budget and goes on in the tree kernel at a sixth of the time per ray: a
-    //                     frame of full trees (R = 1 111) costs 1.5 - 1.9 ms on top of its throughput, where round 4 paid
-    //                     R x step = 7 ms --, tQ = (2 + 0.01 n_shapes)(1 + R / 800)
+    //                     frame of full trees (R = 1 111) costs under a millisecond on top of its throughput, where round 4
+    //                     paid R x step = 7 ms --, tQ = (2 + 0.01 n_shapes)(1 + R / 800)
     // FITTED RANGE: 2 <= N <= 20, D <= 8 (D > 3 with the stack in HBM: x 1.3), <= 300 shapes; outside it the
     // estimate is clamped to that range's corner instead of extrapolated.
     pl.q_min = -1;
@@ -474,7 +474,7 @@ static inline void pt_make_plan(const PtSceneFacts &s, const pt_camera *cam, con
       const double step_ns = (6.0 + 0.02 * fit_shapes) * 1e3 * (pl.q_home != 0 ? 1.0 : 1.3);  // (all frames in HBM: measured on D = 4 ... 8)
       const double t_tree = (4.5 + 0.045 * std::min(tree_rays, 500.0)) * (2048.0 / (8.0 * s.n_cu));
       const double t_queue = (2.0 + 0.01 * fit_shapes) * (1.0 + tree_rays / 800.0);
-      if (t_tree > t_queue) pl.q_min = (long long)std::min(1e15, 1.1 * std::min(tree_rays, 250.0) * step_ns / (t_tree - t_queue));
+      if (t_tree > t_queue) pl.q_min = (long long)std::min(1e15, 1.1 * std::min(tree_rays, 100.0) * step_ns / (t_tree - t_queue));
       if (t.q_min_flagged >= 0) pl.q_min = t.q_min_flagged;
       if (t.qchoice == 2) pl.q_min = 0;
     }

@@ -25,21 +25,6 @@
 // LDS: per wave max(D, 1) node records of PT_TREE_FRAME doubles; of the innermost node hit_color, the running sum, the child
 // counter and the BRDF kind are also kept in registers (wave-uniform).
 #define PT_TREE_FRAME 20  // hc 0..2, em 3..5, cum 6..8, wp 9..11, n 12..14, in 15..17, brdf 18, next child 19
-PT_DEV double rl_f64(double v, int lane) {  // v_readlane of a double (lane wave-uniform)
-  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
-  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, lane);
-  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), lane);
-  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | (unsigned long long)lo);
-}
-PT_DEV unsigned long long rl_u64(unsigned long long u, int lane) {
-  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, lane);
-  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), lane);
-  return ((unsigned long long)hi << 32) | (unsigned long long)lo;
-}
-PT_DEV V3 rl_v3(V3 v, int lane) {
-  V3 r = {rl_f64(v.x, lane), rl_f64(v.y, lane), rl_f64(v.z, lane)};
-  return r;
-}
 
 // SLDS (round 5): the shapes' records (128 B + 256 B each) staged in LDS by the workgroup, as the second pass by regions does:
 // shading gathers ~25 values of the hit shape per lane through dependent loads (needs_uv -> pigments -> matrices), and a
@@ -252,7 +237,7 @@ PT_DEV void path_tree(const PtKArgs &a) {
     const int seq = (int)__builtin_amdgcn_readfirstlane((int)uid);
     if (seq >= n_units) break;
     pt_kargs ca = cold_args(a);
-    const int4 unit = ca->units[seq];
+    const int4 unit = handed ? ca->units_handed[seq] : ca->units[seq];
     const int region = __builtin_amdgcn_readfirstlane(unit.x), first = __builtin_amdgcn_readfirstlane(unit.y) & 0xff;
     // a pixel the one-queue kernel handed over in the middle of its tree (path_trace): record `seq` says where it stands
     const bool resumed = ((__builtin_amdgcn_readfirstlane(unit.y) >> 16) & 1) != 0;

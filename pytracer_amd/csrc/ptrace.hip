@@ -94,6 +94,8 @@ struct pt_scene {
   size_t ws_bytes = 0;
   double *handover = nullptr;  // num_of_rays > 1: records of the pixels the one-queue kernel hands to the tree kernel
   size_t handover_doubles = 0;
+  int4 *units_handed = nullptr;  // ... and their units
+  size_t units_handed_n = 0;
   void *out_dev = nullptr;  // staging for pt_render (host output)
   size_t out_dev_bytes = 0;
   unsigned long long *ray_counter = nullptr;   // totals: all rays, rays resolved by the dome shortcut
@@ -265,6 +267,7 @@ extern "C" void pt_scene_free(pt_scene *s) {
   (void)hipFree(s->hoist_diag);
   (void)hipFree(s->ws);
   (void)hipFree(s->handover);
+  (void)hipFree(s->units_handed);
   (void)hipFree(s->out_dev);
   (void)hipFree(s->ray_counter);
   (void)hipFree(s->ray_partials);
@@ -1194,8 +1197,11 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
     if (pl.q_alt) {
       int rc = ensure(&s->handover, &s->handover_doubles, pl.handover_doubles, st);
       if (rc) return rc;
+      rc = ensure(&s->units_handed, &s->units_handed_n, (size_t)pl.handover_cap, st);
+      if (rc) return rc;
     }
     a.handover = s->handover;
+    a.units_handed = s->units_handed;
     a.handover_cap = pl.q_alt ? pl.handover_cap : 0;
     a.q_budget = 0;  // (the one-queue kernel's block carries these)
     a.q_tail_budget = 0;
