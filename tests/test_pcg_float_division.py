@@ -25,6 +25,7 @@ def test_the_reciprocal_form_is_the_ieee_quotient_for_all_2_to_32_inputs(tmp_pat
 
 def test_the_kernel_source_uses_exactly_that_constant_and_sequence():
     src = open(os.path.join(os.path.dirname(HERE), "pytracer_amd", "csrc", "pt_math.h")).read()
-    body = src[src.index("PT_DEV double pcg_float(Pcg &p) {"):]
+    body = src[src.index("PT_DEV double pcg_unit(uint32_t v) {"):]  # (pcg_float = pcg_unit of the generator's next output)
     body = body[:body.index("\n}\n")]
+    assert "PT_DEV double pcg_float(Pcg &p) { return pcg_unit(pcg_next(p)); }" in src
     assert "0x1.00000001p-32" in body and "__builtin_fma(-4294967295.0, q0, x)" in body and "__builtin_fma(e, r, q0)" in body
