@@ -303,6 +303,10 @@ def extra_rows(device: int):
         "C3_pathtracer_1280x720_32sph_D3_spp16_N1": (32, False, False, 1280, 720, 7, c3),
         "C3_same_PT_PCG_SAMPLE": (32, False, False, 1280, 720, 7, dict(c3, pcg_mode=abi.PCG_SAMPLE)),
         "C3_cli_default_N10_spp1": (32, False, False, 1280, 720, 3, dict(c3, samples_per_side=1, num_of_rays=10)),
+        # the reference CLI's defaults (main.py:95-102: N = 10, D = 3, one sample) on frames FULL of scattering pixels: the C2
+        # scene with its ground plane, and the reference's own demo scene (main.py:40-93) at its 4:3 aspect
+        "C2_scene_with_plane_cli_default_N10_spp1": (32, True, False, 1280, 720, 3, dict(c3, samples_per_side=1, num_of_rays=10)),
+        "demo_scene_1280x960_cli_default_N10_spp1": ("demo", False, False, 1280, 960, 3, dict(c3, samples_per_side=1, num_of_rays=10)),
         "C5_flat_1280x720_10k_spheres": (10000, False, True, 1280, 720, 5, dict(renderer=abi.RENDERER_FLAT)),
         "C4_pathtracer_3840x2160_256sph_D5_spp64_one_gpu": (256, False, True, 3840, 2160, 3, C4["kw"]),
         "C4_same_PT_PCG_SAMPLE": (256, False, True, 3840, 2160, 3, dict(C4["kw"], pcg_mode=abi.PCG_SAMPLE)),
@@ -321,18 +325,23 @@ def extra_rows(device: int):
             for ds_old in scene_cache.values():
                 ds_old[1].close()
             scene_cache.clear()
-            world = scenes.synthetic_world(ns, with_plane=plane, wide=wide)
+            demo_cam = None
+            if ns == "demo":
+                world, demo_cam = scenes.demo_world(clock=150.0)
+            else:
+                world = scenes.synthetic_world(ns, with_plane=plane, wide=wide)
             for l in range(n_lights):
                 from pytracer_amd import hostmodel as hm
 
                 world.add_light(hm.PointLight(hm.Vec(-3.0 + 4.0 * l, 6.0 - 9.0 * l, 8.0), hm.Color(1.0, 0.9, 0.8), 0.0))
             flat = flatten.flatten_world(world)
-            scene_cache[key] = (flat, DeviceScene(flat, device=device))
-        flat, ds = scene_cache[key]
+            scene_cache[key] = (flat, DeviceScene(flat, device=device), flatten.flatten_camera(demo_cam) if demo_cam is not None else None)
+        flat, ds, own_cam = scene_cache[key]
+        cam = own_cam if own_cam is not None else cam_for(W, H)
         par = abi.make_params(W, H, out_format=abi.OUT_F32, **kw)
         out = torch.empty((H, W, 3), dtype=torch.float32, device="cuda")  # (a rank's share uses the top of it)
-        rows[name] = kernel_row(ds, cam_for(W, H), par, out, reps, flat)
-        rows[name]["two_frames_in_flight"] = in_flight_row(ds, cam_for(W, H), par, out, 40 if W * H > 2_000_000 else 120)
+        rows[name] = kernel_row(ds, cam, par, out, reps, flat)
+        rows[name]["two_frames_in_flight"] = in_flight_row(ds, cam, par, out, 40 if W * H > 2_000_000 else 120)
     for ds_old in scene_cache.values():
         ds_old[1].close()
     # the path tracer's second pass on C3: executed VALU instructions (PMC medians committed under profiles/) against

@@ -49,6 +49,9 @@ int pt_debug_scatter_probe(const double *in, int n, double *out, unsigned long l
 /* The 16 leading words of the path tracer's queue block of the last frame (unit counts; section sums of a
  * -DPT_DEBUG_TIME build). */
 int pt_debug_read_queue(pt_scene *scene, unsigned long long *out16);
+/* num_of_rays > 1, last frame: the pixels the one-queue kernel handed to the tree kernel in the middle of their trees
+ * (0 when the tree kernel rendered the frame alone), and the ray budget the device derived from the flagged pixels. */
+int pt_debug_handed_over(pt_scene *scene, unsigned long long *pixels, unsigned long long *budget);
 
 /* What a frame WILL launch -- the plan pt_render / pt_render_device follow (csrc/pt_plan.h) -- computed on the HOST from a scene
  * DESCRIPTION, a camera and the parameters: no device is touched, so the choice of kernels, grids, LDS and thresholds is

@@ -21,7 +21,7 @@ EXPORTS = ("pt_device_count", "pt_scene_upload", "pt_scene_clone", "pt_scene_fre
 # every symbol include/ptrace_debug.h declares for ordinary builds (diagnostics: not part of the boundary)
 DEBUG_EXPORTS = ("pt_debug_probe", "pt_debug_cull_probe", "pt_debug_hit_probe", "pt_debug_lanes_probe",
                  "pt_debug_camera_probe", "pt_debug_scatter_probe", "pt_debug_read_queue", "pt_debug_plan", "pt_debug_plan_scene",
-                 "pt_debug_set_tuning", "pt_debug_get_tuning")
+                 "pt_debug_set_tuning", "pt_debug_get_tuning", "pt_debug_handed_over")
 
 
 # include/ptrace.h: pt_version() = major << 16 | minor; abi.Stats mirrors the 56-byte pt_stats of minor >= 2, the tracer's
@@ -166,6 +166,9 @@ def lib():
             L.pt_debug_set_tuning.argtypes = [C.c_char_p, C.c_longlong]
             L.pt_debug_get_tuning.restype = C.c_int
             L.pt_debug_get_tuning.argtypes = [C.c_char_p, P(C.c_longlong)]
+        if hasattr(L, "pt_debug_handed_over"):
+            L.pt_debug_handed_over.restype = C.c_int
+            L.pt_debug_handed_over.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         if hasattr(L, "pt_debug_read_queue"):
             L.pt_debug_read_queue.restype = C.c_int
             L.pt_debug_read_queue.argtypes = [C.c_void_p, C.c_void_p]

@@ -1932,6 +1932,18 @@ extern "C" int pt_debug_read_queue(pt_scene *s, unsigned long long *out16) {
   return PT_OK;
 }
 
+extern "C" int pt_debug_handed_over(pt_scene *s, unsigned long long *pixels, unsigned long long *budget) {
+  if (!s || !pixels || !budget) return fail(PT_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(s->device));
+  HIP_TRY(hipDeviceSynchronize());
+  unsigned long long w[3] = {0, 0, 0};  // PT_Q_CHOICE, PT_Q_HEAVY, PT_Q_BUDGET
+  static_assert(PT_Q_HEAVY == PT_Q_CHOICE + 1 && PT_Q_BUDGET == PT_Q_CHOICE + 2, "read as one block");
+  HIP_TRY(hipMemcpy(w, (s->queue_last ? s->queue_last : s->queue) + PT_Q_CHOICE, sizeof w, hipMemcpyDeviceToHost));
+  *pixels = w[0] ? w[1] : 0ULL;
+  *budget = w[2];
+  return PT_OK;
+}
+
 #ifdef PT_DEBUG_TIME
 extern "C" int pt_debug_read_dbg(unsigned long long *out8, int reset) {
   HIP_TRY(hipDeviceSynchronize());

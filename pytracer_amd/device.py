@@ -187,6 +187,13 @@ class DeviceScene:
         _lib.check(_lib.lib().pt_get_stats(self._h, C.byref(st)))
         return st
 
+    def handed_over(self) -> Tuple[int, int]:
+        """Diagnostics, ``num_of_rays > 1``: (pixels the one-queue kernel handed to the tree kernel in the last frame, the ray
+        budget the device derived from the frame's flagged pixels)."""
+        n, b = C.c_ulonglong(0), C.c_ulonglong(0)
+        _lib.check(_lib.lib().pt_debug_handed_over(self._h, C.byref(n), C.byref(b)))
+        return int(n.value), int(b.value)
+
 
 def device_info(device: int = 0) -> Tuple[int, int]:
     """-> (compute units, peak shader clock in kHz)."""

@@ -97,6 +97,69 @@ def test_c3_cli_defaults_full_frame_vs_oracle(dev, oracle):
     _path_check(f"C3 N=10 {W}x{H}", out, ora, st.n_rays, n, 1, W * H)
 
 
+@pytest.mark.parametrize("which", ["c2_scene_with_plane_1280x720", "demo_scene_1280x960"])
+def test_cli_defaults_on_frames_full_of_scattering_pixels_vs_oracle(dev, oracle, which):
+    """The CLI's defaults (N = 10, D = 3, one sample) where the whole ground scatters: the device picks the one-queue kernel, which
+    hands its heaviest pixels (trees of up to 1 111 rays) to the tree kernel in the middle of their trees (round 5).  20 - 25 M
+    rays; the frames bench.py quotes as `C2_scene_with_plane_cli_default_N10_spp1` / `demo_scene_1280x960_cli_default_N10_spp1`."""
+    from pytracer_amd import flatten, scenes
+
+    if which.startswith("demo"):
+        W, H = 1280, 960
+        world, camera = scenes.demo_world(clock=150.0)
+        scene, cam = flatten.flatten_world(world), flatten.flatten_camera(camera)
+    else:
+        W, H = 1280, 720
+        scene, cam = _synthetic(32, True, False, W, H)
+    par = abi.make_params(W, H, abi.RENDERER_PATHTRACER, samples_per_side=1, num_of_rays=10, max_depth=3, rr_limit=3,
+                          path_state=45, path_seq=54)
+    with dev.DeviceScene(scene) as ds:
+        out = ds.render(cam, par)
+        st = ds.stats()
+        if dev.get_tuning("qchoice") == 1 and dev.get_tuning("tree") != 0:
+            assert st.kernel == abi.KERNEL_PATH, st.kernel  # (the one-queue kernel took the frame)
+            handed, budget = ds.handed_over()
+            print(f"{which}: {handed} pixels handed to the tree kernel, budget {budget} rays")
+            if all(dev.get_tuning(k) == -1 for k in ("q_budget", "q_tail_budget", "q_few_lanes")):
+                assert 1000 < handed < 65536 and 200 < budget < 500
+    ora, n = _oracle(oracle, scene, cam, par)
+    _path_check(f"{which} N=10", out, ora, st.n_rays, n, 1, W * H)
+
+
+@pytest.mark.parametrize("policy", [dict(q_budget=7), dict(q_budget=0, q_tail_budget=2, q_few_lanes=0), dict(q_budget=0, q_tail_budget=0, q_few_lanes=64),
+                                    dict(q_budget=40, q_tail_budget=10, q_few_lanes=8)])
+@pytest.mark.parametrize("mode", [abi.PCG_PIXEL, abi.PCG_SAMPLE])
+def test_pixels_handed_to_the_tree_kernel_in_the_middle_of_their_trees(dev, oracle, policy, mode):
+    """The hand-over itself, forced at every depth of the stack: after 7 rays of a pixel (its lane is anywhere in the tree: one,
+    two or three nodes on the stack, between two samples of a jittered pixel), 2 rays after the queue ran dry, every pixel in
+    flight when it runs dry, and a mix.  The tree kernel goes on from the record -- node stack, generator, sums, ray count --
+    so frame AND ray count are the oracle's; N = 3 and 4 samples per pixel make a lane hand over between samples too."""
+    W, H = 320, 200
+    scene, cam = _synthetic(32, True, False, W, H)
+    saved = {k: dev.get_tuning(k) for k in ("qchoice", "q_budget", "q_tail_budget", "q_few_lanes")}
+    if saved["qchoice"] == 0 or dev.get_tuning("tree") == 0:
+        pytest.skip("the one-queue kernel is switched off (PTRACE_QCHOICE=0 / PTRACE_TREE=0)")
+    try:
+        dev.set_tuning("qchoice", 2)
+        for k, v in policy.items():
+            dev.set_tuning(k, v)
+        for n_rays, depth, S in ((10, 3, 1), (3, 3, 2), (2, 5, 1), (4, 2, 2)):
+            par = abi.make_params(W, H, abi.RENDERER_PATHTRACER, samples_per_side=S, num_of_rays=n_rays, max_depth=depth, rr_limit=2,
+                                  path_state=45, path_seq=54, pcg_mode=mode)
+            with dev.DeviceScene(scene) as ds:
+                out = ds.render(cam, par)
+                st = ds.stats()
+                handed, _ = ds.handed_over()
+            assert st.kernel == abi.KERNEL_PATH
+            assert handed > 100, f"only {handed} pixels went through the hand-over"
+            ora, n = _oracle(oracle, scene, cam, par)
+            _path_check(f"hand-over {policy} N={n_rays} D={depth} S={S}", out, ora, st.n_rays, n, 1, W * H)
+            assert int(st.n_rays) == n
+    finally:
+        for k, v in saved.items():
+            dev.set_tuning(k, v)
+
+
 def test_c5_full_frame_bit_exact_vs_oracle(dev, oracle):
     """C5 as specified: 1280x720 over 10 000 spheres, Flat (9.2e9 ray-shape tests for the oracle: seconds on the box)."""
     W, H = 1280, 720
