@@ -128,7 +128,10 @@ PT_DEV void path_tree(const PtKArgs &a) {
   // path than per-lane candidate lists -- and a round's latency, not its throughput, is what a pixel's tree waits for
   const bool uniform_loop = a.n_shapes <= cold_args(a)->tree_uniform_max;
   const bool fuse_on = cold_args(a)->tree_fuse != 0;
-  int b_last = N / 2;  // survivors of the last complete leaf family (wave-uniform): where the next one's guesses are centred
+  // survivors of the complete leaf families so far, as a running mean in sixteenths (wave-uniform): where the next family's
+  // guesses are centred.  (Round 4 centred them on the LAST family's count: two families' counts differ by more than the
+  // window's +-4 one time in ten, a family's count and the mean one time in a hundred -- and every miss is a round.)
+  int b_mean16 = 16 * (N / 2);
   // lane r of a leaf round: row = child offset in the round, col = hypothesis b (0..row); rows with row(row+1)/2 + row < 64
   int tri_row = 0;
   while ((tri_row + 1) * (tri_row + 2) / 2 <= lane) ++tri_row;
@@ -426,11 +429,21 @@ PT_DEV void path_tree(const PtKArgs &a) {
         // when the family commits in full and b is among the guesses, the sibling's ray is already traced when the node
         // returns, and a parent whose children all branch costs one round per child instead of two.
         const int leaf_lanes = nrows * (nrows + 1) / 2;
-        bool fused = leaf && sp >= 2 && t_next == 0 && nrows == N && leaf_lanes < 64 && fuse_on;
-        if (fused) fused = (int)rfl_f64(frame(sp - 2)[19]) < N;
+        // (round 5: when this node is its parent's LAST child the parent returns with it -- at no draws --, and the ray that
+        //  follows is the next child of the nearest ancestor that has children left: `up` levels above this node.  A full
+        //  tree of the CLI's N = 10, D = 3 saved one round per leaf family this way in round 3 and saves the ten re-traced
+        //  children of the root now.)
+        int up = 0;
+        if (leaf && sp >= 2 && t_next == 0 && nrows == N && leaf_lanes < 64 && fuse_on)
+          for (int u = 1; u <= sp - 1; ++u)
+            if ((int)rfl_f64(frame(sp - 1 - u)[19]) < N) {
+              up = u;
+              break;
+            }
+        const bool fused = up > 0;
         // (the spare lanes cover nh consecutive values of b around what the last complete family had)
         const int nh = (64 - leaf_lanes) < (N + 1) ? (64 - leaf_lanes) : (N + 1);
-        int bmin = b_last - nh / 2;
+        int bmin = ((b_mean16 + 8) >> 4) - nh / 2;
         bmin = bmin < 0 ? 0 : (bmin > N + 1 - nh ? N + 1 - nh : bmin);
         const bool sib = fused && lane >= leaf_lanes && lane - leaf_lanes < nh;  // hypothesis b = bmin + lane - leaf_lanes
         if (sib) {
@@ -454,7 +467,7 @@ PT_DEV void path_tree(const PtKArgs &a) {
         pcg.n = 0;
         const unsigned long long st_start = pcg.state;
         {
-          const double *f = frame(sib ? sp - 2 : sp - 1);  // the node the ray leaves from
+          const double *f = frame(sib ? sp - 1 - up : sp - 1);  // the node the ray leaves from
           const V3 n_wp = {f[9], f[10], f[11]}, n_n = {f[12], f[13], f[14]}, n_in = {f[15], f[16], f[17]};
           ray = scatter_ray<true>((int)f[18], pcg, n_in, n_wp, n_n);  // materials.py:132-152, 175-196
         }
@@ -466,7 +479,7 @@ PT_DEV void path_tree(const PtKArgs &a) {
         else
           hs = world_query_lanes<false, SMALL ? 1 : 0>(a, ray, INFINITY, ts, act, diag_lds);
         PT_TT(3);
-        if (act) shade_ray(hs, ts, sib ? sp - 1 : sp);
+        if (act) shade_ray(hs, ts, sib ? sp - up : sp);
         PT_TT(4);
 #ifdef PT_DEBUG_TIME
         tsum[7] += 1;
@@ -537,13 +550,14 @@ PT_DEV void path_tree(const PtKArgs &a) {
           }
         }
         if (leaf && t_next == N && nrows == N && fam_draws >= (unsigned)N * c0)
-          b_last = (int)((fam_draws - (unsigned)N * c0) / (2u * (unsigned)N));
+          b_mean16 = (3 * b_mean16 + 16 * (int)((fam_draws - (unsigned)N * c0) / (2u * (unsigned)N)) + 2) >> 2;
 #ifdef PT_DEBUG_TIME
         if (fused) dbg_fused += 1;
 #endif
         if (fused && t_next == N) {
-          // the leaf family is complete: its node returns now, and its parent's next child may be there already
-          (void)pop_node();
+          // the leaf family is complete: its node returns now -- and every ancestor it completes --, and the next child of the
+          // node that is then innermost may be there already
+          for (int u = 0; u < up; ++u) (void)pop_node();
           cpred = base_draws();
           const unsigned long long m = __ballot(sib && st_start == expect);
           if (m) commit_child(__ffsll((long long)m) - 1);
