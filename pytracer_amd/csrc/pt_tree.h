@@ -128,10 +128,9 @@ PT_DEV void path_tree(const PtKArgs &a) {
   // path than per-lane candidate lists -- and a round's latency, not its throughput, is what a pixel's tree waits for
   const bool uniform_loop = a.n_shapes <= cold_args(a)->tree_uniform_max;
   const bool fuse_on = cold_args(a)->tree_fuse != 0;
-  // survivors of the complete leaf families so far, as a running mean in sixteenths (wave-uniform): where the next family's
-  // guesses are centred.  (Round 4 centred them on the LAST family's count: two families' counts differ by more than the
-  // window's +-4 one time in ten, a family's count and the mean one time in a hundred -- and every miss is a round.)
-  int b_mean16 = 16 * (N / 2);
+  // lane b: complete leaf families so far (of this wave, whatever the pixel) that had b survivors -- where the next family's
+  // guesses go (an exponentially fading count)
+  int b_count = 0;
   // lane r of a leaf round: row = child offset in the round, col = hypothesis b (0..row); rows with row(row+1)/2 + row < 64
   int tri_row = 0;
   while ((tri_row + 1) * (tri_row + 2) / 2 <= lane) ++tri_row;
@@ -219,7 +218,7 @@ PT_DEV void path_tree(const PtKArgs &a) {
   // cycles of this wave in: 0 fetch + cull, 1 primary ray, 2 state jump + scatter, 3 scattered-ray query, 4 shade,
   // 5 commit, 6 node returns; 7: rounds
   unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
-  unsigned long long dbg_leaf_rounds = 0, dbg_committed = 0, dbg_traced = 0, dbg_max_rounds = 0, dbg_fused = 0, dbg_fused_hit = 0;
+  unsigned long long dbg_leaf_rounds = 0, dbg_committed = 0, dbg_traced = 0, dbg_max_rounds = 0, dbg_fused = 0, dbg_fused_hit = 0, dbg_fused_incomplete = 0;
 #define PT_TT(k) do { const unsigned long long tn = __builtin_amdgcn_s_memtime(); tsum[k] += tn - tprev; tprev = tn; } while (0)
 #else
 #define PT_TT(k) do { } while (0)
@@ -441,15 +440,28 @@ PT_DEV void path_tree(const PtKArgs &a) {
               break;
             }
         const bool fused = up > 0;
-        // (the spare lanes cover nh consecutive values of b around what the last complete family had)
+        // (the spare lanes cover the nh values of b -- a family's survivors -- that were the most FREQUENT so far: lane b < N + 1
+        //  counts the families that had b survivors, and the nh lanes of highest count, the lower b first on a tie, give the
+        //  guesses.  Ten leaves leave nine lanes for eleven values, and the counts are not of one kind: a node under open sky
+        //  has 0 - 2 survivors, one in a crevice 5 - 8.  Round 4's nine values around the LAST family's count missed one time
+        //  in ten, nine around the running mean one in thirteen -- the window then slides off b = 0 --; every miss is a round.)
         const int nh = (64 - leaf_lanes) < (N + 1) ? (64 - leaf_lanes) : (N + 1);
-        int bmin = ((b_mean16 + 8) >> 4) - nh / 2;
-        bmin = bmin < 0 ? 0 : (bmin > N + 1 - nh ? N + 1 - nh : bmin);
-        const bool sib = fused && lane >= leaf_lanes && lane - leaf_lanes < nh;  // hypothesis b = bmin + lane - leaf_lanes
+        unsigned long long b_set = (N + 1 <= 63) ? ((1ULL << (N + 1)) - 1ULL) : ~0ULL;  // (wave-uniform) the values guessed
+        if (fused && nh < N + 1) {
+          int rank = 0;  // lanes 0 .. N: how many values come before this one
+          for (int j = 0; j <= N; ++j) {
+            const int cj = __builtin_amdgcn_readlane(b_count, j);
+            rank += (cj > b_count || (cj == b_count && j < lane)) ? 1 : 0;
+          }
+          b_set = __ballot(lane <= N && rank < nh);
+        }
+        const int sib_h = (fused && lane >= leaf_lanes && lane - leaf_lanes < nh) ? lane - leaf_lanes : -1;
+        const bool sib = sib_h >= 0;
+        const int sib_b = sib ? nth_set_bit(b_set, sib_h) : 0;  // this lane's guess of the family's survivors
         if (sib) {
           act = true;
           row = -1;
-          ahead = (unsigned)N * c0 + 2u * (unsigned)N * (unsigned)(bmin + lane - leaf_lanes);
+          ahead = (unsigned)N * c0 + 2u * (unsigned)N * (unsigned)sib_b;
         }
         // (what the last round found out is dead: said explicitly, so that it holds no registers across the query)
         o_term = true;
@@ -457,7 +469,7 @@ PT_DEV void path_tree(const PtKArgs &a) {
         o_n = {0.0, 0.0, 1.0};
         o_brdf = 0;
         if (leaf && jump_lds >= 0 && c0 < 4u) {
-          const int e = sib ? 256 + (int)c0 * 64 + (bmin + lane - leaf_lanes) : (int)c0 * 64 + lane;
+          const int e = sib ? 256 + (int)c0 * 64 + sib_b : (int)c0 * 64 + lane;
           const uint64_t A = pt_lds_masks[jump_lds + 2 * (act ? e : 0)], G = pt_lds_masks[jump_lds + 2 * (act ? e : 0) + 1];
           pcg.state = act ? A * gstate + ginc * G : gstate;
         } else {
@@ -550,9 +562,14 @@ PT_DEV void path_tree(const PtKArgs &a) {
           }
         }
         if (leaf && t_next == N && nrows == N && fam_draws >= (unsigned)N * c0)
-          b_mean16 = (3 * b_mean16 + 16 * (int)((fam_draws - (unsigned)N * c0) / (2u * (unsigned)N)) + 2) >> 2;
+        {
+          const int bf = (int)((fam_draws - (unsigned)N * c0) / (2u * (unsigned)N));
+          b_count -= b_count >> 4;  // (the recent past counts: sixteen families' memory)
+          if (lane == bf) b_count += 256;
+        }
 #ifdef PT_DEBUG_TIME
         if (fused) dbg_fused += 1;
+        if (fused && t_next != N) dbg_fused_incomplete += 1;
 #endif
         if (fused && t_next == N) {
           // the leaf family is complete: its node returns now -- and every ancestor it completes --, and the next child of the
@@ -596,7 +613,7 @@ PT_DEV void path_tree(const PtKArgs &a) {
     for (int q = 0; q < 8; ++q) atomicAdd(pt_queue(a) + 1 + q, tsum[q]);
     atomicAdd(pt_queue(a) + 12, dbg_leaf_rounds | (dbg_fused << 24) | (dbg_fused_hit << 44));
     atomicAdd(pt_queue(a) + 13, dbg_committed);
-    atomicAdd(pt_queue(a) + 14, dbg_traced);
+    atomicAdd(pt_queue(a) + 14, dbg_traced | (dbg_fused_incomplete << 40));
     atomicMax(pt_queue(a) + 15, dbg_max_rounds);
   }
 #endif

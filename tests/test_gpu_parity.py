@@ -414,42 +414,38 @@ def test_orthogonal_camera_beam_culling_is_invisible(dev, oracle, n, renderer, S
         assert util.bits_equal(got, ora)
 
 
-def test_plain_kernels_without_culling(oracle):
-    """PTRACE_CULL=0 (read once per process, hence a child process): every renderer through the
-    one-lane-per-pixel kernels and the one-queue path tracer, both cameras, against the oracle."""
-    import subprocess
-    import sys
+def test_plain_kernels_without_culling(dev, oracle):
+    """The `cull` switch off (PTRACE_CULL=0; settable in the running process since round 5 -- this test used to start a child
+    process for it, and a fork of a process that holds a GPU context is something the suite can do without): every renderer
+    through the one-lane-per-pixel kernels and the one-queue path tracer, both cameras, against the oracle."""
+    from pytracer_amd import flatten, hostmodel as hm, scenes
 
-    code = r'''
-import numpy as np
-from pytracer_amd import abi, flatten, hostmodel as hm, scenes, device
-from oracle import oracle
-from tests import util
-world = scenes.synthetic_world(24, with_plane=True)
-world.add_light(hm.PointLight(hm.Vec(-2.0, 3.0, 6.0), hm.Color(1.0, 0.9, 0.8), 0.0))
-scene = flatten.flatten_world(world)
-W, H = 72, 40
-for camera in (hm.PerspectiveCamera(1.0, W / H, hm.translation(hm.Vec(-1.0, 0.0, 1.0))),
-               hm.OrthogonalCamera(W / H, hm.translation(hm.Vec(-1.0, 0.0, 1.0)) * hm.scaling(hm.Vec(1.0, 3.0, 2.0)))):
-    cam = flatten.flatten_camera(camera)
-    with device.DeviceScene(scene) as ds:
-        for renderer, S in ((abi.RENDERER_ONOFF, 0), (abi.RENDERER_FLAT, 2), (abi.RENDERER_POINTLIGHT, 0)):
-            par = abi.make_params(W, H, renderer, samples_per_side=S)
-            ora, n_rays = oracle.render(scene, cam, par, sqr_mode=oracle.SQR_MUL)
-            out = ds.render(cam, par)
-            assert ds.stats().kernel == abi.KERNEL_SIMPLE, "culling should be off"
-            assert util.bits_equal(out, ora), (renderer, S)
-            assert ds.stats().n_rays == n_rays
-        par = abi.make_params(W, H, abi.RENDERER_PATHTRACER, samples_per_side=2, num_of_rays=2, max_depth=3, rr_limit=2,
-                              path_state=45, path_seq=54)
-        ora, _ = oracle.render(scene, cam, par, sqr_mode=oracle.SQR_MUL)
-        out = ds.render(cam, par)
-        assert np.all(util.rel_err(out, ora) <= 1e-5)
-print("plain kernels ok")
-'''
-    env = dict(os.environ, PTRACE_CULL="0")
-    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "plain kernels ok" in r.stdout, r.stdout + r.stderr
+    world = scenes.synthetic_world(24, with_plane=True)
+    world.add_light(hm.PointLight(hm.Vec(-2.0, 3.0, 6.0), hm.Color(1.0, 0.9, 0.8), 0.0))
+    scene = flatten.flatten_world(world)
+    W, H = 72, 40
+    saved = dev.get_tuning("cull")
+    try:
+        dev.set_tuning("cull", 0)
+        for camera in (hm.PerspectiveCamera(1.0, W / H, hm.translation(hm.Vec(-1.0, 0.0, 1.0))),
+                       hm.OrthogonalCamera(W / H, hm.translation(hm.Vec(-1.0, 0.0, 1.0)) * hm.scaling(hm.Vec(1.0, 3.0, 2.0)))):
+            cam = flatten.flatten_camera(camera)
+            with dev.DeviceScene(scene) as ds:
+                for renderer, S in ((abi.RENDERER_ONOFF, 0), (abi.RENDERER_FLAT, 2), (abi.RENDERER_POINTLIGHT, 0)):
+                    par = abi.make_params(W, H, renderer, samples_per_side=S)
+                    ora, n_rays = oracle.render(scene, cam, par, sqr_mode=oracle.SQR_MUL)
+                    out = ds.render(cam, par)
+                    assert ds.stats().kernel == abi.KERNEL_SIMPLE, "culling should be off"
+                    assert util.bits_equal(out, ora), (renderer, S)
+                    assert ds.stats().n_rays == n_rays
+                par = abi.make_params(W, H, abi.RENDERER_PATHTRACER, samples_per_side=2, num_of_rays=2, max_depth=3, rr_limit=2,
+                                      path_state=45, path_seq=54)
+                ora, _ = oracle.render(scene, cam, par, sqr_mode=oracle.SQR_MUL)
+                out = ds.render(cam, par)
+                assert np.all(util.rel_err(out, ora) <= 1e-5)
+    finally:
+        dev.set_tuning("cull", saved)
+        oracle.set_sqr_mode(oracle.SQR_POW)
 
 
 def _dome_world(dome, dome_material, n_small, seed, planes=()):

@@ -32,7 +32,7 @@ for name in sys.argv[1:] or ["c3n10"]:
     fused, fused_hit, q12 = (q[12] >> 24) & 0xfffff, q[12] >> 44, q[12] & 0xffffff
     print(f"  leaf rounds carrying the parent's next child: {fused}, of which it was there when the family returned: {fused_hit}")
     print(f"{name}: kernel {st.kernel_ms:.3f} ms, rays {st.n_rays}, units {q[9]}, rounds {q[8]} (leaf {q12}), "
-          f"children traced {q[14]}, rays committed {q[13]}, most rounds in one pixel {q[15]}")
+          f"children traced {q[14] & ((1 << 40) - 1)} (leaf rounds with a fused ray whose family did not complete: {q[14] >> 40}), rays committed {q[13]}, most rounds in one pixel {q[15]}")
     for n, v in zip(names, list(q)[1:8]):
         print(f"  {n:22s} {v / 1e6:10.2f} Mcycles  {100 * v / tot:5.1f} %   {v / rounds:8.0f} cycles / round")
     ds.close()
