@@ -341,8 +341,12 @@ static inline void pt_make_plan(const PtSceneFacts &s, const pt_camera *cam, con
   if (pl.q_alt) {
     pl.q_tail_budget = t.q_tail_budget >= 0 ? (int)t.q_tail_budget : PT_Q_TAIL_BUDGET_DEFAULT;
     pl.q_few_lanes = t.q_few_lanes >= 0 ? (int)t.q_few_lanes : PT_Q_FEW_LANES_DEFAULT;
-    pl.handover_cap = (int)std::min<long long>(pl.npix, PT_HANDOVER_CAP);
-    pl.handover_doubles = (size_t)pl.handover_cap * (size_t)(PT_PLAN_HANDOVER_HEADER + 20 * std::max(p->max_depth, 1));
+    {  // records of PT_PLAN_HANDOVER_HEADER + 20 doubles per node of the deepest stack: at most PT_HANDOVER_CAP of them and 256 MB
+      const size_t rec = (size_t)(PT_PLAN_HANDOVER_HEADER + 20 * std::max(p->max_depth, 1));
+      const long long by_bytes = std::max<long long>(1024, (long long)(((size_t)256 << 20) / (rec * sizeof(double))));
+      pl.handover_cap = (int)std::min<long long>(std::min<long long>(pl.npix, PT_HANDOVER_CAP), by_bytes);
+      pl.handover_doubles = (size_t)pl.handover_cap * rec;
+    }
     int wgq = pl.q_home == 1 ? std::min<int>(3, (int)(PT_LDS_BUDGET / q_frame_bytes)) : 2;
     if (t.q_wg_per_cu > 0) wgq = (int)t.q_wg_per_cu;
     pl.grid_q = (int)std::max<long long>(1, std::min<long long>(want, (long long)s.n_cu * wgq));
