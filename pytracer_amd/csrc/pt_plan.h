@@ -366,7 +366,10 @@ static inline void pt_make_plan(const PtSceneFacts &s, const pt_camera *cam, con
       }
       const int ns = p->samples_per_side > 0 ? p->samples_per_side * p->samples_per_side : 1;
       pl.q_budget_per_flagged = mean * (double)ns / ((double)pl.grid_q * B);
-      pl.q_budget_min = 32;
+      // (never below N + 2: the primary ray, the root's N children and one more -- a pixel that gets there has a child that
+      //  scatters, and on a frame with fewer flagged pixels than lanes, where every pixel has had a lane from the start, the
+      //  tree kernel is where it belongs: C3 N = 10 1.32 -> 1.25 ms with the one-queue kernel in front, profiles/r05_tree_vs_queue.txt)
+      pl.q_budget_min = p->num_of_rays + 2;
     }
   }
   if (pl.path_tiled) {  // first pass (pt_tile_kernel<PATHTRACER>): one wave per 8x8 region
@@ -460,7 +463,7 @@ static inline void pt_make_plan(const PtSceneFacts &s, const pt_camera *cam, con
     // heavy pixels: profiles/r05_tree_vs_queue.txt):
     //   tree kernel       F x tT,  tT = 4.5 + 0.045 min(R, 500)   (R = sum of N^d, the rays of a full tree: one pixel at a
     //                     time on each of the 8 n_cu resident waves, a handful of rounds per family of children)
-    //   one-queue kernel  min(R, 100) x step + F x tQ,  step = 6 + 0.02 n_shapes us: the chain of its deepest lane -- which,
+    //   one-queue kernel  min(R, 80) x step + F x tQ,  step = 6 + 0.02 n_shapes us: the chain of its deepest lane -- which,
     //                     since round 5, ends at the budget and goes on in the tree kernel at a sixth of the time per ray: a
     //                     frame of full trees (R = 1 111) costs under a millisecond on top of its throughput, where round 4
     //                     paid R x step = 7 ms --, tQ = (2 + 0.01 n_shapes)(1 + R / 800)
@@ -478,7 +481,7 @@ static inline void pt_make_plan(const PtSceneFacts &s, const pt_camera *cam, con
       const double step_ns = (6.0 + 0.02 * fit_shapes) * 1e3 * (pl.q_home != 0 ? 1.0 : 1.3);  // (all frames in HBM: measured on D = 4 ... 8)
       const double t_tree = (4.5 + 0.045 * std::min(tree_rays, 500.0)) * (2048.0 / (8.0 * s.n_cu));
       const double t_queue = (2.0 + 0.01 * fit_shapes) * (1.0 + tree_rays / 800.0);
-      if (t_tree > t_queue) pl.q_min = (long long)std::min(1e15, 1.1 * std::min(tree_rays, 100.0) * step_ns / (t_tree - t_queue));
+      if (t_tree > t_queue) pl.q_min = (long long)std::min(1e15, 1.1 * std::min(tree_rays, 80.0) * step_ns / (t_tree - t_queue));
       if (t.q_min_flagged >= 0) pl.q_min = t.q_min_flagged;
       if (t.qchoice == 2) pl.q_min = 0;
     }

@@ -72,6 +72,9 @@ def main():
     args = ap.parse_args()
     for name in args.names:
         sample = name.endswith(":sample")  # e.g. c4:sample = the same configuration under PT_PCG_SAMPLE
+        tree_only = name.endswith(":tree")  # num_of_rays > 1: the tree kernel renders the frame alone (qchoice 0)
+        from pytracer_amd import device as _dev
+        _dev.set_tuning("qchoice", 0 if tree_only else int(os.environ.get("PTRACE_QCHOICE", "1")))
         ns, plane, wide, W, H, kw = CONFIGS[name.split(":")[0]]
         kw = dict(kw)
         if sample:

@@ -49,7 +49,7 @@ done <<'CFG'
 c3|c3|pt_path_regions_kernel|pmc_c3_second_pass.json|C3, PT_PCG_PIXEL
 c3s|c3:sample|pt_path_regions_kernel|pmc_c3_second_pass_sample.json|C3, PT_PCG_SAMPLE
 c4s|c4:sample|pt_path_regions_kernel|pmc_c4_second_pass_sample.json|C4: 3840x2160, 256 spheres, D = 5, spp 64, PT_PCG_SAMPLE
-tree|c3n10|pt_path_tree_kernel|pmc_c3n10_tree.json|C3 scene, PathTracer N = 10, D = 3, S = 1: the CLI's defaults
+tree|c3n10:tree|pt_path_tree_kernel|pmc_c3n10_tree.json|C3 scene, PathTracer N = 10, D = 3, S = 1: the CLI's defaults, the tree kernel rendering the frame alone (qchoice 0; at its 29 k flagged pixels the device lets the one-queue kernel start the frame since round 5)
 c2n10|c2n10|pt_path_flagged_kernel|pmc_c2n10_flagged.json|C2 scene with its ground plane, PathTracer N = 10, D = 3, S = 1: 490 k flagged pixels, the device picks the one-queue kernel
 pl|pl|pt_tile_kernel<3, 3, false, false|pmc_pointlight_tile.json|C2 scene + two point lights, PointLightRenderer: primary + shadow rays
 c3ortho|c3ortho|pt_path_regions_kernel|pmc_c3ortho_second_pass.json|C3 scene through an orthogonal camera: first pass with beams, second pass by regions
