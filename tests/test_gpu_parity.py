@@ -673,7 +673,9 @@ def test_random_scenes_match_oracle(dev, oracle, seed):
             else:
                 assert util.bits_equal(out, ora), f"seed {seed} renderer {renderer} S={S}: max rel {util.rel_err(out, ora).max()}"
                 assert ds.stats().n_rays == n_rays
-        par = abi.make_params(W, H, abi.RENDERER_PATHTRACER, samples_per_side=2, num_of_rays=1 + seed % 3, max_depth=1 + seed % 4,
+        # (PT_FUZZ_RAYS: more rays per hit than the default 1 - 3, for runs that force the num_of_rays > 1 kernels' hand-over)
+        n_rays_fuzz = int(os.environ.get("PT_FUZZ_RAYS", "0")) or 1 + seed % 3
+        par = abi.make_params(W, H, abi.RENDERER_PATHTRACER, samples_per_side=2, num_of_rays=n_rays_fuzz, max_depth=1 + seed % 4,
                               rr_limit=seed % 3, path_state=45 + seed, path_seq=54)
         ora, n_rays = oracle.render(scene, cam, par, sqr_mode=oracle.SQR_MUL)
         out = ds.render(cam, par)
