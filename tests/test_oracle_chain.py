@@ -62,3 +62,26 @@ def test_pow_and_mul_modes_render_the_same_C5_frame(oracle):
     cam = flatten.flatten_camera(scenes.synthetic_camera(W, H))
     differing, n_pow, n_mul = _both(oracle, scene, cam, abi.make_params(W, H, abi.RENDERER_FLAT))
     assert differing == 0 and n_pow == n_mul
+
+
+def test_oracle_ray_image_adds_up_to_the_ray_count(oracle):
+    """pto_set_ray_image (diagnostics for tools/ray_histogram.py: rays per pixel of a frame): the counts it writes add up to
+    what pto_render returns, a pixel whose primary ray scatters nothing counts 1, and nothing of it changes the frame."""
+    import ctypes as C
+
+    W, H = 96, 54
+    flat = flatten.flatten_world(scenes.synthetic_world(32, with_plane=True))
+    cam = flatten.flatten_camera(scenes.synthetic_camera(W, H))
+    par = abi.make_params(W, H, abi.RENDERER_PATHTRACER, samples_per_side=1, num_of_rays=4, max_depth=3, rr_limit=3,
+                          path_state=45, path_seq=54)
+    plain, n0 = oracle.render(flat, cam, par, sqr_mode=oracle.SQR_MUL)
+    img = np.zeros((H, W), dtype=np.uint32)
+    oracle.lib().pto_set_ray_image.argtypes = [C.c_void_p]
+    oracle.lib().pto_set_ray_image(img.ctypes.data_as(C.c_void_p))
+    try:
+        out, n = oracle.render(flat, cam, par, sqr_mode=oracle.SQR_MUL)
+    finally:
+        oracle.lib().pto_set_ray_image(None)
+        oracle.set_sqr_mode(oracle.SQR_POW)
+    assert n == n0 and int(img.sum()) == n and img.min() >= 1 and img.max() <= 1 + 4 + 16 + 64
+    assert np.array_equal(out.view(np.uint8), plain.view(np.uint8))
