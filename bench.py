@@ -1,27 +1,28 @@
 #!/usr/bin/env python3
-"""bench.py — benchmark of the MI355X ray-trace/shade path (BASELINE.json metric: Mray/s, ms/frame).
+"""bench.py -- benchmark of the MI355X ray-trace/shade path (BASELINE.json metric: Mray/s, ms/frame).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
-N = 1 — workload = BASELINE.json configs[1] ("C2"): 1280x720, 32 spheres + 1 checkered plane, FlatRenderer,
-pixel-centre rays (S=0), synthetic scene of SURVEY.md §8(d).  One *step* = one frame through the C-ABI
+The LAST line on stdout is ONE compact JSON object (a fixed set of keys, < 8 KB: tests/test_bench_helpers.py); everything else
+the run measured goes to bench_detail.json next to this script and, as one line, to stderr.
+
+N = 1 -- workload = BASELINE.json configs[1] ("C2"): 1280x720, 32 spheres + 1 checkered plane, FlatRenderer,
+pixel-centre rays (S=0), synthetic scene of SURVEY.md 8(d).  One *step* = one frame through the C-ABI
 (`pt_render_device`) with the scene resident in HBM and the output left in HBM (fp32 RGB, the reference's PFM
-precision: 12 B/pixel).  Every timed launch carries its own hipEvent pair IN the dispatch (no barrier
-packets), so `roofline.avg_kernel_ms` is the mean over all K timed launches.
+precision: 12 B/pixel).  The headline loop runs with the dome shortcut OFF: every primary ray is generated and handed to a
+world query, so `value` counts only queried rays; the library's default frame (shortcut on) is the side row
+`frame_with_dome_shortcut`, and `ms_per_frame_at_c_abi` is kernel + D2H through `pt_render`.
 
 N > 1 (one rank per GPU, RCCL; under `torch.distributed.run`, or by itself: `python bench.py --gpus N` starts its
-own N ranks before touching the GPU and relays rank 0's line) — workload = configs[3] ("C4"): ONE 3840x2160 frame,
+own N ranks before touching the GPU and relays rank 0's line) -- workload = configs[3] ("C4"): ONE 3840x2160 frame,
 256 spheres, PathTracer depth 5, 64 samples per pixel, STRONG-scaled: rows are cut in interleaved 8-row blocks,
 every rank renders its blocks, and the frame is assembled on rank 0 by one batched RCCL point-to-point group per
-frame (one transfer per remote rank + a strided placement copy; double-buffered: the gather of frame i overlaps
-the render of frame i+1).  The gather is INSIDE the timed region: `value` = rays of the whole frame x K / wall
-time.  This is NOT the N = 1 line's workload, so the line carries its own one-GPU figure (`n1_same_workload`: the
-same frame loop on rank 0 alone, same clock) with `speedup` and `parallel_efficiency` against it, `ranks_seen`
-(all-reduced) and `backend`; the same loop without the gather, with the dome shortcut off and under the other PCG
-mode are side rows.  After every phase the ranks all-reduce an error flag, so a rank's exception ends the job with
-a line carrying `error` instead of a watchdog abort.
-
-Prints ONE JSON line (rank 0).
+frame, INSIDE the timed region: `value` = rays that went through a world query x K / wall time.  The whole-shard gather (one
+transfer per remote rank) is measured first and completely -- loop, check against rank 0 alone, the same loop on one GPU, the
+oracle check -- then the sparse gather; the headline is the faster, and the whole-shard row if the sparse one fails or overruns
+its deadline (`gather.fallback_reason`).  Every phase runs under a deadline (PT_BENCH_PHASE_S); a phase that overruns ends the
+job with the line measured so far (or an `error` line when nothing is complete yet).  The estimated wall time is printed to
+stderr up front.
 """
 import argparse
 import datetime
@@ -257,11 +258,12 @@ def kernel_row(ds, cam, par, out, reps, flat):
     t = float(np.median(ms)) * 1e-3
     n_sph = int((flat.kind == abi.SHAPE_SPHERE).sum())
     n_pl = flat.n_shapes - n_sph
-    return {"Mray_s": st.n_rays / t / 1e6, "ms_per_frame": t * 1e3, "rays_per_frame": int(st.n_rays),
-            "traced_ray_fraction": 1.0 - st.n_rays_resolved / max(1, st.n_rays),
-            "traced_Mray_s": (st.n_rays - st.n_rays_resolved) / t / 1e6,
-            "ray_shape_tests_per_s": st.n_rays * flat.n_shapes / t,
-            "algorithmic_equivalent_TFLOP_s": st.n_rays * (n_sph * FLOP_PER_SPHERE_TEST + n_pl * FLOP_PER_PLANE_TEST) / t / 1e12}
+    traced = int(st.n_rays - st.n_rays_resolved)
+    # (rates count only rays that went through a world query; the rays the dome shortcut settled are listed beside them)
+    return {"traced_Mray_s": traced / t / 1e6, "ms_per_frame": t * 1e3, "rays_traced_per_frame": traced,
+            "rays_settled_without_a_query_per_frame": int(st.n_rays_resolved),
+            "ray_shape_tests_per_s": traced * flat.n_shapes / t,
+            "algorithmic_equivalent_TFLOP_s": traced * (n_sph * FLOP_PER_SPHERE_TEST + n_pl * FLOP_PER_PLANE_TEST) / t / 1e12}
 
 
 def in_flight_row(ds, cam, par, out, frames):
@@ -613,6 +615,7 @@ def in_flight_rows(flat, cam, par, steps, local_rank, rays_per_step, pmc, n_simd
         with FramePipeline(flat, n_in_flight=n, device=local_rank) as pipe:
             pipe.set_count_rays(False)
             pipe.set_timing(False)
+            pipe.set_dome_shortcut(False)  # (the headline's frames: every primary ray traced)
             outs = [torch.empty((H, W, 3), dtype=torch.float32, device=f"cuda:{local_rank}") for _ in range(n)]
             for i in range(2 * n):
                 pipe.submit(cam, par, outs[i % n])
@@ -648,6 +651,11 @@ def run_single(args, local_rank):
     par = abi.make_params(W, H, abi.RENDERER_FLAT, out_format=abi.OUT_F32)
     loop = ShardedFrameLoop(ds, cam, par, row_block=8)
 
+    # The headline loop runs with the dome shortcut OFF (pt_set_dome_shortcut(0)): every primary ray of the frame is generated and
+    # handed to a world query, which is what SURVEY.md 8(d) counts ("all rays passed to a world query").  The product's default
+    # (shortcut on: tiles that can only see the sphere around the camera are settled without rays, exact) is the side row
+    # `frame_with_dome_shortcut`, whose rate counts only the rays that were traced.
+    ds.set_dome_shortcut(False)
     ds.set_count_rays(True)
     for i in range(max(1, args.warmup)):
         loop.step(i, gather=False)
@@ -657,9 +665,11 @@ def run_single(args, local_rank):
     # rays per frame are counted (in-kernel counter) during warm-up; the workload is deterministic, so the timed
     # steps run without the counter: one step == exactly one render-kernel launch
     rays_per_step, resolved = int(st.n_rays), int(st.n_rays_resolved)
+    if resolved != 0:
+        raise RuntimeError(f"{resolved} rays were settled without a world query although the dome shortcut is off")
     n_wg = st.grid
-    # the headline: K frames back to back -- the K-step loop REPEATED (20 launches of 14 us are a 0.3 ms
-    # timed region); `value` / `ms_per_step` are the MEDIAN repeat, min and max beside them.  Before the first timed loop the
+    # the headline: K frames back to back -- the K-step loop REPEATED (20 launches of 15 us are a 0.3 ms timed region);
+    # `value` / `ms_per_step` are the MEDIAN repeat, min and max in the detail file.  Before the first timed loop the
     # same launches run untimed for >= 30 ms (clocks), and the loop is repeated until >= 20 ms have been timed (at least
     # --repeats times): K stays what --steps says for every loop
     ds.set_count_rays(False)
@@ -671,7 +681,7 @@ def run_single(args, local_rank):
     elapsed = float(np.median(elapsed_all))
     # the same loop with TEN TIMES the steps (a few repeats): what a timed region costs beyond its frames -- the first launch's
     # way to the GPU and the last synchronisation's way back, ~16 us per region -- divides by K: at the driver's K = 20 it is
-    # 0.8 us of every step, at K = 200 a tenth of that.  Reported so that the line explains its own K.
+    # 0.8 us of every step, at K = 200 a tenth of that.  Reported so that the detail file explains its own K.
     k10 = 10 * args.steps
     el10 = float(np.median([timed_loop(ds, loop, k10, None, False, events=False)[0] for _ in range(max(3, min(repeats, 400 // max(1, args.steps))))]))
     parity = parity_check(flat, cam, par, loop.image())  # the frame those loops left in HBM, against the oracle's
@@ -680,15 +690,28 @@ def run_single(args, local_rank):
     avg_kernel_s = bracketed_loop(ds, loop, args.steps, repeats)  # the same K launches between one event pair on their stream (median of the repeats)
     ms_per_step = elapsed / args.steps * 1e3
 
-    # the same frames with the dome shortcut off: every primary ray generated and traced
-    ds.set_dome_shortcut(False)
-    for i in range(3):
-        loop.step(i, gather=False)
-    n_dome_off = max(5, args.steps // 10)  # (a side row: few launches, so that the bench command's launches of this kernel
-    #                                          under rocprofv3 are essentially the timed ones)
-    el_off, _, _ = timed_loop(ds, loop, n_dome_off, None, False, events=False)
-    _, k_off, n_off = timed_loop(ds, loop, n_dome_off, None, False, events=True)
-    ds.set_dome_shortcut(True)
+    # the product's default: the same frame with the dome shortcut on (a side row: few launches, so that the bench command's
+    # launches of this kernel under rocprofv3 are essentially the headline's)
+    dome_row = None
+    if not args.headline_only:
+        ds.set_dome_shortcut(True)
+        ds.set_count_rays(True)
+        for i in range(3):
+            loop.step(i, gather=False)
+        fence(None)
+        ds.sync()
+        st_on = ds.stats()
+        traced_on = int(st_on.n_rays) - int(st_on.n_rays_resolved)
+        n_dome_on = max(5, args.steps // 10)
+        el_on = float(np.median([timed_loop(ds, loop, n_dome_on, None, False, events=False)[0] for _ in range(5)]))
+        parity_on = parity_check(flat, cam, par, loop.image())
+        dome_row = {"ms_per_frame": el_on / n_dome_on * 1e3, "rays_traced_per_frame": traced_on,
+                    "rays_settled_without_a_query_per_frame": int(st_on.n_rays_resolved),
+                    "traced_Mray_s": traced_on * n_dome_on / el_on / 1e6, "steps": n_dome_on, "bit_identical": parity_on["bit_identical"],
+                    "note": "the library's default (pt_set_dome_shortcut(1)): tiles whose only possible hit is the sphere around the camera "
+                            "are settled without generating rays (exact, DESIGN.md 4 item 8); only the traced rays are counted in the rate"}
+        ds.set_dome_shortcut(False)
+        ds.set_count_rays(False)
 
     n_cu, clock_khz = device_info(local_rank)
     n_simd = n_cu * 4
@@ -701,7 +724,7 @@ def run_single(args, local_rank):
     roofline = {
         "bound": "valu_issue",
         "achieved": None, "peak": None, "unit": "T lane-op/s (executed VALU lane-operations, any type)", "frac": None, "traffic": None,
-        "kernel": "pt_tile4_kernel<FLAT> (16x16 tiles, four pixels per lane, culled shape lists, hoisted scale+translate tests)",
+        "kernel": "pt_tile4_kernel<FLAT> (16x16 tiles, four pixels per lane, culled shape lists, hoisted scale+translate tests), dome shortcut off",
         "avg_kernel_ms": avg_kernel_s * 1e3, "launches_timed": args.steps * repeats,
         "avg_kernel_ms_method": "K launches back to back between one HIP event pair recorded on their stream / K (rocprofv3's "
                                 "kernel trace of the same command shows the same average for launches run back to back)",
@@ -777,7 +800,7 @@ def run_single(args, local_rank):
                        "frac": alg_bytes / avg_kernel_s / 1e9 / PEAK_HBM_GBS, "algorithmic_bytes_per_launch": alg_bytes,
                        "note": "12 B per pixel written + the scene once per workgroup: not the bound"}
     result = {
-        "metric": "Mray/s (primary+shadow) at 1280x720 per GPU, C2: 32 spheres + 1 plane, FlatRenderer",
+        "metric": "Mray/s (primary+shadow; rays handed to a world query) at 1280x720 per GPU, C2: 32 spheres + 1 plane, FlatRenderer",
         "value": rays_per_step * args.steps / elapsed / 1e6,
         "unit": "Mray/s",
         "n_gpus": 1,
@@ -803,30 +826,185 @@ def run_single(args, local_rank):
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": f"C2 flat {W}x{H}, 32 spheres + 1 plane, S=0, fp32 RGB output resident in HBM",
+        "config": {"workload": f"C2 flat {W}x{H}, 32 spheres + 1 plane, S=0, every primary ray traced (dome shortcut off), fp32 RGB resident in HBM",
                    "width": W, "height": H, "n_shapes": flat.n_shapes, "renderer": "FlatRenderer"},
         "ray_shape_tests_per_s": rays_per_step * flat.n_shapes * args.steps / elapsed,
-        "traced_ray_fraction": 1.0 - resolved / max(1, rays_per_step),
-        "traced_ray_note": "rays of tiles whose only possible hit is the sphere around the camera are resolved without being "
-                           "generated (exact, DESIGN.md 4 item 8) and counted in `value`; this is the share that was traced",
-        "dome_off": {"value": rays_per_step * n_dome_off / el_off / 1e6, "unit": "Mray/s",
-                     "ms_per_step": el_off / n_dome_off * 1e3, "per_launch_event_pair_ms": k_off / max(1, n_off), "steps": n_dome_off,
-                     "note": "same frames with the shortcut switched off (pt_set_dome_shortcut(0)): every primary ray traced"},
+        "rays_per_step": rays_per_step,
+        "value_note": "every ray counted in `value` was generated and handed to a world query (dome shortcut off for the headline "
+                      "loop: pt_set_dome_shortcut(0)); the library's default frame is frame_with_dome_shortcut",
+        "frame_with_dome_shortcut": dome_row,
         "roofline": roofline,
     }
     if not parity["bit_identical"]:  # a fast frame that is not the reference's frame is not a result
         result["error"] = f"parity_check failed: the timed frame differs from the oracle's in {parity.get('pixels_differing', '?')} pixels"
         result["value_unchecked"], result["value"] = result["value"], None
-    ds.close()
-    if not args.no_in_flight:  # measured by THIS run (round 4 pasted a committed line here): a few hundred frames, behind the headline loops
+    elif dome_row is not None and not dome_row["bit_identical"]:
+        result["error"] = "parity_check failed: the frame rendered with the dome shortcut differs from the oracle's"
+        result["value_unchecked"], result["value"] = result["value"], None
+    # in-flight rows: the headline's frames (shortcut off) on 2 and 4 streams
+    if not args.no_in_flight:  # measured by THIS run: a few hundred frames, behind the headline loops
         result["frames_in_flight"] = in_flight_rows(flat, cam, par, args.in_flight_steps, local_rank, rays_per_step, pmc if fresh(pmc) else None,
                                                     n_simd, clock_hz)
+    ds.close()
     if not args.no_extras:
         result["extra"] = extra_rows(local_rank)
         result["boundary"] = boundary_rows(flat, local_rank, rays_per_step)
     if not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(flat)
-    print(json.dumps(result), flush=True)
+    emit(result, compact_single(result))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The result line.  bench.py's LAST stdout line is a COMPACT object (target <= 4 KB, hard limit 8 KB: tests/test_bench_helpers.py)
+# with a fixed set of keys; everything else the run measured goes to bench_detail.json next to this script and to stderr.
+# (Rounds 1-5 printed everything on the one line; it grew to 21.7 KB and the driver could no longer read it.)
+COMPACT_LIMIT = 8192
+DETAIL_NAME = "bench_detail.json"
+
+
+def _pick(d, keys):
+    return {k: d.get(k) for k in keys} if isinstance(d, dict) else None
+
+
+def _short(x, n=200):
+    return x if x is None or len(str(x)) <= n else str(x)[: n - 3] + "..."
+
+
+def compact_roofline(r):
+    if not isinstance(r, dict):
+        return None
+    out = _pick(r, ("bound", "achieved", "peak", "unit", "frac"))
+    out["frac_bounds"] = r.get("frac_bounds_from_disassembly")
+    out["traffic"] = r.get("traffic")
+    out["algorithmic_bytes"] = (r.get("hbm") or {}).get("algorithmic_bytes_per_launch")
+    out["hbm_frac"] = (r.get("hbm") or {}).get("frac")
+    out["kernel"] = _short(r.get("kernel"), 120)
+    out["avg_kernel_ms"] = r.get("avg_kernel_ms")
+    out["code_hash_matches_loaded_library"] = (r.get("executed") or {}).get("code_hash_matches_loaded_library")
+    if r.get("reason_frac_is_null"):
+        out["reason_frac_is_null"] = _short(r["reason_frac_is_null"], 240)
+    return out
+
+
+def compact_cpu_baseline(c):
+    if not isinstance(c, dict):
+        return None
+    out = _pick(c, ("value", "unit", "cores", "kind", "ms_per_frame", "one_core_Mray_s", "cpu_model"))
+    out["sample"] = _short(c.get("sample"), 160)
+    out["interpreted_Mray_s"] = (c.get("interpreted") or {}).get("value")
+    return out
+
+
+def compact_single(full):
+    """The N = 1 line: BASELINE.json's metric on C2 plus `roofline` and `cpu_baseline`, nothing that is not a number, a short
+    name or a flag."""
+    dome = full.get("frame_with_dome_shortcut")
+    out = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                    "vs_baseline", "dtype", "data")}
+    out["config"] = _pick(full.get("config"), ("workload", "width", "height", "n_shapes", "renderer"))
+    out["rays_per_step"] = full.get("rays_per_step")
+    out["ray_shape_tests_per_s"] = full.get("ray_shape_tests_per_s")
+    out["parity_check"] = _pick(full.get("parity_check"), ("bit_identical",))
+    out["roofline"] = compact_roofline(full.get("roofline"))
+    out["cpu_baseline"] = compact_cpu_baseline(full.get("cpu_baseline"))
+    out["ms_per_frame_at_c_abi"] = ((full.get("boundary") or {}).get("value_at_c_abi") or {}).get("ms_per_frame")
+    out["frame_with_dome_shortcut"] = _pick(dome, ("ms_per_frame", "rays_traced_per_frame", "traced_Mray_s", "bit_identical"))
+    out["code_hash"] = (full.get("code_hash") or "")[:16] or None
+    if full.get("error"):
+        out["error"] = _short(full["error"], 400)
+    return out
+
+
+def compact_multi(full):
+    """The N > 1 line: the C4 frame strong-scaled over the ranks; rates count only rays that went through a world query."""
+    out = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                    "vs_baseline", "dtype", "data", "ranks_seen", "backend")}
+    out["config"] = _pick(full.get("config"), ("workload", "width", "height", "n_shapes", "renderer", "pcg_mode", "frames_in_flight_per_rank"))
+    out["rays_traced_per_frame"] = full.get("rays_traced_per_frame")
+    out["ms_per_frame_without_gather"] = (full.get("without_gather") or {}).get("ms_per_step")
+    g = full.get("gather") or {}
+    out["gather"] = {"used": g.get("used"), "ms_per_frame": g.get("probe_ms_per_frame"), "bytes_per_frame_whole": g.get("gather_bytes_per_frame"),
+                     "bytes_per_frame_sent": full.get("gather_bytes_per_frame_sent"), "fallback_reason": _short(g.get("fallback_reason"), 240)}
+    out["gather_check"] = full.get("gather_check")
+    oc = full.get("oracle_check")
+    out["parity_check"] = _pick(oc, ("checked", "bit_identical", "pixels_beyond_1e-5", "rays_match")) if isinstance(oc, dict) else None
+    n1 = full.get("n1_same_workload")
+    out["n1_same_workload"] = _pick(n1, ("value", "ms_per_step")) if isinstance(n1, dict) else None
+    out["speedup"] = full.get("speedup")
+    out["rank_share_imbalance"] = full.get("rank_share_imbalance")
+    a = full.get("at_1280x720")
+    out["at_1280x720"] = _pick(a, ("value", "ms_per_step", "speedup")) if isinstance(a, dict) else None
+    r = full.get("c2_replicas")
+    out["c2_replicas"] = _pick(r, ("value", "ms_per_step")) if isinstance(r, dict) else None
+    out["code_hash"] = (full.get("code_hash") or "")[:16] or None
+    if full.get("error"):
+        out["error"] = _short(full["error"], 400)
+    return out
+
+
+def detail_path():
+    """Where the detail file goes: next to this script; if that is not writable, under gpurun_out/ or the temp directory."""
+    import tempfile
+
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out"), tempfile.gettempdir()):
+        try:
+            os.makedirs(d, exist_ok=True)
+            probe = os.path.join(d, ".bench_detail_probe")
+            with open(probe, "w"):
+                pass
+            os.remove(probe)
+            return os.path.join(d, DETAIL_NAME)
+        except OSError:
+            continue
+    return None
+
+
+def compact_dumps(compact):
+    """-> the JSON text of the compact line, bounded: floats to 6 significant digits; should it still exceed COMPACT_LIMIT (it
+    cannot with the fixed key set, but a line that does not parse loses the round), optional sub-objects are dropped one by one."""
+    def rnd(x):
+        if isinstance(x, float):
+            return float(f"{x:.6g}") if x == x and abs(x) != float("inf") else None
+        if isinstance(x, dict):
+            return {k: rnd(v) for k, v in x.items()}
+        if isinstance(x, (list, tuple)):
+            return [rnd(v) for v in x]
+        return x
+
+    obj = rnd(compact)
+    text = json.dumps(obj, separators=(",", ":"))
+    for k in ("at_1280x720", "c2_replicas", "n1_same_workload", "frame_with_dome_shortcut", "gather", "config"):
+        if len(text) < COMPACT_LIMIT:
+            break
+        obj.pop(k, None)
+        obj["truncated"] = True
+        text = json.dumps(obj, separators=(",", ":"))
+    return text
+
+
+def write_detail(full):
+    """-> where the detail file was written (relative to this script when next to it), or a reason why not."""
+    path = detail_path()
+    if not path:
+        return "not written: no writable directory"
+    try:
+        with open(path, "w") as f:
+            json.dump(full, f, indent=1)
+            f.write("\n")
+    except OSError as e:
+        return f"not written: {e}"
+    return os.path.relpath(path, ROOT) if path.startswith(ROOT) else path
+
+
+def emit(full, compact):
+    """Detail -> bench_detail.json + stderr; the compact line -> stdout, LAST."""
+    compact["detail_file"] = write_detail(full)
+    try:
+        print("[bench detail] " + json.dumps(full), file=sys.stderr, flush=True)
+    except (OSError, ValueError):
+        pass
+    sys.stdout.flush()
+    print(compact_dumps(compact), flush=True)
 
 
 class SceneGroup:
@@ -883,29 +1061,87 @@ def progress(msg):
         print(f"[bench {time.perf_counter() - _T0:7.1f} s] {msg}", file=sys.stderr, flush=True)
 
 
+class Watchdog:
+    """A per-phase deadline on every rank (a thread; the main thread may sit in a collective that never returns -- torch releases
+    the GIL there).  When a phase overruns: rank 0 prints the FALLBACK line if one has been stashed (the whole-shard gather's
+    measurement, complete and checked, marked with what failed) or an `error` line, and every rank leaves with os._exit -- status
+    0 with a fallback (all ranks know whether one exists: it is stashed behind an all-reduce), 1 without.  No rank re-execs."""
+
+    def __init__(self, rank):
+        import threading
+
+        self.rank = rank
+        self.lock = threading.Lock()
+        self.phase, self.deadline = None, None
+        self.fallback = None       # rank 0: (full, compact) of the measurement that is already complete
+        self.have_fallback = False  # every rank
+        self.error_stub = {"metric": "Mray/s", "value": None, "unit": "Mray/s"}
+        self.thread = threading.Thread(target=self._watch, daemon=True)
+        self.thread.start()
+
+    def arm(self, phase, seconds):
+        with self.lock:
+            self.phase, self.deadline = phase, time.perf_counter() + seconds
+
+    def disarm(self):
+        with self.lock:
+            self.phase, self.deadline = None, None
+
+    def _watch(self):
+        while True:
+            time.sleep(0.5)
+            with self.lock:
+                phase, deadline = self.phase, self.deadline
+            if deadline is None or time.perf_counter() < deadline:
+                continue
+            why = f"phase '{phase}' exceeded its deadline"
+            if self.rank == 0:
+                print(f"[bench] {why}: leaving", file=sys.stderr, flush=True)
+                if self.fallback is not None:
+                    full, compact = self.fallback
+                    full = dict(full)
+                    full["gather"] = dict(full.get("gather") or {}, used="whole", fallback_reason=f"{why} (the job ended there)")
+                    full["phases_not_run"] = why
+                    emit(full, compact_multi(full))
+                else:
+                    stub = dict(self.error_stub, error=why)
+                    emit(stub, dict(stub))
+            else:
+                time.sleep(3.0)  # (rank 0 prints first)
+            os._exit(0 if self.have_fallback else 1)
+
+
+PHASE_DEADLINE_S = float(os.environ.get("PT_BENCH_PHASE_S", "120"))
+
+
 class Agreement:
     """Ranks agree after every phase on whether all of them got through it: a rank that raised still enters this
     all-reduce, so the others learn of it here instead of waiting in the next collective until the watchdog ends
-    the job -- and rank 0 can still print its line (with `error`)."""
+    the job -- and rank 0 can still print its line (with `error`).  Every phase runs under the Watchdog's deadline."""
 
-    def __init__(self, dist):
+    def __init__(self, dist, watchdog=None):
         self.dist = dist
         self.error = None
         self.soft = {}
+        self.watchdog = watchdog
+        self.log = []  # (phase, seconds)
 
-    def attempt(self, phase, fn):
+    def attempt(self, phase, fn, deadline_s=None):
         """Like run(), but a failure is remembered as `soft[phase]` only: the job goes on (used for a choice that has a
         fallback)."""
         saved, self.error = self.error, None
-        ok = self.run(phase, fn)
+        ok = self.run(phase, fn, deadline_s)
         if not ok:
             self.soft[phase] = self.error
         self.error = saved
         return ok
 
-    def run(self, phase, fn):
+    def run(self, phase, fn, deadline_s=None):
         """Run `fn()` on this rank; -> True iff EVERY rank completed it (collective)."""
         progress(phase)
+        t0 = time.perf_counter()
+        if self.watchdog is not None:
+            self.watchdog.arm(phase, deadline_s or PHASE_DEADLINE_S)
         if self.error is None:
             try:
                 fn()
@@ -918,6 +1154,9 @@ class Agreement:
                 self.error = f"{phase}: another rank failed"
         except Exception as e:  # noqa: BLE001
             self.error = self.error or f"{phase}: agreement failed: {type(e).__name__}: {e}"[:400]
+        if self.watchdog is not None:
+            self.watchdog.disarm()
+        self.log.append((phase, time.perf_counter() - t0))
         return self.error is None
 
 
@@ -937,156 +1176,196 @@ def rank_spread(dist, values, world_size):
                 "per_rank": [float(v) for v in table[:, i]]} for i, k in enumerate(keys)}
 
 
-def sharded_workload(args, cfg, modes, ds, cam, rank, world_size, dist, agree, gather_sparse, steps):
-    """One frame of `cfg` strong-scaled over the ranks, per PCG mode: warm-up and ray count, the timed loop with and
-    without the gather, the per-phase probe, the dome-off side row, the gather check against rank 0 alone and the
-    same loop on ONE GPU by the same clock.  -> {mode: row dict} on rank 0 (None elsewhere)."""
+def choose_gather(whole_ms, sparse_ms, sparse_error):
+    """Which gather the headline uses, from what was measured: -> (used, fallback_reason).  The whole-shard gather (one padded
+    transfer per remote rank: the plainest use of RCCL) is measured FIRST and is what the line falls back on; the sparse one is
+    used only if it completed on every rank, assembled the same frame and was faster."""
+    if sparse_error:
+        return "whole", f"sparse failed: {sparse_error}"[:300]
+    if sparse_ms is None:
+        return "whole", "sparse not measured"
+    if whole_ms is None:
+        return "sparse", None
+    return ("sparse", None) if sparse_ms <= whole_ms else ("whole", None)
+
+
+def sharded_workload(args, cfg, mode, ds, cam, rank, world_size, dist, agree, gather_sparse, steps, full=True):
+    """One frame of `cfg` strong-scaled over the ranks under PCG mode `mode`, shards gathered sparse or whole: warm-up and ray
+    count, the timed loop with the gather; with `full` also the loop without the gather, the per-phase probe, the gather check
+    against rank 0 alone, the same loop on ONE GPU by the same clock and the oracle check.  Every rate counts only rays that
+    went through a world query.  -> row dict on rank 0 (None elsewhere, or when a phase failed)."""
     W, H = cfg["W"], cfg["H"]
-    rows, rays_frame, resolved_frame = {}, {}, {}
-    for mode in modes:
-        if agree.error is not None:
-            break
-        par = abi.make_params(W, H, out_format=abi.OUT_F32, pcg_mode=mode, **cfg["kw"])
-        loop = [None]
-        tag = f"{cfg['name']} {PCG_NAMES[mode]}"
+    rows = {}
+    par = abi.make_params(W, H, out_format=abi.OUT_F32, pcg_mode=mode, **cfg["kw"])
+    loop = [None]
+    tag = f"{cfg['name']} {PCG_NAMES[mode]} {'sparse' if gather_sparse else 'whole'} gather"
+    counts = {}
 
-        def warm():
-            loop[0] = ShardedFrameLoop(ds.scenes, cam, par, row_block=8, sparse=gather_sparse)
-            ds.set_count_rays(True)
-            ds.set_timing(True)
-            for i in range(max(2, args.warmup)):
-                loop[0].step(i, gather=True)
-            loop[0].finish()
-            fence(dist)
-            ds.sync()
-            st = ds.stats()
-            r = torch.tensor([int(st.n_rays), int(st.n_rays_resolved)], dtype=torch.int64, device="cuda")
-            dist.all_reduce(r, op=dist.ReduceOp.SUM)
-            rays_frame[mode], resolved_frame[mode] = int(r[0].item()), int(r[1].item())
+    def warm():
+        loop[0] = ShardedFrameLoop(ds.scenes, cam, par, row_block=8, sparse=gather_sparse)
+        ds.set_count_rays(True)
+        ds.set_timing(True)
+        for i in range(max(2, args.warmup)):
+            loop[0].step(i, gather=True)
+        loop[0].finish()
+        fence(dist)
+        ds.sync()
+        st = ds.stats()
+        r = torch.tensor([int(st.n_rays), int(st.n_rays_resolved)], dtype=torch.int64, device="cuda")
+        dist.all_reduce(r, op=dist.ReduceOp.SUM)
+        counts["rays"], counts["resolved"] = int(r[0].item()), int(r[1].item())
 
-        if not agree.run(f"warm-up {tag}", warm):
-            break
-        for gather in (True, False):
-            def timed():
-                elapsed, _, _ = timed_loop(ds, loop[0], steps, dist, gather, events=False)
-                _, kernel_ms, launches = timed_loop(ds, loop[0], max(2, steps // 2), dist, gather, events=True)
-                t = torch.tensor([elapsed, kernel_ms / max(1, launches)], dtype=torch.float64, device="cuda")
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                rows[(mode, gather)] = (float(t[0].item()), float(t[1].item()))
-
-            if not agree.run(f"timed loop {tag} gather={gather}", timed):
-                break
-        if agree.error is not None:
-            break
-
-        def phases():  # where a frame's time goes on every rank, phases one after the other (a measurement mode)
-            ds.set_count_rays(False)
-            ds.set_timing(False)
-            mine = loop[0].phase_probe(frames=4)
-            ds.set_timing(True)
-            rows[(mode, "phases")] = rank_spread(dist, mine, world_size)
-
-        if not agree.run(f"phase probe {tag}", phases):
-            break
-
-        def dome_off():  # the same frames with every primary ray generated and traced (no gather: a side row)
-            ds.set_dome_shortcut(False)
+    def close():
+        if loop[0] is not None:
+            if agree.watchdog is not None:  # (draining a loop whose gather failed on one rank may wait for that rank)
+                agree.watchdog.arm(f"closing the loop of {tag}", 60.0)
             try:
-                elapsed, _, _ = timed_loop(ds, loop[0], max(2, steps // 4), dist, False, events=False)
-            finally:
-                ds.set_dome_shortcut(True)
-            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+                loop[0].close()
+            except Exception:  # noqa: BLE001
+                pass
+            if agree.watchdog is not None:
+                agree.watchdog.disarm()
+
+    if not agree.run(f"warm-up {tag}", warm):
+        close()
+        return None
+    for gather in ((True, False) if full else (True,)):
+        def timed():
+            inject_failure(f"timed {'sparse' if gather_sparse else 'whole'}")
+            elapsed, _, _ = timed_loop(ds, loop[0], steps, dist, gather, events=False)
+            _, kernel_ms, launches = timed_loop(ds, loop[0], max(2, steps // 2), dist, gather, events=True)
+            t = torch.tensor([elapsed, kernel_ms / max(1, launches)], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            rows[(mode, "dome_off")] = (float(t[0].item()), max(2, steps // 4))
+            rows[("t", gather)] = (float(t[0].item()), float(t[1].item()))
 
-        if not agree.run(f"dome-off loop {tag}", dome_off):
-            break
+        if not agree.run(f"timed loop {tag} gather={gather}", timed):
+            close()
+            return None
 
-        def check_and_solo():
-            # the frame assembled on rank 0 must be bit-identical to the same frame rendered by one rank ...
-            loop[0].step(0, gather=True)
-            loop[0].finish()
-            fence(dist)
-            if rank == 0:
-                rows[(mode, "gather_bytes")] = loop[0].gather_bytes
+    def phases():  # where a frame's time goes on every rank, phases one after the other (a measurement mode)
+        ds.set_count_rays(False)
+        ds.set_timing(False)
+        mine = loop[0].phase_probe(frames=4)
+        ds.set_timing(True)
+        rows["phases"] = rank_spread(dist, mine, world_size)
+
+    if full and not agree.run(f"phase probe {tag}", phases):
+        close()
+        return None
+
+    def check_and_solo():
+        # the frame assembled on rank 0 must be bit-identical to the same frame rendered by one rank ...
+        loop[0].step(0, gather=True)
+        loop[0].finish()
+        fence(dist)
+        if rank == 0:
+            rows["gather_bytes"] = loop[0].gather_bytes
+            solo = ShardedFrameLoop(ds.scenes[:1], cam, par, row_block=8, solo=True)
+            if full:
                 # ... and the SAME workload on ONE GPU, by the same wall clock as `value` (rank 0 alone, the others wait)
-                solo = ShardedFrameLoop(ds.scenes[:1], cam, par, row_block=8, solo=True)
                 el1, _, _ = timed_loop(ds, solo, steps, None, False, events=False)
                 if len(ds.scenes) > 1:  # ... with as many frames in flight as the ranks have, if that is faster on one GPU
                     many = ShardedFrameLoop(ds.scenes, cam, par, row_block=8, solo=True)
                     el_many, _, _ = timed_loop(ds, many, steps, None, False, events=False)
-                    rows[(mode, "n1_in_flight")] = (el1, el_many)
+                    rows["n1_in_flight"] = (el1, el_many)
                     el1 = min(el1, el_many)
                 _, k1, n1 = timed_loop(ds, solo, max(2, steps // 2), None, False, events=True)
-                rows[(mode, "check")] = "ok" if torch.equal(solo.image(), loop[0].image()) else "MISMATCH"
-                rows[(mode, "n1")] = (el1, k1 / max(1, n1))
-                # ... and against the ORACLE's frame (VERDICT r4 next 5c: rank 0 alone is the same kernels): the CPU restatement
-                # of the reference path on this rank's host cores, while the GPUs idle -- bounded: skipped (and said so) when the
-                # frame's ray-shape tests would take the host longer than PT_BENCH_ORACLE_S seconds
-                if mode == modes[0]:  # (the headline alignment; the other one has the gather check and the GPU suite's whole-frame test)
-                    progress(f"oracle check {tag} (the CPU oracle renders the whole frame on this rank's host cores; the other ranks wait)")
-                    rows[(mode, "oracle")] = oracle_check(cfg["flat"], cam, par, loop[0].image(), rays_frame[mode])
-                else:
-                    rows[(mode, "oracle")] = {"checked": False, "reason": "only the headline alignment is checked against the oracle in the run "
-                                                                          "(tests/test_gpu_fullsize.py checks both on the whole frame)"}
-            fence(dist)
-            loop[0].close()
-            if rank == 0 and rows[(mode, "check")] != "ok":  # (raised behind the fence: every rank has left its collectives)
-                raise RuntimeError(f"{tag}: the gathered frame differs from the frame rank 0 renders alone")
-            oc = rows.get((mode, "oracle")) if rank == 0 else None
-            if oc and oc.get("checked") and (oc["pixels_beyond_1e-5"] > 1 or not oc["rays_match"]):
+                rows["n1"] = (el1, k1 / max(1, n1))
+            else:
+                solo.step(0, gather=False)
+                solo.finish()
+            rows["check"] = "ok" if torch.equal(solo.image(), loop[0].image()) else "MISMATCH"
+            rows["image"] = loop[0].image()
+        fence(dist)
+        if rank == 0 and rows["check"] != "ok":  # (raised behind the fence: every rank has left its collectives)
+            raise RuntimeError(f"{tag}: the gathered frame differs from the frame rank 0 renders alone")
+
+    if not agree.run(f"gather check{' + one-GPU loop' if full else ''} {tag}", check_and_solo):
+        close()
+        return None
+
+    def oracle():
+        # ... and against the ORACLE's frame: the CPU restatement of the reference path on this rank's host cores, while the
+        # GPUs idle -- bounded: skipped (and said so) when it would take the host longer than PT_BENCH_ORACLE_S seconds
+        if rank == 0:
+            rows["oracle"] = oracle_check(cfg["flat"], cam, par, rows["image"], counts["rays"])
+            oc = rows["oracle"]
+            if oc.get("checked") and (oc["pixels_beyond_1e-5"] > 1 or not oc["rays_match"]):
                 raise RuntimeError(f"{tag}: the gathered frame differs from the ORACLE's in {oc['pixels_beyond_1e-5']} pixels beyond 1e-5 "
                                    f"(rays match: {oc['rays_match']})")
 
-        if not agree.run(f"gather check + one-GPU loop {tag}", check_and_solo):
-            break
-
-    if rank != 0:
+    ok = True
+    if full:
+        ok = agree.run(f"oracle check {tag} (the CPU oracle renders the whole frame on rank 0's host cores; the other ranks wait)", oracle,
+                       deadline_s=ORACLE_LIMIT_S * 1.5 + 60)
+    close()
+    rows.pop("image", None)
+    if not ok or rank != 0:
         return None
 
-    def line(mode, gather):
-        el, k = rows[(mode, gather)]
-        traced = rays_frame[mode] - resolved_frame[mode]
-        return {"value": rays_frame[mode] * steps / el / 1e6, "unit": "Mray/s", "ms_per_step": el / steps * 1e3,
-                "traced_Mray_s": traced * steps / el / 1e6,
+    traced = counts["rays"] - counts["resolved"]
+
+    def line(gather):
+        el, k = rows[("t", gather)]
+        return {"value": traced * steps / el / 1e6, "unit": "Mray/s", "ms_per_step": el / steps * 1e3,
                 "avg_render_kernels_ms_max_over_ranks": k}
 
-    def mode_rows(mode):
-        out = dict(line(mode, True), without_gather=line(mode, False), gather_check=rows.get((mode, "check")),
-                   oracle_check=rows.get((mode, "oracle")),
-                   gather_bytes_per_frame_sent=rows.get((mode, "gather_bytes")),
-                   rays_per_frame=rays_frame[mode], steps=steps,
-                   traced_ray_fraction=1.0 - resolved_frame[mode] / max(1, rays_frame[mode]))
-        if (mode, "phases") in rows:
-            ph = rows[(mode, "phases")]
-            out["phases_ms"] = dict(ph, note="per rank, mean of 4 frames, phases run ONE AFTER THE OTHER with a device "
-                                             "synchronisation between them (pytracer_amd/dist.py: phase_probe) and a barrier behind "
-                                             "the render: render = the rank's rows; encode = the sparse encode incl. its count "
-                                             "read-back (remote ranks); transfer = sends (remote) / until every shard is in (rank 0: "
-                                             "the slowest remote encode + the wire); decode = placement + one-launch decode (rank 0). "
-                                             "The frame loops overlap these; min / median / max are over the ranks")
-            r = ph["render_ms"]["per_rank"]
-            out["rank_share_imbalance"] = max(r) / max(1e-12, sum(r) / len(r))
-        if (mode, "dome_off") in rows:
-            el, k = rows[(mode, "dome_off")]
-            out["dome_off"] = {"value": rays_frame[mode] * k / el / 1e6, "unit": "Mray/s", "ms_per_step": el / k * 1e3, "steps": k,
-                               "note": "same frames, no gather, pt_set_dome_shortcut(0): every primary ray generated and traced"}
-        if (mode, "n1") in rows:
-            el1, k1 = rows[(mode, "n1")]
-            n1 = {"value": rays_frame[mode] * steps / el1 / 1e6, "unit": "Mray/s", "ms_per_step": el1 / steps * 1e3,
-                  "avg_render_kernels_ms": k1,
-                  "note": "the same frame loop on rank 0 alone (no partition, no gather), same wall clock as `value`; the "
-                          "faster of one frame after the other and as many frames in flight as the ranks have"}
-            if (mode, "n1_in_flight") in rows:
-                a1, am = rows[(mode, "n1_in_flight")]
-                n1["ms_per_step_one_after_the_other"] = a1 / steps * 1e3
-                n1["ms_per_step_frames_in_flight"] = am / steps * 1e3
-            out["n1_same_workload"] = n1
-            out["speedup"] = out["value"] / n1["value"]
-            out["parallel_efficiency"] = out["speedup"] / world_size
-        return out
+    out = dict(line(True), gather_check=rows.get("check"), oracle_check=rows.get("oracle"),
+               gather_bytes_per_frame_sent=rows.get("gather_bytes"), rays_traced_per_frame=traced,
+               rays_settled_without_a_query_per_frame=counts["resolved"], steps=steps)
+    if ("t", False) in rows:
+        out["without_gather"] = line(False)
+    if "phases" in rows:
+        ph = rows["phases"]
+        out["phases_ms"] = dict(ph, note="per rank, mean of 4 frames, phases run ONE AFTER THE OTHER with a device "
+                                         "synchronisation between them (pytracer_amd/dist.py: phase_probe) and a barrier behind "
+                                         "the render: render = the rank's rows; encode = the sparse encode incl. its count "
+                                         "read-back (remote ranks); transfer = sends (remote) / until every shard is in (rank 0: "
+                                         "the slowest remote encode + the wire); decode = placement + one-launch decode (rank 0). "
+                                         "The frame loops overlap these; min / median / max are over the ranks")
+        r = ph["render_ms"]["per_rank"]
+        out["rank_share_imbalance"] = max(r) / max(1e-12, sum(r) / len(r))
+    if "n1" in rows:
+        el1, k1 = rows["n1"]
+        n1 = {"value": traced * steps / el1 / 1e6, "unit": "Mray/s", "ms_per_step": el1 / steps * 1e3,
+              "avg_render_kernels_ms": k1,
+              "note": "the same frame loop on rank 0 alone (no partition, no gather), same wall clock as `value`; the "
+                      "faster of one frame after the other and as many frames in flight as the ranks have"}
+        if "n1_in_flight" in rows:
+            a1, am = rows["n1_in_flight"]
+            n1["ms_per_step_one_after_the_other"] = a1 / steps * 1e3
+            n1["ms_per_step_frames_in_flight"] = am / steps * 1e3
+        out["n1_same_workload"] = n1
+        out["speedup"] = out["value"] / n1["value"]
+        out["parallel_efficiency"] = out["speedup"] / world_size
+    return out
 
-    return {mode: mode_rows(mode) for mode in modes if (mode, True) in rows and (mode, False) in rows}
+
+ORACLE_LIMIT_S = float(os.environ.get("PT_BENCH_ORACLE_S", "150"))
+
+
+def inject_failure(where):
+    """PT_BENCH_FAIL=<where>:raise|hang -- the rehearsal of the fallback paths (profiles/r06_bench_gloo2_*): `raise` throws on
+    rank 1 inside that phase, `hang` parks rank 1 there until the watchdog ends the job."""
+    spec = os.environ.get("PT_BENCH_FAIL", "")
+    if not spec or int(os.environ.get("RANK", "0")) != 1:
+        return
+    target, _, how = spec.partition(":")
+    if target != where:
+        return
+    if how == "hang":
+        time.sleep(10 * PHASE_DEADLINE_S + 3600)
+    raise RuntimeError(f"injected failure in '{where}' (PT_BENCH_FAIL)")
+
+
+def estimate_wall_s(world_size, cores):
+    """Rough wall time of the N > 1 run, printed up front: the GPU phases are seconds; rank 0's oracle check of the 4K frame is the
+    long part and is bounded by PT_BENCH_ORACLE_S (skipped, and said so, beyond it)."""
+    c4_tests = 5.33e8 * 257  # rays of the C4 frame (every ray: the oracle traces them all) x shapes
+    oracle_s = c4_tests / (ORACLE_TESTS_PER_CORE_S * max(1, cores))
+    oracle_s = oracle_s if oracle_s <= ORACLE_LIMIT_S else 0.0
+    gpu_s = 45.0 + 3.0 * world_size  # start-up, RCCL communicators, the loops (measured under gloo at 2 ranks: ~25 s without the oracle)
+    return gpu_s + oracle_s + 3.0, oracle_s
 
 
 def run_multi(args, rank, local_rank, world_size, dist, backend):
@@ -1095,12 +1374,17 @@ def run_multi(args, rank, local_rank, world_size, dist, backend):
     W, H = C4["W"], C4["H"]
     flat = flatten.flatten_world(scenes.synthetic_world(C4["n_spheres"], wide=C4["wide"]))
     cam = cam_for(W, H)
+    est, est_oracle = estimate_wall_s(world_size, usable_cores()[0])
+    progress(f"estimated wall time of this run: about {est:.0f} s ({est_oracle:.0f} s of it rank 0's oracle check on {usable_cores()[0]} host cores; "
+             f"per-phase deadline {PHASE_DEADLINE_S:.0f} s)")
     # frames in flight per rank: a rank's share of the frame is short and latency-bound (0.11 ms for an eighth of C4 against
     # 0.55 ms for the whole), and only another frame fills what it leaves idle (tools/share_in_flight.py: 0.108 -> 0.077 ms
     # per frame with two).  The one-GPU reference loop (n1_same_workload) runs with the same number in flight.
     n_in_flight = max(1, int(os.environ.get("PT_FRAMES_IN_FLIGHT", "2")))
     ds = SceneGroup(flat, n_in_flight, local_rank)
-    agree = Agreement(dist)
+    dog = Watchdog(rank)
+    dog.error_stub.update(n_gpus=world_size, steps=args.steps, warmup=args.warmup, backend=backend)
+    agree = Agreement(dist, dog)
     seen = [0]
 
     def count_ranks():
@@ -1112,60 +1396,110 @@ def run_multi(args, rank, local_rank, world_size, dist, backend):
 
     agree.run("rank count", count_ranks)
 
-    # How the shards travel: sparse (runs of one colour as one pixel; two messages per rank and a count read back) or whole
-    # (one message per rank).  Both assemble the same frame; which one is faster is a property of the node's links and of
-    # the frame, so a few frames of each are timed before the measured loops and the faster one is used -- by all ranks.
-    gather_choice = {"sparse": ptdist.sparse_default(), "probe_ms_per_frame": {}}
+    plan = ptdist.gather_plan(H, W, 8, world_size, itemsize=4, transport=ptdist.P2P)
+    HEAD, SIDE = abi.PCG_SAMPLE, abi.PCG_PIXEL
+    result = {
+        "metric": "Mray/s (primary+shadow; rays handed to a world query), C4: ONE 3840x2160 frame, 256 spheres, PathTracer depth 5, "
+                  f"64 spp, strong-scaled over {world_size} MI355X, RCCL gather of the HdrImage inside the timed region",
+        "value": None, "unit": "Mray/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": None, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic", "ranks_seen": seen[0], "backend": backend, "code_hash": loaded_code_hash(),
+        "config": {"workload": "C4 path tracer 3840x2160, 256 spheres, N=1, D=5, rr=3, S=8 (64 spp), fp32 RGB assembled on rank 0",
+                   "width": W, "height": H, "n_shapes": flat.n_shapes, "renderer": "PathTracer",
+                   "pcg_mode": "PT_PCG_SAMPLE", "frames_in_flight_per_rank": n_in_flight,
+                   "partition": f"interleaved 8-row blocks over {world_size} ranks; a frame's shards reach rank 0 in batched RCCL send/recv groups "
+                                "(whole: ONE transfer per remote rank; sparse: a fixed-size part and the runs that are not one colour), "
+                                "then a strided placement copy per rank; the gather of a frame runs behind the next frame's render"},
+        "workload_note": "NOT the N=1 line's workload (`python bench.py` measures C2, 1280x720 Flat, 15 us per frame: nothing to shard); the "
+                         "one-GPU figure for THIS workload is n1_same_workload (rank 0 alone, same clock), speedup is against it; the "
+                         "1280x720 figure on N ranks is at_1280x720; pcg_mode: one generator per sample ('PCG random state per-thread')",
+        "gather": dict(plan, used=None, probe_ms_per_frame={}, fallback_reason=None,
+                       note="the whole-shard gather (one transfer per remote rank, gather_bytes_per_frame) is measured FIRST, complete "
+                            "with its checks; then the sparse one (pytracer_amd/dist.py: runs of 128 pixels that are one colour to the bit "
+                            "travel as one pixel, lossless; two messages per remote rank); the headline is the faster of the two, and the "
+                            "whole-shard row if the sparse one failed or overran its deadline (fallback_reason)"),
+        "value_note": "every rate counts only rays that went through a world query (SURVEY.md 8(d)); the rays of sky tiles that the dome "
+                      "shortcut settles without generating them (exact: DESIGN.md 4 items 6/8) are rays_settled_without_a_query_per_frame",
+    }
 
-    def probe_gathers():
-        par0 = abi.make_params(W, H, out_format=abi.OUT_F32, pcg_mode=abi.PCG_SAMPLE, **C4["kw"])
-        images = {}
-        for name, sp in (("sparse", True), ("whole", False)):
-            lp = ShardedFrameLoop(ds.scenes, cam, par0, row_block=8, sparse=sp)
-            ds.set_count_rays(False)
-            ds.set_timing(False)
-            for i in range(2):
-                lp.step(i, gather=True)
-            lp.finish()
-            fence(dist)
-            n = 6
-            t0 = time.perf_counter()
-            for i in range(n):
-                lp.step(i, gather=True)
-            lp.finish()
-            fence(dist)
-            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            gather_choice["probe_ms_per_frame"][name] = float(t.item()) / n * 1e3
-            images[name] = lp.image().clone() if rank == 0 else None
-            lp.close()
-        if rank == 0 and not torch.equal(images["sparse"], images["whole"]):
-            raise RuntimeError("the sparse gather assembled a different frame")
+    # ---- 1. the whole-shard gather: the plainest use of RCCL, measured first and completely (this is the fallback row) ----
+    cfg4 = dict(C4, name="C4", flat=flat)
+    whole = sharded_workload(args, cfg4, HEAD, ds, cam, rank, world_size, dist, agree, False, args.steps, full=True)
+    if agree.error is None:
+        dog.have_fallback = True
+        if rank == 0:
+            result.update(whole)
+            result["gather"].update(used="whole", fallback_reason="sparse not measured yet")
+            result["gather"]["probe_ms_per_frame"]["whole"] = whole["ms_per_step"]
+            result["whole_gather"] = _pick(whole, ("value", "ms_per_step", "gather_bytes_per_frame_sent"))
+            dog.fallback = (dict(result), None)
+            write_detail(dict(result, partial="whole-shard gather measured; sparse gather and side rows follow"))
 
-    if gather_choice["sparse"] and agree.error is None:
-        if agree.attempt("gather probe", probe_gathers):
-            pr = gather_choice["probe_ms_per_frame"]
-            gather_choice["sparse"] = pr["sparse"] <= pr["whole"]
-        else:
-            gather_choice["sparse"] = False
-            gather_choice["probe_error"] = agree.soft.get("gather probe")
+    # ---- 2. the sparse gather of the same frame: used if it completes everywhere, assembles the same frame and is faster ----
+    if agree.error is None and ptdist.sparse_default():
+        inner_error = [None]
+        saved = agree.error
+        sp = sharded_workload(args, cfg4, HEAD, ds, cam, rank, world_size, dist, agree, True, args.steps, full=False)
+        if agree.error is not None:  # (a failure of the sparse path is soft: the whole-shard row stands)
+            inner_error[0], agree.error = agree.error, saved
+            agree.soft["sparse gather"] = inner_error[0]
+        if rank == 0:
+            sparse_ms = sp["ms_per_step"] if sp else None
+            used, why = choose_gather(whole["ms_per_step"], sparse_ms, inner_error[0])
+            result["gather"].update(used=used, fallback_reason=why)
+            if sparse_ms is not None:
+                result["gather"]["probe_ms_per_frame"]["sparse"] = sparse_ms
+                result["sparse_gather"] = _pick(sp, ("value", "ms_per_step", "gather_bytes_per_frame_sent", "gather_check"))
+            if used == "sparse":  # the same frame (checked against rank 0 alone, which the oracle checked): its loop is the headline
+                for k in ("value", "ms_per_step", "avg_render_kernels_ms_max_over_ranks", "gather_bytes_per_frame_sent", "gather_check"):
+                    result[k] = sp[k]
+                n1 = result.get("n1_same_workload")
+                if n1:
+                    result["speedup"] = result["value"] / n1["value"]
+                    result["parallel_efficiency"] = result["speedup"] / world_size
+            dog.fallback = (dict(result), None)
+            write_detail(dict(result, partial="C4 measured with both gathers; side rows follow"))
+    elif agree.error is None and rank == 0:
+        result["gather"].update(used="whole", fallback_reason="PT_GATHER_SPARSE=0")
+    use_sparse = [bool(result["gather"].get("used") == "sparse")]
+    if agree.error is None:  # every rank uses what rank 0 chose
+        def share_choice():
+            t = torch.tensor([1 if use_sparse[0] else 0], dtype=torch.int32, device="cuda")
+            dist.broadcast(t, src=0)
+            use_sparse[0] = bool(int(t.item()))
 
-    c4_rows = sharded_workload(args, dict(C4, name="C4", flat=flat), (abi.PCG_SAMPLE, abi.PCG_PIXEL), ds, cam, rank, world_size, dist, agree,
-                               gather_choice["sparse"], args.steps)
+        agree.run("gather choice", share_choice)
+
+    # ---- 3. side rows, each soft: the same frame under PT_PCG_PIXEL, C3 at 1280x720, C2 replicas ----
+    def soft_rows(name, cfg, mode, dsx, camx, steps):
+        if agree.error is not None:
+            return None
+        saved = agree.error
+        row = sharded_workload(args, cfg, mode, dsx, camx, rank, world_size, dist, agree, use_sparse[0], steps, full=(name != "pcg_pixel"))
+        if agree.error is not None:
+            agree.soft[name], agree.error = agree.error, saved
+            return {"error": agree.soft[name]} if rank == 0 else None
+        return row
+
+    pix = soft_rows("pcg_pixel", cfg4, SIDE, ds, cam, args.steps)
+    if rank == 0 and pix is not None:
+        result["pcg_pixel"] = dict(pix, note="the same frame with one generator per PIXEL (SURVEY.md 8c Mode PIXEL): a pixel's 64 samples "
+                                             "consume ONE stream in order; checked against rank 0 alone (tests/test_gpu_fullsize.py checks "
+                                             "this alignment against the oracle on the whole frame)")
     ds.close()
 
-    # BASELINE.json's metric is quoted "at 1280x720, 1/2/4/8 MI355X" (VERDICT r3 row e'): C3 -- 1280x720, 32 spheres,
-    # PathTracer D = 3, spp 16, per-thread PCG -- through the same sharded loop.  A frame of 0.12 ms cut in N: the
-    # launch and the gather are most of what is left, so more steps per timed loop than the 4K frame gets.
-    c3_rows = None
+    # BASELINE.json's metric is quoted "at 1280x720, 1/2/4/8 MI355X": C3 -- 1280x720, 32 spheres, PathTracer D = 3, spp 16, per-thread
+    # PCG -- through the same sharded loop.  A frame of 0.12 ms cut in N: the launch and the gather are most of what is left.
     flat3 = flatten.flatten_world(scenes.synthetic_world(C3["n_spheres"], wide=C3["wide"]))
     ds3 = SceneGroup(flat3, n_in_flight, local_rank)
-    if agree.error is None:
-        c3_rows = sharded_workload(args, dict(C3, name="C3", flat=flat3), (abi.PCG_SAMPLE,), ds3, cam_for(C3["W"], C3["H"]), rank, world_size,
-                                   dist, agree, gather_choice["sparse"], max(args.steps, 5 * args.steps))
+    c3 = soft_rows("at_1280x720", dict(C3, name="C3", flat=flat3), HEAD, ds3, cam_for(C3["W"], C3["H"]), 5 * args.steps)
     ds3.close()
+    if rank == 0 and c3 is not None:
+        result["at_1280x720"] = dict(c3, workload="C3 path tracer 1280x720, 32 spheres, N=1, D=3, rr=3, S=4 (16 spp), PT_PCG_SAMPLE, fp32 RGB "
+                                                  f"assembled on rank 0: ONE frame strong-scaled over {world_size} ranks (interleaved 8-row "
+                                                  "blocks), same ShardedFrameLoop, gather inside the timed region")
 
-    # ... and the N = 1 line's own workload, C2 (1280x720 Flat: one launch of 14 us, nothing to shard), as N independent
+    # ... and the N = 1 line's own workload, C2 (1280x720 Flat: one launch of 15 us, nothing to shard), as N independent
     # replicas without any collective: the figure the N = 1 line's `value` scales to if every GPU renders its own frames
     replicas = {}
 
@@ -1175,6 +1509,7 @@ def run_multi(args, rank, local_rank, world_size, dist, backend):
         try:
             par2 = abi.make_params(1280, 720, abi.RENDERER_FLAT, out_format=abi.OUT_F32)
             lp = ShardedFrameLoop(ds2, cam_for(1280, 720), par2, row_block=8, solo=True)
+            ds2.set_dome_shortcut(False)  # (the N = 1 line's frames: every primary ray traced)
             ds2.set_count_rays(True)
             for i in range(max(2, args.warmup)):
                 lp.step(i, gather=False)
@@ -1186,68 +1521,27 @@ def run_multi(args, rank, local_rank, world_size, dist, backend):
             t = torch.tensor([el], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             replicas.update(value=world_size * rays2 * k2 / float(t.item()) / 1e6, unit="Mray/s", ms_per_step=float(t.item()) / k2 * 1e3,
-                            steps=k2, note=f"{world_size} independent replicas of the N = 1 line's workload (C2, 1280x720 Flat, "
-                                           "one frame after the other per GPU), no collective: frames of all ranks / the slowest rank's time")
+                            steps=k2, note=f"{world_size} independent replicas of the N = 1 line's workload (C2, 1280x720 Flat, dome shortcut "
+                                           "off, one frame after the other per GPU), no collective: frames of all ranks / the slowest rank's time")
         finally:
             ds2.close()
 
     if agree.error is None:
         agree.attempt("C2 replicas", c2_replicas)
 
+    dog.disarm()
     if rank == 0:
-        plan = ptdist.gather_plan(H, W, 8, world_size, itemsize=4, transport=ptdist.choose_transport() if agree.error is None else ptdist.P2P)
-        result = {
-            "metric": "Mray/s (primary+shadow), C4: ONE 3840x2160 frame, 256 spheres, PathTracer depth 5, 64 spp, strong-scaled "
-                      f"over {world_size} MI355X with the RCCL gather of the HdrImage inside the timed region "
-                      "(NOT the N=1 line's workload: `python bench.py` measures C2, 1280x720 Flat; the one-GPU figure for THIS "
-                      "workload is n1_same_workload, and speedup / parallel_efficiency are computed against it; the 1280x720 "
-                      "figure on N ranks is the row at_1280x720)",
-            "value": None, "unit": "Mray/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": None, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
-            "data": "synthetic", "ranks_seen": seen[0], "backend": backend,
-            "config": {"workload": "C4 path tracer 3840x2160, 256 spheres, N=1, D=5, rr=3, S=8 (64 spp), fp32 RGB assembled on rank 0",
-                       "width": W, "height": H, "n_shapes": flat.n_shapes, "renderer": "PathTracer",
-                       "pcg_mode": "PT_PCG_SAMPLE (one generator per sample = per lane of the second pass: 'PCG random state per-thread' of the north star; headline since round 2 -- round 1's headline was the PT_PCG_PIXEL frame, now the row pcg_pixel)",
-                       "frames_in_flight_per_rank": n_in_flight,
-                       "partition": f"interleaved 8-row blocks over {world_size} ranks; a frame's shards reach rank 0 in batched RCCL send/recv groups "
-                                    "(sparse: a fixed-size part and the runs that are not one colour; whole: ONE transfer per remote rank), "
-                                    "then a strided placement copy per rank; the gather of a frame runs behind the next frame's render"},
-            "gather": dict(plan, sparse=gather_choice["sparse"], probe_ms_per_frame=gather_choice["probe_ms_per_frame"],
-                           probe_error=gather_choice.get("probe_error"),
-                           note="gather_bytes_per_frame is what the shards weigh whole; with `sparse` (pytracer_amd/dist.py: runs of "
-                                "128 pixels that are one colour to the bit travel as one pixel, lossless) what the remote ranks "
-                                "really sent for a frame is gather_bytes_per_frame_sent; two messages per remote rank then, the "
-                                "second one sized by a count the first one carries.  Six frames of each way are timed before the "
-                                "measured loops (probe_ms_per_frame, max over ranks) and the faster one is used; PT_GATHER_SPARSE=0 "
-                                "sends the shards whole without asking"),
-            "value_note": "`value` counts every primary ray of the frame, including those of sky tiles that are resolved without "
-                          "being generated (exact: DESIGN.md 4 items 6/8); traced_Mray_s counts only rays that went through a "
-                          "world query, dome_off is the same loop with the shortcut switched off",
-        }
-        HEAD, SIDE = abi.PCG_SAMPLE, abi.PCG_PIXEL
-        if c4_rows and HEAD in c4_rows:
-            result.update(c4_rows[HEAD])
-            result["steps"] = args.steps
-            if SIDE in c4_rows:
-                result["pcg_pixel"] = dict(c4_rows[SIDE],
-                                           note="the same frame with one generator per PIXEL (SURVEY.md 8c Mode PIXEL): a pixel's 64 "
-                                                "samples consume ONE stream in order, so the lanes of a pixel speculate on where each "
-                                                "sample starts (DESIGN.md 4 item 10) and a rank's share of the frame is bounded by its "
-                                                "slowest pixel's rounds, not by its share of the work")
-        if c3_rows and HEAD in c3_rows:
-            result["at_1280x720"] = dict(c3_rows[HEAD],
-                                         workload="C3 path tracer 1280x720, 32 spheres, N=1, D=3, rr=3, S=4 (16 spp), PT_PCG_SAMPLE, fp32 RGB "
-                                                  f"assembled on rank 0: ONE frame strong-scaled over {world_size} ranks (interleaved 8-row "
-                                                  "blocks), same ShardedFrameLoop, gather inside the timed region",
-                                         note="BASELINE.json quotes its metric 'at 1280x720, 1/2/4/8 MI355X'; C2 (14 us per frame) cannot "
-                                              "shard, C3 (0.12 ms) can: n1_same_workload is this frame on rank 0 alone by the same clock")
         if replicas:
             result["c2_replicas"] = replicas
         elif "C2 replicas" in agree.soft:
             result["c2_replicas"] = {"error": agree.soft["C2 replicas"]}
+        result["ranks_seen"] = seen[0]
+        result["phase_seconds"] = [[p, round(t, 2)] for p, t in agree.log]
+        if agree.soft:
+            result["soft_failures"] = agree.soft
         if agree.error is not None:
             result["error"] = agree.error
-        print(json.dumps(result), flush=True)
+        emit(result, compact_multi(result))
     return 0 if agree.error is None else 1
 
 
@@ -1324,6 +1618,8 @@ def main():
     ap.add_argument("--pre-roll-ms", type=float, default=30.0, help="N=1: untimed launches before the first timed loop, in ms of wall time")
     ap.add_argument("--min-timed-ms", type=float, default=20.0, help="N=1: the K-step loop is repeated until this much has been timed")
     ap.add_argument("--no-in-flight", action="store_true", help="N=1: skip the rows with 2 and 4 frames in flight")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="N=1: skip the side row with the dome shortcut on (PMC collection: every launch of the kernel is the headline's)")
     ap.add_argument("--in-flight-steps", type=int, default=100,
                     help="N=1: frames per in-flight row (few against the headline's launches: rocprofv3's average of the headline "
                          "kernel over the whole command stays that of launches run back to back)")

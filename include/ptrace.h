@@ -187,6 +187,23 @@ int pt_render(pt_scene *scene, const pt_camera *cam, const pt_params *p, void *o
  * buffer the binding hands to numpy.)  pt_host_free(NULL) is a no-op. */
 int pt_host_alloc(size_t bytes, void **out);
 int pt_host_free(void *p);
+/* Device memory and streams for a caller WITHOUT a GPU framework of its own (ABI 1.5; the reference's frame lives in a Python
+ * list, hdrimages.py:70, and its `render` command post-processes it in place, main.py:203-213: here the frame stays in HBM
+ * between pt_render_device and pt_image_*, and these are the buffer and the stream that takes).  A caller that owns device
+ * tensors (torch, a hipMalloc of its own) keeps handing their pointers to pt_render_device: nothing here is required.
+ *   pt_device_alloc    bytes of HBM on `device` (0 bytes: *out = NULL, PT_OK); PT_ERR_NOMEM when the device is full.
+ *   pt_device_free     waits for the device's work on the buffer; NULL is a no-op.
+ *   pt_device_download blocking copy of `bytes` from HBM to host memory, ordered behind `stream` (NULL: the default stream).
+ *   pt_stream_create   a non-blocking hipStream_t on `device`, for pt_render_device / pt_image_*: frames on different streams
+ *                      (through different handles of a scene, pt_scene_clone) overlap.
+ *   pt_stream_sync     block until everything enqueued on `stream` is done.
+ *   pt_stream_destroy  drains, then destroys; NULL is a no-op. */
+int pt_device_alloc(int device, size_t bytes, void **out);
+int pt_device_free(int device, void *p);
+int pt_device_download(int device, void *dst_host, const void *src_dev, size_t bytes, void *stream);
+int pt_stream_create(int device, void **out);
+int pt_stream_sync(int device, void *stream);
+int pt_stream_destroy(int device, void *stream);
 /* Render into a caller-owned DEVICE buffer on `stream` (a hipStream_t, NULL = the library's own
  * stream); asynchronous when a stream is given. Nothing is copied to the host.
  * A scene's workspace is shared by all its launches, which are ordered by running on one stream: a
@@ -260,9 +277,9 @@ int pt_last_error(char *buf, size_t n);
  * (pytracer_amd.prefer_device_kernargs(), the `render` command and bench.py do).  A value set after the runtime came up
  * is reported here but has no effect. */
 int pt_device_kernargs(void);
-/* Library/ABI version: (major<<16)|minor; this header describes 1.4.  The minor grows whenever a struct here grows or an
+/* Library/ABI version: (major<<16)|minor; this header describes 1.5.  The minor grows whenever a struct here grows or an
  * entry point is added (1.2: pt_stats gained `kernel` and `_reserved` -- 56 bytes, which pt_get_stats writes in full --,
- * pt_scene_clone, pt_image_sparse_*; 1.3: PT_PCG_SEQ on the device for OnOff / Flat / PointLight; 1.4: pt_device_kernargs, no load-time setenv): a caller built
+ * pt_scene_clone, pt_image_sparse_*; 1.3: PT_PCG_SEQ on the device for OnOff / Flat / PointLight; 1.4: pt_device_kernargs, no load-time setenv; 1.5: pt_device_alloc / _free / _download, pt_stream_create / _sync / _destroy): a caller built
  * against an older header must check pt_version() before it hands pt_get_stats its smaller struct. */
 int pt_version(void);
 

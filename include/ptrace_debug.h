@@ -76,7 +76,7 @@ typedef struct pt_plan_info {
   int32_t wg_per_cu, block_h, hier, ortho, hoist, tile4_lds;
   int32_t n_spheres, n_diag, has_grid, ball_levels;  /* the scene facts the plan was made from */
   int32_t units_need, nregions, min_rounds, spec_draws;
-  int32_t alt_budget;        /* rays after which the one-queue kernel hands a pixel over to the tree kernel behind it (0: never) */
+  int32_t alt_budget;        /* rays after which the one-queue kernel hands a pixel over to the tree kernel behind it (0: never; -1, the default: derived on the device per frame from the flagged-pixel count -- pt_plan.h q_budget_per_flagged, never below num_of_rays + 2) */
   int32_t _reserved[7];
 } pt_plan_info;
 int pt_debug_plan(const pt_scene_desc *desc, const pt_camera *cam, const pt_params *params, int n_cu, int dome_shortcut,

@@ -15,7 +15,8 @@ EXPORTS = ("pt_device_count", "pt_scene_upload", "pt_scene_clone", "pt_scene_fre
            "pt_render", "pt_render_device", "pt_get_stats", "pt_set_count_rays", "pt_sync", "pt_last_error",
            "pt_version", "pt_profile_begin", "pt_profile_end", "pt_set_timing", "pt_image_pack_pfm",
            "pt_image_average_luminosity", "pt_image_tonemap", "pt_host_alloc", "pt_host_free", "pt_set_dome_shortcut", "pt_device_info",
-           "pt_image_sparse_fixed_bytes", "pt_image_sparse_encode", "pt_image_sparse_decode", "pt_image_sparse_decode_many", "pt_device_kernargs")
+           "pt_image_sparse_fixed_bytes", "pt_image_sparse_encode", "pt_image_sparse_decode", "pt_image_sparse_decode_many", "pt_device_kernargs",
+           "pt_device_alloc", "pt_device_free", "pt_device_download", "pt_stream_create", "pt_stream_sync", "pt_stream_destroy")
 
 
 # every symbol include/ptrace_debug.h declares for ordinary builds (diagnostics: not part of the boundary)
@@ -26,7 +27,8 @@ DEBUG_EXPORTS = ("pt_debug_probe", "pt_debug_cull_probe", "pt_debug_hit_probe", 
 
 # include/ptrace.h: pt_version() = major << 16 | minor; abi.Stats mirrors the 56-byte pt_stats of minor >= 2, the tracer's
 # default alignment needs the PT_PCG_SEQ of minor >= 3, device.device_kernargs() the entry point of minor 4
-ABI_MAJOR, ABI_MINOR_NEEDED = 1, 4
+# ... devmem.DeviceBuffer / Stream the entry points of minor 5
+ABI_MAJOR, ABI_MINOR_NEEDED = 1, 5
 
 
 class PtraceError(RuntimeError):
@@ -37,6 +39,18 @@ class PtraceError(RuntimeError):
 
 def lib_path() -> str:
     return _LIB_PATH
+
+
+_share_with_torch = True
+
+
+def standalone() -> None:
+    """Call BEFORE the library is first loaded, from a process that will not use torch at all (the ``render`` command): the
+    library then binds to the system's HIP runtime (/opt/rocm) and torch's bundled copy is not preloaded.  Such a process must
+    not import torch afterwards (two HIP runtimes in one process: the second finds no GPU)."""
+    global _share_with_torch
+    if _lib is None:
+        _share_with_torch = False
 
 
 def _share_hip_runtime_with_torch() -> None:
@@ -74,7 +88,8 @@ def lib():
             raise ImportError(
                 f"{_LIB_PATH} is missing: the HIP extension has not been built. "
                 "Run `python -m pytracer_amd.build` (needs hipcc); there is no CPU fallback.")
-        _share_hip_runtime_with_torch()
+        if _share_with_torch:
+            _share_hip_runtime_with_torch()
         L = C.CDLL(_LIB_PATH)
         P = C.POINTER
         L.pt_device_count.restype = C.c_int
@@ -138,6 +153,18 @@ def lib():
         L.pt_host_alloc.argtypes = [C.c_size_t, P(C.c_void_p)]
         L.pt_host_free.restype = C.c_int
         L.pt_host_free.argtypes = [C.c_void_p]
+        L.pt_device_alloc.restype = C.c_int
+        L.pt_device_alloc.argtypes = [C.c_int, C.c_size_t, P(C.c_void_p)]
+        L.pt_device_free.restype = C.c_int
+        L.pt_device_free.argtypes = [C.c_int, C.c_void_p]
+        L.pt_device_download.restype = C.c_int
+        L.pt_device_download.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.pt_stream_create.restype = C.c_int
+        L.pt_stream_create.argtypes = [C.c_int, P(C.c_void_p)]
+        L.pt_stream_sync.restype = C.c_int
+        L.pt_stream_sync.argtypes = [C.c_int, C.c_void_p]
+        L.pt_stream_destroy.restype = C.c_int
+        L.pt_stream_destroy.argtypes = [C.c_int, C.c_void_p]
         # diagnostics (include/ptrace_debug.h): bound when the build carries them -- a renderer never needs one
         if hasattr(L, "pt_debug_cull_probe"):
             L.pt_debug_cull_probe.restype = C.c_int

@@ -15,9 +15,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libptrace.so")
 SOURCES = ["ptrace.hip"]
-DEPS = ["ptrace.hip", "pt_kernels.h", "pt_math.h", "pt_query.h", "pt_shade.h", "pt_camera.h", "pt_simple.h", "pt_tile.h", "pt_path.h",
-        "pt_tree.h", "pt_probes.h", "pt_layout.h", "pt_post.h", os.path.join("..", "..", "include", "ptrace.h"),
-        os.path.join("..", "..", "include", "ptrace_debug.h")]
+# every file the one translation unit includes: all of csrc/ (tests/test_host.py checks this list against the #include lines)
+DEPS = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))) + [os.path.join("..", "..", "include", "ptrace.h"),
+                                                                            os.path.join("..", "..", "include", "ptrace_debug.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-fast-math", "-std=c++17", "-fPIC",
          "-shared", "-Wall", "-Wno-unused-function", "-Wno-pass-failed",
          # a fixed compilation-unit id: by default clang derives it from the command line (paths included), which would make

@@ -154,9 +154,10 @@ def render(width, height, algorithm, pfm_output, png_output, num_of_rays, max_de
     except UsageError as e:
         click.echo(f"pytracer_amd render: {e}", err=True)
         sys.exit(2)
-    from . import prefer_device_kernargs
+    from . import _lib, prefer_device_kernargs
 
     prefer_device_kernargs()  # (this process is ours: kernel arguments in device memory, before its first HIP call)
+    _lib.standalone()  # (... and it never imports torch: the frame's HBM and streams come from the C-ABI, pt_device_alloc)
     click.echo(f"{width}x{height} px, {algorithm}, {job.samples_per_side ** 2} sample(s) per pixel, "
                f"{len(job.world.shapes)} shape(s), GPU {device}")
     image = hm.HdrImage(width, height)

@@ -14,6 +14,7 @@
 // forced variants against the oracle).
 #pragma once
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -132,7 +133,7 @@ enum PtSecondPass {  // the path tracer's second-pass kernel
 #ifndef PT_Q_FEW_LANES_DEFAULT
 #define PT_Q_FEW_LANES_DEFAULT 16
 #endif
-enum PtAltPass {  // the one-queue alternative enqueued behind the tree kernel (PT_Q_CHOICE)
+enum PtAltPass {  // the one-queue alternative launched IN FRONT OF the tree kernel (PT_Q_CHOICE: which of the two the device lets work)
   PT_ALT_NONE = 0,
   PT_ALT_FLAGGED_LEAN_HBM,  // pt_path_flagged_kernel<1, false>
   PT_ALT_FLAGGED_HBM,       // <0, false>
@@ -347,7 +348,14 @@ static inline void pt_make_plan(const PtSceneFacts &s, const pt_camera *cam, con
       pl.handover_cap = (int)std::min<long long>(std::min<long long>(pl.npix, PT_HANDOVER_CAP), by_bytes);
       pl.handover_doubles = (size_t)pl.handover_cap * rec;
     }
-    int wgq = pl.q_home == 1 ? std::min<int>(3, (int)(PT_LDS_BUDGET / q_frame_bytes)) : 2;
+    // workgroups of the one-queue kernel a CU holds: by the LDS a workgroup REALLY asks for -- its frames plus the diag records
+    // staged behind them when they fit (decided below by the same rule: lds_q), not the frames alone (at D = 1
+    // three were assumed where two fit, and the hand-over budget divided by lanes that were not resident)
+    const size_t q_diag_here = (size_t)s.n_diag * PT_PLAN_DIAG_BYTES;
+    const bool q_diag_fits = s.n_diag > 0 && q_diag_here <= 48 * 1024 &&
+                             q_frame_lds + q_diag_here <= (pl.q_home == 1 ? PT_LDS_BUDGET : PT_LDS_BUDGET / 2);
+    const size_t q_lds_per_wg = std::max<size_t>(1, q_frame_lds + (q_diag_fits ? q_diag_here : 0));
+    int wgq = pl.q_home == 1 ? std::max<int>(1, std::min<int>(3, (int)(PT_LDS_BUDGET / q_lds_per_wg))) : 2;
     if (t.q_wg_per_cu > 0) wgq = (int)t.q_wg_per_cu;
     pl.grid_q = (int)std::max<long long>(1, std::min<long long>(want, (long long)s.n_cu * wgq));
     // The budget: what a lane traces in the whole frame were the work spread evenly -- F flagged pixels x nsamp samples x the

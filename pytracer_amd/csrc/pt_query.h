@@ -309,7 +309,6 @@ PT_DEV int world_query_lanes(const PtKArgs &a, const Ray &r, double tmax, double
   best_t = INFINITY;
   const double tmin = r.tmin;
   const int nd = a.n_diag, ns = a.n_spheres, n = a.n_shapes;
-  const float tmaxf_dd = (float)tmax;  // (multiplied by |d|^2 below)
 
   const float ofx = (float)r.o.x, ofy = (float)r.o.y, ofz = (float)r.o.z;
   const float dfx = (float)r.d.x, dfy = (float)r.d.y, dfz = (float)r.d.z;

@@ -771,7 +771,6 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(WAVES,
     // wave that 60 finished lanes wait for.  (Planes carry no bounding sphere: a pixel of a tile some plane
     // survived in is always left over.)
     if (RENDERER == PT_RENDERER_PATHTRACER && !ORTHO && dome_on && dome_here && nsurv > 1) {
-      pt_kargs ca = cold_args(a);
       dome_prepare(dome_slot);
       // (dc_settled for the path tracer: Russian roulette on and a black BRDF pigment -- the sample ends on the dome)
       if (dc_usable && dc_settled && dc_hc < -0.5 && dc_fro2 * tc.dmax2 < 1e6f && tc.dmin > 1e-6f && !tc.all) {

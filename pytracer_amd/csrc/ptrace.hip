@@ -26,8 +26,9 @@
 // major << 16 | minor.  The minor grows whenever a struct of include/ptrace.h grows or an entry point is added (minor 2:
 // pt_stats gained `kernel` + `_reserved`, pt_scene_clone / pt_image_sparse_* arrived; minor 3: PT_PCG_SEQ accepted for
 // OnOff / Flat / PointLight at any samples_per_side; minor 4: pt_device_kernargs, and the library no longer sets
-// HIP_FORCE_DEV_KERNARG when it is loaded); a caller built against an older header checks pt_version() first.
-#define PT_VERSION ((1 << 16) | 4)
+// HIP_FORCE_DEV_KERNARG when it is loaded; minor 5: pt_device_alloc / pt_device_free / pt_device_download / pt_stream_*);
+// a caller built against an older header checks pt_version() first.
+#define PT_VERSION ((1 << 16) | 5)
 
 // (Kernel arguments in device memory -- HIP_FORCE_DEV_KERNARG=1, ~1 us per launch, profiles/r04_dev_kernarg.txt -- are the
 // CALLER's choice: the HIP runtime reads the variable when it initialises, and a library that edited the process environment
@@ -113,6 +114,7 @@ struct pt_scene {
   PtKArgs args2_last;
   bool args2_valid = false;
   hipStream_t args2_stream = nullptr;
+  int last_handover_cap = 0;            // records the last num_of_rays > 1 frame's hand-over table held (pt_debug_handed_over)
   bool choice_pending = false;          // ray_counter_host[2] will hold the frame's PT_Q_CHOICE word once ev_count has passed
   unsigned char *region_keys = nullptr;  // path tracer region ordering
   struct DomeCand {
@@ -1203,6 +1205,7 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
     a.handover = s->handover;
     a.units_handed = s->units_handed;
     a.handover_cap = pl.q_alt ? pl.handover_cap : 0;
+    s->last_handover_cap = a.handover_cap;
     a.q_budget = 0;  // (the one-queue kernel's block carries these)
     a.q_tail_budget = 0;
     a.q_few_lanes = 0;
@@ -1391,7 +1394,9 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
         default: PT_SECOND((pt_path_regions_kernel<false>)); break;
       }
 #undef PT_SECOND
-      if (pl.q_alt) {  // (pt_stats.vgprs: the tree kernel's; pt_stats.kernel follows the device's choice, see fold_stats)
+      // (pt_stats.vgprs: the tree kernel's; pt_stats.kernel follows the device's choice, see fold_stats -- only when the frame
+      // is measured at all: a frame loop with timing and counting off enqueues neither the copy nor its event)
+      if (pl.q_alt && (s->timing || s->count_rays || prof)) {
         HIP_TRY(hipMemcpyAsync(s->ray_counter_host + 2, s->queue_last + PT_Q_CHOICE, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         s->choice_pending = true;
       }
@@ -1572,6 +1577,82 @@ extern "C" int pt_host_alloc(size_t bytes, void **out) {
 extern "C" int pt_host_free(void *p) {
   if (!p) return PT_OK;
   HIP_TRY(hipHostFree(p));
+  return PT_OK;
+}
+
+// ---- device memory and streams for callers WITHOUT a GPU framework of their own (ABI 1.5) ----
+// The `render` command leaves its frame in HBM (pt_render_device) and post-processes it there (pt_image_*): with these it needs
+// no torch for the buffer.  Thin and error-coded; a caller that owns device tensors keeps passing their pointers.
+static int device_ok(int device) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(PT_ERR_NODEVICE, "no HIP device visible");
+  if (device < 0 || device >= ndev) return fail(PT_ERR_INVALID, "device %d out of range (%d visible)", device, ndev);
+  return PT_OK;
+}
+
+extern "C" int pt_device_alloc(int device, size_t bytes, void **out) {
+  if (!out) return fail(PT_ERR_INVALID, "null output pointer");
+  *out = nullptr;
+  if (bytes == 0) return PT_OK;
+  int rc = device_ok(device);
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(device));
+  hipError_t e = hipMalloc(out, bytes);
+  if (e != hipSuccess) {
+    *out = nullptr;
+    return fail(e == hipErrorOutOfMemory ? PT_ERR_NOMEM : PT_ERR_HIP, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+  }
+  return PT_OK;
+}
+
+extern "C" int pt_device_free(int device, void *p) {
+  if (!p) return PT_OK;
+  int rc = device_ok(device);
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(hipFree(p));  // (waits for the device's work on it)
+  return PT_OK;
+}
+
+extern "C" int pt_device_download(int device, void *dst_host, const void *src_dev, size_t bytes, void *stream) {
+  if (bytes == 0) return PT_OK;
+  if (!dst_host || !src_dev) return fail(PT_ERR_INVALID, "null argument");
+  int rc = device_ok(device);
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(device));
+  hipStream_t st = (hipStream_t)stream;
+  HIP_TRY(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return PT_OK;
+}
+
+extern "C" int pt_stream_create(int device, void **out) {
+  if (!out) return fail(PT_ERR_INVALID, "null output pointer");
+  *out = nullptr;
+  int rc = device_ok(device);
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(device));
+  hipStream_t st = nullptr;
+  HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));  // (the legacy default stream serialises the host with the device)
+  *out = (void *)st;
+  return PT_OK;
+}
+
+extern "C" int pt_stream_sync(int device, void *stream) {
+  int rc = device_ok(device);
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  return PT_OK;
+}
+
+extern "C" int pt_stream_destroy(int device, void *stream) {
+  if (!stream) return PT_OK;
+  int rc = device_ok(device);
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  HIP_TRY(hipStreamDestroy((hipStream_t)stream));
   return PT_OK;
 }
 
@@ -1939,7 +2020,8 @@ extern "C" int pt_debug_handed_over(pt_scene *s, unsigned long long *pixels, uns
   unsigned long long w[3] = {0, 0, 0};  // PT_Q_CHOICE, PT_Q_HEAVY, PT_Q_BUDGET
   static_assert(PT_Q_HEAVY == PT_Q_CHOICE + 1 && PT_Q_BUDGET == PT_Q_CHOICE + 2, "read as one block");
   HIP_TRY(hipMemcpy(w, (s->queue_last ? s->queue_last : s->queue) + PT_Q_CHOICE, sizeof w, hipMemcpyDeviceToHost));
-  *pixels = w[0] ? w[1] : 0ULL;
+  // (PT_Q_HEAVY keeps counting the lanes that ASKED once the record table is full, pt_path.h: handed over are at most its capacity)
+  *pixels = w[0] ? std::min<unsigned long long>(w[1], (unsigned long long)s->last_handover_cap) : 0ULL;
   *budget = w[2];
   return PT_OK;
 }

@@ -432,6 +432,7 @@ def confirm_sparse(state: SparseGatherState, group=None, dst: int = 0) -> None:
                 if count > cap:  # the tail of its runs follows now
                     ops.append(dist.P2POp(dist.irecv, f["payload"][r][cap:count], peer_of(r), group))
                     redo.append(r)
+                    last_gather["bytes"] = last_gather.get("bytes", 0) + f["payload"][r][cap:count].numel() * f["payload"][r].element_size()
             _wait_all(ops)
             for r in redo:
                 state.overflows += 1
@@ -443,6 +444,7 @@ def confirm_sparse(state: SparseGatherState, group=None, dst: int = 0) -> None:
             if count > cap:
                 state.overflows += 1
                 _wait_all([dist.P2POp(dist.isend, f["payload"][cap:count], peer_of(dst), group)])
+    last_gather["confirmed"] = True
 
 
 def _gather_sparse_async(local, height, row_block, world, rank, group, dst, out, nrows, state, clock=None):
@@ -479,7 +481,9 @@ def _gather_sparse_async(local, height, row_block, world, rank, group, dst, out,
         state.pending.append({"counts": counts, "event": ev, "remote": remote, "cap": {r: state.cap[r] for r in remote}, "runs": runs,
                               "fixed": fixed, "payload": payload, "npx": {r: nrows[r] * W for r in remote}, "out": out,
                               "row_block": row_block, "world": world})
-        last_gather.update(bytes=sum(fixed[r].numel() + state.cap[r] * SPARSE_TILE * 3 * esize for r in remote), sparse=True)
+        # (not final until confirm_sparse has looked at the counts: a shard whose count exceeded its capacity is repaired there,
+        #  and the repair's bytes are added to `bytes`)
+        last_gather.update(bytes=sum(fixed[r].numel() + state.cap[r] * SPARSE_TILE * 3 * esize for r in remote), sparse=True, confirmed=False)
     elif nrows[rank] > 0:
         fixed, payload = encode_sparse_full(local[: nrows[rank]].contiguous(), parity)
         _mark(clock, "encode_ms")  # (classify + scan + pack: no read-back)
@@ -553,8 +557,10 @@ def gather_image(local: torch.Tensor, height: int, row_block: int, group=None, d
     ``local`` is this rank's ``[>= rows_of_this_rank, W, 3]`` shard (rows beyond its own are ignored).
     ``staging`` (``dst`` only, optional): a ``[world, max_shard_rows, W, 3]`` buffer the remote shards land in.
     ``state`` (a frame loop's ``SparseGatherState``): the sparse gather then moves both of a rank's messages in one group
-    without reading a count back; the frame is final once ``confirm_sparse(state)`` has run (the next gather and
-    ``ShardedFrameLoop.finish`` do).  Returns the ``[H, W, 3]`` image on ``dst`` (``out`` when given) and ``None`` elsewhere."""
+    without reading a count back; the returned image is then PROVISIONAL -- ``last_gather["confirmed"]`` is False -- until
+    ``confirm_sparse(state)`` has run (the next gather and ``ShardedFrameLoop.finish`` do; ``ShardedFrameLoop.image()`` only
+    hands out confirmed frames): a shard whose run count exceeded the capacity it travelled with is repaired there, and the
+    repair's bytes are added to ``last_gather["bytes"]``.  Returns the ``[H, W, 3]`` image on ``dst`` (``out`` when given) and ``None`` elsewhere."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     if world == 1:

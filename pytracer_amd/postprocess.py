@@ -2,8 +2,9 @@
 does after ``fire_all_rays`` — ``write_pfm``, ``average_luminosity``, ``normalize_image``,
 ``clamp_image``, ``write_ldr_image`` (hdrimages.py:96-171) — on a frame that sits in HBM.
 
-``DeviceImage`` wraps ``[H, W, 3]`` pixels (fp32 or fp64, row 0 on top) — a CUDA torch tensor left in HBM
-by ``pt_render_device`` or a host numpy array — and mirrors the reference method names; every operation is
+``DeviceImage`` wraps ``[H, W, 3]`` pixels (fp32 or fp64, row 0 on top) — a frame left in HBM by ``pt_render_device``
+(a :class:`pytracer_amd.devmem.DeviceBuffer`, which needs no torch, or a CUDA torch tensor) or a host numpy array — and
+mirrors the reference method names; every operation is
 a HIP kernel behind the C-ABI (``pt_image_*``).  PNG encoding itself stays on the host (Pillow), as in
 the reference.
 """
@@ -20,12 +21,18 @@ LITTLE_ENDIAN, BIG_ENDIAN = 1, 2  # hdrimages.py:26-30 (Endianness values)
 
 
 class DeviceImage:
-    """``[H, W, 3]`` fp32/fp64 pixels: a CUDA torch tensor (frame resident in HBM) or a numpy array (host;
-    the C-ABI stages it through the device).  Either way every operation below is a HIP kernel."""
+    """``[H, W, 3]`` fp32/fp64 pixels: a ``DeviceBuffer`` or a CUDA torch tensor (frame resident in HBM) or a numpy array
+    (host; the C-ABI stages it through the device).  Either way every operation below is a HIP kernel."""
 
     def __init__(self, pixels, device: int = 0):
-        self.is_torch = hasattr(pixels, "data_ptr")
-        if self.is_torch:
+        self.is_buffer = bool(getattr(pixels, "is_device_buffer", False))
+        self.is_torch = hasattr(pixels, "data_ptr") and not self.is_buffer
+        if self.is_buffer:
+            if len(pixels.shape) != 3 or pixels.shape[2] != 3 or pixels.dtype not in (np.float32, np.float64):
+                raise ValueError("expected a [H, W, 3] float32/float64 DeviceBuffer")
+            f32 = pixels.dtype == np.float32
+            self.device = pixels.device
+        elif self.is_torch:
             if pixels.dim() != 3 or pixels.shape[2] != 3 or not pixels.is_cuda or not pixels.is_contiguous():
                 raise ValueError("expected a contiguous [H, W, 3] CUDA tensor")
             f32 = str(pixels.dtype) == "torch.float32"
@@ -47,9 +54,11 @@ class DeviceImage:
         return cls(np.array(arr, order="C"), device)
 
     def _ptr(self):
-        return C.c_void_p(self.t.data_ptr() if self.is_torch else self.t.ctypes.data)
+        return C.c_void_p(self.t.data_ptr() if (self.is_torch or self.is_buffer) else self.t.ctypes.data)
 
     def numpy(self) -> np.ndarray:
+        if self.is_buffer:
+            return self.t.numpy()
         return self.t.cpu().numpy() if self.is_torch else self.t
 
     # -- hdrimages.py:96-118 ---------------------------------------------------------------------------

@@ -60,9 +60,11 @@ default) REPLACES ``image.pixels`` by a :class:`pytracer_amd.pixels.L
 assigns and keeps object identity like the list did and makes a ``Color`` when an index is first read -- 0.001 ms per frame,
 for callers that only index / iterate / write the image out.
 
-``tracer.pcg`` is advanced behind a ``"seq"`` frame (by the ``2 W H S²`` draws the reference's loop makes) only when the
-caller SUPPLIED the generator: a tracer built without ``pcg`` starts every frame from ``PCG()`` -- the reference's shared
-default-argument generator (imagetracer.py:34) is not imitated.
+``tracer.pcg`` is advanced behind a ``"seq"`` frame by the ``2 W H S²`` draws the reference's loop makes
+(imagetracer.py:84-101), whether the caller supplied the generator or the tracer made its own ``PCG()``: a second frame
+through the same tracer continues the stream, as a second ``ImageTracer.fire_all_rays`` does.  What is NOT imitated is the
+reference's default ARGUMENT being one object shared by every ``ImageTracer`` of a process (imagetracer.py:34):
+each tracer built without ``pcg`` gets a fresh ``PCG()``.
 
 ``fallback="host"`` (opt-in, never the default): a reference renderer whose world the device cannot express (an
 unknown shape / BRDF / pigment class, a non-affine matrix) is itself a callable ``Ray -> Color``; with this option it
@@ -121,7 +123,6 @@ class GpuImageTracer:
         self.image = image
         self.camera = camera
         self.samples_per_side = samples_per_side
-        self._own_pcg = pcg is None  # (no generator supplied: every frame starts from PCG())
         self.pcg = pcg if pcg is not None else PCG()
         self.device = device
         if pcg_mode not in _PCG_MODES:
@@ -218,9 +219,9 @@ class GpuImageTracer:
         scene = self._device_scene(func.world)
         dev_t = None
         if self.resident:
-            import torch  # device memory for the resident frame (plumbing only)
+            from .devmem import DeviceBuffer  # HBM through the C-ABI (pt_device_alloc): no GPU framework needed
 
-            dev_t = torch.empty((h, w, 3), dtype=torch.float64, device=torch.device("cuda", self.device))
+            dev_t = DeviceBuffer((h, w, 3), np.float64, self.device)
             params = abi.copy_params(params, out_format=abi.OUT_F64)
         row_bytes = w * 3 * 8
 
@@ -271,8 +272,7 @@ class GpuImageTracer:
                     band //= 2
             st.n_rays, st.n_rays_resolved, st.kernel_ms, st.total_ms, st.n_pixels = n_rays, n_res, kernel_ms, total_ms, w * h
             self.last_stats = st
-        if (mode == abi.PCG_SEQ and int(self.samples_per_side) > 0 and not self._own_pcg
-                and hasattr(self.pcg, "state") and hasattr(self.pcg, "inc")):
+        if mode == abi.PCG_SEQ and int(self.samples_per_side) > 0 and hasattr(self.pcg, "state") and hasattr(self.pcg, "inc"):
             # the reference's loop leaves ImageTracer.pcg 2 W H S^2 draws further on (imagetracer.py:84-101)
             self.pcg.state = pcg_advance(int(self.pcg.state), int(self.pcg.inc), 2 * w * h * int(self.samples_per_side) ** 2)
         if dev_t is not None:

@@ -106,6 +106,27 @@ int main(int argc, char **argv) {
     if (rc) return fail("pt_get_stats", rc);
     printf("rays %llu pixels %llu kernel %d\n", (unsigned long long)st.n_rays, (unsigned long long)st.n_pixels, st.kernel);
     for (size_t i = 0; i < (size_t)W * H * 3; ++i) printf("%a\n", out[i]);
+    /* the same frame left in HBM: buffer and stream from the C-ABI itself (1.5), no GPU framework on the caller's side */
+    void *dev = NULL, *stream = NULL;
+    double *back = (double *)malloc(bytes);
+    rc = pt_device_alloc(0, bytes, &dev);
+    if (rc) return fail("pt_device_alloc", rc);
+    rc = pt_stream_create(0, &stream);
+    if (rc) return fail("pt_stream_create", rc);
+    rc = pt_render_device(scene, &cam, &p, dev, bytes, stream);
+    if (rc) return fail("pt_render_device", rc);
+    rc = pt_stream_sync(0, stream);
+    if (rc) return fail("pt_stream_sync", rc);
+    rc = pt_device_download(0, back, dev, bytes, stream);
+    if (rc) return fail("pt_device_download", rc);
+    printf("device frame identical %d\n", memcmp(out, back, bytes) == 0);
+    rc = pt_stream_destroy(0, stream);
+    if (rc) return fail("pt_stream_destroy", rc);
+    rc = pt_device_free(0, dev);
+    if (rc) return fail("pt_device_free", rc);
+    printf("free(NULL) %d %d alloc(0) %d\n", pt_device_free(0, NULL), pt_stream_destroy(0, NULL), pt_device_alloc(0, 0, &dev) == PT_OK && dev == NULL);
+    printf("bad device -> %d\n", pt_device_alloc(4096, 16, &dev));
+    free(back);
     rc = pt_render(scene, &cam, &p, out, bytes - 1); /* a buffer one byte short must be refused, not overrun */
     printf("short buffer -> %d\n", rc);
     free(out);

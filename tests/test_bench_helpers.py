@@ -80,3 +80,103 @@ def test_counter_cross_checks_and_scalar_co_issue():
     assert abs(pr["frac_counter_active_inst_valu_x4"] - 0.4) < 1e-12  # every instruction charged a quad-cycle
     assert abs(pr["frac_with_salu_coissue"] - (pr["frac"] + 500 * b.SALU_COISSUE_PENALTY_CYCLES / 10000.0)) < 1e-12
     assert pr["wave_cycles_waiting_any_frac"] == 0.5 and pr["wave_cycles_waiting_inst_frac"] == 0.125
+
+
+# ---- the result line: compact, bounded, a fixed set of keys; the rest goes to bench_detail.json ----
+N1_KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+           "config", "parity_check", "roofline", "cpu_baseline", "ms_per_frame_at_c_abi", "frame_with_dome_shortcut", "detail_file"}
+ROOFLINE_KEYS = {"bound", "achieved", "peak", "unit", "frac", "frac_bounds", "traffic", "algorithmic_bytes", "kernel", "avg_kernel_ms",
+                 "code_hash_matches_loaded_library"}
+CPU_KEYS = {"value", "unit", "cores", "kind", "sample", "ms_per_frame", "one_core_Mray_s", "cpu_model"}
+LONG = "a note that goes on and on " * 400  # 10 KB: what the old one-line output carried in a dozen places
+
+
+def _canned_n1():
+    return {
+        "metric": "Mray/s (primary+shadow; rays handed to a world query) at 1280x720 per GPU, C2", "value": 62103.0491, "unit": "Mray/s",
+        "n_gpus": 1, "steps": 20, "warmup": 5, "ms_per_step": 0.014839851, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic", "code_hash": "ef" * 32, "rays_per_step": 921600, "ray_shape_tests_per_s": 2.05e12,
+        "config": {"workload": "C2 flat 1280x720", "width": 1280, "height": 720, "n_shapes": 33, "renderer": "FlatRenderer", "more": LONG},
+        "repeats": {"note": LONG}, "value_note": LONG,
+        "parity_check": {"bit_identical": True, "pixels": 921600, "against": LONG},
+        "frame_with_dome_shortcut": {"ms_per_frame": 0.0132, "rays_traced_per_frame": 509440, "traced_Mray_s": 38600.0, "bit_identical": True, "note": LONG},
+        "roofline": {"bound": "valu_issue", "achieved": 14.28, "peak": 42.6, "unit": "T lane-op/s", "frac": 0.335, "traffic": 11664896,
+                     "frac_bounds_from_disassembly": [0.3307, 0.3396], "kernel": "pt_tile4_kernel<FLAT> " + LONG, "avg_kernel_ms": 0.01313,
+                     "note": LONG, "executed": {"code_hash_matches_loaded_library": True, "static_mix": {"x": LONG}},
+                     "hbm": {"algorithmic_bytes_per_launch": 14216640, "frac": 0.135}},
+        "cpu_baseline": {"value": 46.03, "unit": "Mray/s", "cores": 16, "kind": "port", "sample": LONG, "ms_per_frame": 20.02,
+                         "one_core_Mray_s": 2.99, "cpu_model": "AMD EPYC 9575F 64-Core Processor", "interpreted": {"value": 0.0613},
+                         "reference_itself": LONG},
+        "boundary": {"value_at_c_abi": {"ms_per_frame": 0.2615, "note": LONG}, "python_hdrimage_note": LONG},
+        "extra": {f"row{i}": {"note": LONG} for i in range(12)}, "frames_in_flight": {"note": LONG},
+    }
+
+
+def _canned_multi():
+    row = {"value": 8900.0, "unit": "Mray/s", "ms_per_step": 0.51, "gather_check": "ok", "note": LONG}
+    return {
+        "metric": "Mray/s, C4 strong-scaled", "value": 30000.0, "unit": "Mray/s", "n_gpus": 8, "steps": 20, "warmup": 3, "ms_per_step": 0.15,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic", "ranks_seen": 8,
+        "backend": "nccl", "code_hash": "ab" * 32, "rays_traced_per_frame": 4580321,
+        "config": {"workload": "C4 path tracer 3840x2160", "width": 3840, "height": 2160, "n_shapes": 257, "renderer": "PathTracer",
+                   "pcg_mode": "PT_PCG_SAMPLE", "frames_in_flight_per_rank": 2, "partition": LONG},
+        "gather": {"used": "whole", "probe_ms_per_frame": {"whole": 0.9, "sparse": None}, "gather_bytes_per_frame": 87091200,
+                   "fallback_reason": "sparse failed: " + LONG, "rows_per_rank": list(range(8)), "note": LONG},
+        "gather_bytes_per_frame_sent": 87091200, "gather_check": "ok", "without_gather": {"ms_per_step": 0.11},
+        "oracle_check": {"checked": True, "bit_identical": True, "pixels_beyond_1e-5": 0, "rays_match": True, "against": LONG},
+        "n1_same_workload": {"value": 8900.0, "ms_per_step": 0.51, "note": LONG}, "speedup": 3.4, "rank_share_imbalance": 1.02,
+        "phases_ms": {"note": LONG, "render_ms": {"per_rank": [0.1] * 8}},
+        "at_1280x720": dict(row, speedup=1.2, workload=LONG), "pcg_pixel": row, "c2_replicas": {"value": 4.9e5, "ms_per_step": 0.0149, "note": LONG},
+        "value_note": LONG, "workload_note": LONG, "phase_seconds": [["x", 1.0]] * 40,
+    }
+
+
+def test_the_result_line_is_compact_and_carries_its_keys(tmp_path, monkeypatch, capsys):
+    b = _bench()
+    monkeypatch.setattr(b, "ROOT", str(tmp_path))
+    for full, compact_fn, need in ((_canned_n1(), b.compact_single, N1_KEYS),
+                                   (_canned_multi(), b.compact_multi, {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                                                                       "higher_is_better", "scaling", "ranks_seen", "backend", "config",
+                                                                       "gather", "parity_check", "n1_same_workload", "speedup", "detail_file"})):
+        assert len(json.dumps(full)) > 100_000  # (the canned detail is as verbose as round 5's line was, and more)
+        b.emit(full, compact_fn(full))
+        out, err = capsys.readouterr()
+        lines = [ln for ln in out.splitlines() if ln.strip()]
+        line = lines[-1]
+        assert len(lines) == 1 and len(line) < 4096 < b.COMPACT_LIMIT == 8192  # target 4 KB, hard limit 8 KB
+        got = json.loads(line)
+        assert need <= set(got), need - set(got)
+        assert got["detail_file"] == b.DETAIL_NAME and json.load(open(tmp_path / b.DETAIL_NAME)) == full  # everything else: the side file ...
+        assert err.startswith("[bench detail] ") and json.loads(err[len("[bench detail] "):]) == full       # ... and stderr
+        if compact_fn is b.compact_single:
+            assert ROOFLINE_KEYS <= set(got["roofline"]) and CPU_KEYS <= set(got["cpu_baseline"])
+            assert set(got["config"]) == {"workload", "width", "height", "n_shapes", "renderer"}
+            assert got["parity_check"] == {"bit_identical": True} and got["roofline"]["frac_bounds"] == [0.3307, 0.3396]
+            assert got["ms_per_frame_at_c_abi"] == 0.2615 and got["roofline"]["algorithmic_bytes"] == 14216640
+            assert got["value"] == 62103.0 and got["ms_per_step"] == 0.0148399  # six significant digits
+        else:
+            assert got["gather"]["used"] == "whole" and got["gather"]["fallback_reason"].startswith("sparse failed: ") and got["ranks_seen"] == 8
+            assert got["parity_check"] == {"checked": True, "bit_identical": True, "pixels_beyond_1e-5": 0, "rays_match": True}
+
+
+def test_a_line_that_would_not_fit_is_cut_not_printed_long():
+    b = _bench()
+    c = b.compact_single(_canned_n1())
+    c["config"]["workload"] = "w" * 9000  # (cannot happen with the fixed key set; a line that does not parse loses the round)
+    text = b.compact_dumps(c)
+    assert len(text) < b.COMPACT_LIMIT and json.loads(text)["truncated"] is True and json.loads(text)["value"] == 62103.0
+    assert json.loads(b.compact_dumps({"value": float("nan"), "x": [float("inf"), 1.0]})) == {"value": None, "x": [None, 1.0]}  # strict JSON
+
+
+def test_the_headline_gather_falls_back_on_the_whole_shards():
+    b = _bench()
+    assert b.choose_gather(0.9, 0.4, None) == ("sparse", None)
+    assert b.choose_gather(0.4, 0.9, None) == ("whole", None)
+    used, why = b.choose_gather(0.9, None, "timed loop C4 sparse: RuntimeError: ncclInternalError")
+    assert used == "whole" and why.startswith("sparse failed: timed loop C4 sparse")
+    assert b.choose_gather(0.9, 0.4, "another rank failed")[0] == "whole"  # measured on this rank, failed on another: not used
+    assert b.choose_gather(0.9, None, None) == ("whole", "sparse not measured")
+    est, oracle_s = b.estimate_wall_s(8, 128)
+    assert est < 8 * 60 and 0 < oracle_s < b.ORACLE_LIMIT_S
+    est16, oracle16 = b.estimate_wall_s(8, 16)
+    assert est16 < 8 * 60  # (16 cores: ~95 s of oracle, inside the limit; beyond the limit the check is skipped and costs nothing)

@@ -56,6 +56,8 @@ def test_a_c_program_renders_the_frame_the_python_binding_renders(probe, oracle)
     assert lines[0].split()[:4] == ["rays", str(W * H), "pixels", str(W * H)]
     got = np.array([float.fromhex(x) for x in lines[1:1 + W * H * 3]]).reshape(H, W, 3)
     assert lines[-1] == f"short buffer -> {-5}"  # PT_ERR_SIZE
+    # ABI 1.5: the same frame through pt_device_alloc + pt_stream_create + pt_render_device + pt_device_download
+    assert lines[-4:-1] == ["device frame identical 1", "free(NULL) 0 0 alloc(0) 1", "bad device -> -1"]
     # the same scene through the Python objects and the ctypes binding, and through the oracle
     w = hm.World()
     w.add_shape(hm.Sphere(hm.translation(hm.Vec(2.0, 0.25, 0.5)) * hm.scaling(hm.Vec(0.5, 0.5, 0.5)),

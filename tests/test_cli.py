@@ -199,3 +199,35 @@ def test_cli_scene_file_on_the_gpu(tmp_path, reference_importable):
                                  "--pfm-output", pfm, "--png-output", png, REF_DEMO])
     assert r.exit_code == 0, r.output
     assert np.array_equal(_read_pfm(pfm, 64, 48), util.load("g5_seq_cli_demo_flat_s1_64x48")["pixels"].astype(np.float32))
+
+
+@pytest.mark.gpu
+def test_cli_renders_without_torch(tmp_path):
+    """`python -m pytracer_amd render builtin:c2` in a process where torch CANNOT be imported (masked in
+    sys.modules) -- the resident frame's HBM and stream come from the C-ABI (pt_device_alloc, ABI 1.5) -- writes the same PFM
+    and PNG bytes as the in-process run of this test process, where torch may be loaded."""
+    import subprocess
+    import sys
+
+    from pytracer_amd.cli import cli
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    args = ["render", "--width", "160", "--height", "90", "--algorithm", "pathtracing", "--samples-per-pixel", "4", "--num-of-rays", "2"]
+    pfm0, png0 = str(tmp_path / "a.pfm"), str(tmp_path / "a.png")
+    r = CliRunner().invoke(cli, args + ["--pfm-output", pfm0, "--png-output", png0, "builtin:c2"])
+    assert r.exit_code == 0, r.output
+    pfm1, png1 = str(tmp_path / "b.pfm"), str(tmp_path / "b.png")
+    code = ("import sys; sys.modules['torch'] = None\n"
+            "from pytracer_amd.cli import cli\n"
+            "try:\n"
+            "    cli(sys.argv[1:], standalone_mode=False)\n"
+            "finally:\n"
+            "    mods = sorted(m for m in sys.modules if m == 'torch' or m.startswith('torch.'))\n"
+            "    assert mods == ['torch'] and sys.modules['torch'] is None, mods\n"
+            "    maps = open('/proc/self/maps').read()\n"
+            "    assert 'libptrace.so' in maps and 'site-packages/torch' not in maps and 'libtorch' not in maps\n"
+            "    print('no torch in this process')\n")
+    r = subprocess.run([sys.executable, "-c", code] + args + ["--pfm-output", pfm1, "--png-output", png1, "builtin:c2"],
+                       capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0 and "no torch in this process" in r.stdout, r.stdout + r.stderr
+    assert open(pfm0, "rb").read() == open(pfm1, "rb").read() and open(png0, "rb").read() == open(png1, "rb").read()

@@ -170,3 +170,22 @@ def test_sparse_shard_sizes_agree_between_library_and_python():
         assert L.pt_image_sparse_fixed_bytes(npx, abi.OUT_F32) == ptdist.sparse_fixed_bytes(npx, 4)
         assert L.pt_image_sparse_fixed_bytes(npx, abi.OUT_F64) == ptdist.sparse_fixed_bytes(npx, 8)
     assert L.pt_image_sparse_fixed_bytes(0, abi.OUT_F32) == -1 and L.pt_image_sparse_fixed_bytes(10, 7) == -1
+
+
+def test_the_build_recipe_watches_every_file_the_library_includes():
+    """`needs_build()` must see an edit of ANY header of the translation unit (pt_plan.h was missing)."""
+    import re
+
+    from pytracer_amd import build
+
+    seen, todo = set(), ["ptrace.hip"]
+    while todo:
+        f = todo.pop()
+        if f in seen:
+            continue
+        seen.add(f)
+        for inc in re.findall(r'#include\s+"([^"]+)"', open(os.path.join(build.CSRC, f)).read()):
+            todo.append(os.path.normpath(os.path.join(os.path.dirname(f), inc)))
+    deps = {os.path.normpath(d) for d in build.DEPS}
+    assert seen <= deps, seen - deps
+    assert "pt_plan.h" in deps and all(os.path.exists(os.path.join(build.CSRC, d)) for d in build.DEPS)

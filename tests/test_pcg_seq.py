@@ -164,6 +164,14 @@ def test_drop_in_default_is_the_reference_stream_and_advances_the_tracers_pcg(de
     ora2, _ = oracle.render(scene, cam, abi.copy_params(par, jitter_state=js, jitter_seq=jq), sqr_mode=oracle.SQR_MUL)
     oracle.set_sqr_mode(oracle.SQR_POW)
     assert util.bits_equal(image.array, ora2) and not util.bits_equal(image.array, first)
+    # ... and so does a tracer built WITHOUT a generator: its own PCG() is the reference's default PCG(42, 54),
+    # frame 1 = the frame above, frame 2 continues 2 W H S^2 draws further on
+    own = GpuImageTracer(image, camera, samples_per_side=S)
+    own.fire_all_rays(hm.FlatRenderer(world))
+    assert util.bits_equal(image.array, first) and own.pcg.state == want.state
+    own.fire_all_rays(hm.FlatRenderer(world))
+    assert util.bits_equal(image.array, ora2)
+    own.close()
     # the path tracer takes one generator per sample under "auto" (one per pixel on request), and "seq" is refused for it
     pt = hm.PathTracer(world, pcg=hm.PCG(45, 54), num_of_rays=1, max_depth=2)
     tracer.fire_all_rays(pt)

@@ -22,7 +22,7 @@ cp $f $OUT/kernel_stats.csv
 head -14 $OUT/kernel_stats.csv | cut -d, -f1-4
 if [ "$MODE" = "trace-only" ]; then exit 0; fi
 # PMC on the headline kernel: the same loops, a few hundred dispatches (counters are per dispatch; medians)
-BENCH="python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras --no-in-flight --pre-roll-ms 3 --min-timed-ms 3"
+BENCH="python3 $ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras --no-in-flight --headline-only --pre-roll-ms 3 --min-timed-ms 3"
 rocprofv3 --pmc $P1 --output-format csv -d $OUT/pmc1 -- $BENCH > $OUT/pmc1.log 2>&1
 rocprofv3 --pmc $P2 --output-format csv -d $OUT/pmc2 -- $BENCH > $OUT/pmc2.log 2>&1
 rocprofv3 --pmc $P3 --output-format csv -d $OUT/pmc2b -- $BENCH > $OUT/pmc2b.log 2>&1
