@@ -119,7 +119,6 @@ struct PtKArgs {
   const int4 *units;               // path tracer, second pass: (region, first flagged pixel | pixels << 8, region mask) per work unit
   int dome_slot;                   // path tracer, first pass: the sphere the camera is deepest inside (uniform pigments), or -1
   int dome_shortcut;               // 0: every tile goes through rays (pt_set_dome_shortcut; a measurement switch)
-  int tree_fuse;                   // pt_path_tree_kernel: spare lanes of a leaf round trace the parent's next child (1) or idle (0)
   int4 *units_handed;              // num_of_rays > 1: the units of the pixels the one-queue kernel hands to the tree kernel (handover_cap of them)
   double *handover;                // num_of_rays > 1: records of the pixels the one-queue kernel hands to the tree kernel (PT_Q_HEAVY)
   int handover_cap;                // ... how many fit
@@ -127,7 +126,6 @@ struct PtKArgs {
   int q_tail_budget;               // ... or this many rays after the pixel queue has run dry (0: never)
   int q_few_lanes;                 // ... or when, the queue dry, this many lanes of its wave or fewer still hold a pixel (0: never)
   int tree_jump_lds;               // pt_path_tree_kernel: where the leaf rounds' state-jump coefficients live in LDS (8-byte words; 2 x 4 x 64 pairs), -1 = none
-  int tree_uniform_max;            // pt_path_tree_kernel: worlds up to this many shapes are queried by the wave-uniform loop
   int dbg_trace_unit;              // -DPT_DEBUG_TIME builds: the unit whose steps are traced (PTRACE_TRACE_UNIT)
   int spec_draws;                  // ... PT_PCG_PIXEL: draws per sample assumed for a pixel nothing is known about yet
   unsigned long long *region_mask; // path tracer: [region] pixels the first pass left to pt_path_kernel

@@ -1096,18 +1096,20 @@ PT_DEV void path_trace(const PtKArgs &a) {
   add_ray_count(a, nrays, TILED ? 0 : cold_args(a)->count_base);
 }
 
-// every pixel of the frame, pixels from one queue (orthogonal camera; FLAGGED: the flagged pixels of a perspective frame
-// of num_of_rays > 1 when the device chose this kernel, PT_Q_CHOICE): throughput matters
-template <bool LDSF, bool FLAGGED = false>
+// every pixel of the frame, one lane per pixel, pixels from one queue, every shape tested by the wave-uniform loop, the frame
+// stack in HBM: worlds the tiled kernels do not take (no shape at all) and the measurement switch PTRACE_CULL=0 -- the
+// brute-force device path the culled kernels are checked against
 __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_WAVES_PATH, 8))) void pt_path_kernel(const PtKArgs a) {
-  path_trace<false, LDSF, false, false, 0, FLAGGED>(a);
+  path_trace<false, 0, false, false, 0, false>(a);
 }
-// ... FLAGGED with the scattered rays on per-lane candidate lists (world_query_lanes) and everything inline, like the second
-// pass by regions: it runs with 20 doubles per depth and lane of frame stack in LDS -- one workgroup per CU at the CLI's
+// The flagged pixels of a perspective frame of num_of_rays > 1 when the device chose this kernel (PT_Q_CHOICE): a lane per
+// pixel from one queue, the scattered rays on per-lane candidate lists (world_query_lanes) and everything inline, like the
+// second pass by regions: it runs with 20 doubles per depth and lane of frame stack in LDS -- one workgroup per CU at the CLI's
 // D = 3, one wave per SIMD --, so registers are no object and a step's latency is what counts
-// (HOME 0: the whole stack in HBM, same layout; 2: only the deepest slot in LDS -- see ws_get; two waves per SIMD in both)
+// (HOME 1: the whole stack in LDS; 2: only the deepest slot in LDS -- see frame_ref_split; two waves per SIMD)
 template <int LEAN, int HOME = 1>
 __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(HOME == 1 ? 1 : 2, 2))) void pt_path_flagged_kernel(const PtKArgs a) {
+  static_assert(HOME == 1 || HOME == 2, "the one-queue kernel's stack: all in LDS, or split");
   path_trace<false, HOME, true, false, LEAN, true>(a);
 }
 // second pass behind pt_tile_kernel<PATHTRACER> (perspective camera): the flagged pixels, by region

@@ -33,24 +33,19 @@
   X(scene_lds, "PTRACE_SCENE_LDS", 1)             /* second pass: the shapes' records staged in LDS when they fit */        \
   X(tile_wg_per_cu, "PTRACE_TILE_WG_PER_CU", 0)   /* 8x8 tile kernels: cap on resident workgroups per CU (0: 8) */          \
   X(tile4, "PTRACE_TILE4", 1)                     /* 0: never pt_tile4_kernel */                                            \
-  X(tile4_npx, "PTRACE_TILE4_NPX", 0)             /* 2 / 4: pixels per lane of pt_tile4_kernel (0: by frame size) */        \
   X(tile4_lds, "PTRACE_TILE4_LDS", 1)             /* pt_tile4_kernel<FLAT>: records staged in LDS for shading */            \
   X(qchoice, "PTRACE_QCHOICE", 1)                 /* 0: never the one-queue alternative, 2: always (measurement) */         \
   X(q_wg_per_cu, "PTRACE_Q_WG_PER_CU", 0)         /* the one-queue kernel: workgroups per CU (0: what its LDS frames allow) */  \
-  X(q_lds_frames, "PTRACE_Q_LDS_FRAMES", 1)       /* 0: the one-queue kernel's frame stack always in HBM */                 \
-  X(q_frames_home, "PTRACE_Q_FRAMES_HOME", -1)    /* ... 0 HBM, 1 LDS, 2 split (deepest slot in LDS); -1: by the plan */    \
+  X(q_frames_home, "PTRACE_Q_FRAMES_HOME", -1)    /* the one-queue kernel's frame stack: 1 LDS, 2 split (deepest slot in LDS); -1: by the plan */ \
   X(q_min_flagged, "PTRACE_Q_MIN_FLAGGED", -1)    /* >= 0: the flagged-pixel count from which the one-queue kernel works */ \
   X(q_budget, "PTRACE_Q_BUDGET", -1)              /* rays after which the one-queue kernel hands a pixel to the tree kernel (0: never; -1: by the plan) */ \
   X(q_tail_budget, "PTRACE_Q_TAIL_BUDGET", -1)    /* ... the same counted from the moment the pixel queue runs dry (0: never; -1: by the plan) */ \
   X(q_few_lanes, "PTRACE_Q_FEW_LANES", -1)        /* ... or when, the queue dry, a wave holds this many pixels or fewer (0: never; -1: by the plan) */ \
-  X(q_lanes, "PTRACE_Q_LANES", 1)                 /* 0: the one-queue alternative is pt_path_kernel<true, true> */          \
   X(p_maxpath, "PTRACE_P_MAXPATH", 0)             /* step batching of path_trace (0: by kernel) */                          \
   X(s_min, "PTRACE_S_MIN", 0)                                                                                               \
   X(unit_lanes_cap, "PTRACE_UNIT_LANES_CAP", -1)  /* lanes pt_unit_scatter may plan for (-1: the resident ones, 0: a unit = a region) */ \
   X(unit_min_rounds, "PTRACE_UNIT_MIN_ROUNDS", 0)                                                                           \
   X(spec_draws, "PTRACE_SPEC_DRAWS", -1)          /* PT_PCG_PIXEL: draws assumed per sample of an unknown pixel */          \
-  X(tree_uniform_max, "PTRACE_TREE_UNIFORM_MAX", 0)                                                                         \
-  X(tree_fuse, "PTRACE_TREE_FUSE", 1)                                                                                       \
   X(tree_scene_lds, "PTRACE_TREE_SCENE_LDS", 1)   /* tree kernel (small worlds): the shapes' records staged in LDS */       \
   X(tree_jump, "PTRACE_TREE_JUMP", 1)             /* tree kernel: leaf rounds' state jumps from a table in LDS */           \
   X(trace_unit, "PTRACE_TRACE_UNIT", 0)                                                                                     \
@@ -135,9 +130,6 @@ enum PtSecondPass {  // the path tracer's second-pass kernel
 #endif
 enum PtAltPass {  // the one-queue alternative launched IN FRONT OF the tree kernel (PT_Q_CHOICE: which of the two the device lets work)
   PT_ALT_NONE = 0,
-  PT_ALT_FLAGGED_LEAN_HBM,  // pt_path_flagged_kernel<1, false>
-  PT_ALT_FLAGGED_HBM,       // <0, false>
-  PT_ALT_PATH_UNIFORM,      // pt_path_kernel<true, true>
   PT_ALT_FLAGGED_LEAN_LDS,  // pt_path_flagged_kernel<1, 1>
   PT_ALT_FLAGGED_LDS,       // <0, 1>
   PT_ALT_FLAGGED_LEAN_SPLIT,  // pt_path_flagged_kernel<1, 2>: the deepest stack slot in LDS, the others in HBM
@@ -157,7 +149,6 @@ struct PtPlan {
   int second = PT_SECOND_NONE, alt = PT_ALT_NONE;
   bool simple_hoist = false;  // pt_simple_kernel<R, hoist>
   // tile4
-  int npx = 4;
   bool t4lds = false;
   unsigned grid4_x = 1, grid4_y = 1;
   // grids (workgroups of PT_BLOCK threads)
@@ -181,7 +172,8 @@ struct PtPlan {
                           // -1: q_budget_per_flagged x the frame's flagged pixels, at least q_budget_min -- pt_unit_scatter)
   double q_budget_per_flagged = 0.0;
   int q_budget_min = 0;
-  int q_home = 0;         // the one-queue alternative's frame stack: 0 HBM, 1 LDS, 2 split (deepest slot in LDS, the rest in HBM)
+  int q_home = 0;         // the one-queue alternative's frame stack: 1 LDS, 2 split (deepest slot in LDS, the rest in HBM)
+                          // (all of it in HBM was never faster than the split stack and was deleted in round 6)
   int frame_doubles = 6;
   int diag_lds = -1, grid_occ_lds = -1, scene_lds = -1;  // offsets as the kernels take them (PtKArgs)
   int q_diag_lds = -1;
@@ -258,7 +250,8 @@ static inline void pt_make_plan(const PtSceneFacts &s, const pt_camera *cam, con
       pl.frame_doubles = PT_PLAN_TREE_FRAME;
       frame_lds = tree_lds;
     }
-    pl.lds_frames = t.lds_frames != 0 && frame_lds + mask_lds <= PT_LDS_BUDGET;
+    // (the one-lane-per-pixel pt_path_kernel -- empty worlds, PTRACE_CULL=0 -- keeps its stack in HBM: its LDS variant went in round 6)
+    pl.lds_frames = regions && t.lds_frames != 0 && frame_lds + mask_lds <= PT_LDS_BUDGET;
     // the scale+translate records ride along in LDS when they fit (world_query_lanes gathers them per lane)
     const size_t base_lds = mask_lds + (pl.lds_frames ? frame_lds : 0);
     staged_bytes = (size_t)s.n_diag * PT_PLAN_DIAG_BYTES;
@@ -305,16 +298,9 @@ static inline void pt_make_plan(const PtSceneFacts &s, const pt_camera *cam, con
   // per lane (pt_tile4_kernel), a 2x2 block of tiles per workgroup of a 2-D grid
   pl.tile4 = pl.tile && t.tile4 != 0 && !pl.ortho && p->samples_per_side == 0 && s.n_shapes <= 256 &&
              (p->renderer == PT_RENDERER_ONOFF || p->renderer == PT_RENDERER_FLAT) && (n_ranks == 1 || row_block % 16 == 0);
-  // two pixels per lane (16x8 tiles) where the 16x16 tiles of the frame are fewer than the waves the chip holds
-  const long long tiles16 = (long long)((p->width + 15) / 16) * ((rows + 15) / 16);
-#ifndef PT_TILE4_NPX_SMALL
-#define PT_TILE4_NPX_SMALL 4  // pixels per lane of pt_tile4_kernel on frames with few 16x16 tiles (2: measured slower)
-#endif
-  pl.npx = t.tile4_npx == 2 || t.tile4_npx == 4 ? (int)t.tile4_npx : (tiles16 < (long long)s.n_cu * 4 * 5 ? PT_TILE4_NPX_SMALL : 4);
   if (pl.tile4) {
-    const int th = pl.npx == 4 ? 16 : 8;
     pl.grid4_x = (unsigned)(((p->width + 15) / 16 + 1) / 2);
-    pl.grid4_y = (unsigned)(((rows + th - 1) / th + 1) / 2);
+    pl.grid4_y = (unsigned)(((rows + 15) / 16 + 1) / 2);
     grid = (int)(pl.grid4_x * pl.grid4_y);
     const size_t scene_bytes = (size_t)s.n_shapes * (PT_PLAN_REC_BYTES + PT_PLAN_AUX_BYTES);
     pl.t4lds = t.tile4_lds != 0 && p->renderer == PT_RENDERER_FLAT && scene_bytes <= 24 * 1024;
@@ -333,11 +319,10 @@ static inline void pt_make_plan(const PtSceneFacts &s, const pt_camera *cam, con
   // slowest lane, and with 64 lanes one of them is at a shallow node nearly every iteration: two waves per SIMD do not
   // buy back an HBM round trip per iteration --; at D > 3 it equals or slightly beats the all-HBM stack it replaces.
   pl.q_home = q_frame_bytes <= PT_LDS_BUDGET ? 1 : 2;
-  if (t.q_lds_frames == 0) pl.q_home = 0;
-  if (t.q_frames_home >= 0 && t.q_frames_home <= 2) pl.q_home = (int)t.q_frames_home;
+  if (t.q_frames_home == 1 || t.q_frames_home == 2) pl.q_home = (int)t.q_frames_home;
   if (pl.q_home == 1 && q_frame_bytes > PT_LDS_BUDGET) pl.q_home = 2;
   pl.q_lds_frames = pl.q_home == 1;
-  const size_t q_frame_lds = pl.q_home == 1 ? q_frame_bytes : (pl.q_home == 2 ? (size_t)20 * B * sizeof(double) : 0);
+  const size_t q_frame_lds = pl.q_home == 1 ? q_frame_bytes : (size_t)20 * B * sizeof(double);
   pl.q_alt = pl.tree && t.qchoice != 0;
   if (pl.q_alt) {
     pl.q_tail_budget = t.q_tail_budget >= 0 ? (int)t.q_tail_budget : PT_Q_TAIL_BUDGET_DEFAULT;
@@ -486,7 +471,7 @@ static inline void pt_make_plan(const PtSceneFacts &s, const pt_camera *cam, con
         pw *= (double)fit_n;
         tree_rays += pw;
       }
-      const double step_ns = (6.0 + 0.02 * fit_shapes) * 1e3 * (pl.q_home != 0 ? 1.0 : 1.3);  // (all frames in HBM: measured on D = 4 ... 8)
+      const double step_ns = (6.0 + 0.02 * fit_shapes) * 1e3;
       const double t_tree = (4.5 + 0.045 * std::min(tree_rays, 500.0)) * (2048.0 / (8.0 * s.n_cu));
       const double t_queue = (2.0 + 0.01 * fit_shapes) * (1.0 + tree_rays / 800.0);
       if (t_tree > t_queue) pl.q_min = (long long)std::min(1e15, 1.1 * std::min(tree_rays, 80.0) * step_ns / (t_tree - t_queue));
@@ -535,12 +520,8 @@ static inline void pt_make_plan(const PtSceneFacts &s, const pt_camera *cam, con
                           q_frame_lds + q_diag_bytes <= (pl.q_home == 1 ? PT_LDS_BUDGET : PT_LDS_BUDGET / 2);
       pl.q_diag_lds = q_diag ? (int)(q_frame_lds / 8) : -1;
       pl.lds_q = q_frame_lds + (q_diag ? q_diag_bytes : 0);
-      if (pl.q_home == 0)
-        pl.alt = small_world ? PT_ALT_FLAGGED_LEAN_HBM : PT_ALT_FLAGGED_HBM;
-      else if (pl.q_home == 2)
+      if (pl.q_home == 2)
         pl.alt = small_world ? PT_ALT_FLAGGED_LEAN_SPLIT : PT_ALT_FLAGGED_SPLIT;
-      else if (!t.q_lanes)
-        pl.alt = PT_ALT_PATH_UNIFORM;
       else
         pl.alt = small_world ? PT_ALT_FLAGGED_LEAN_LDS : PT_ALT_FLAGGED_LDS;
     }
@@ -549,7 +530,7 @@ static inline void pt_make_plan(const PtSceneFacts &s, const pt_camera *cam, con
   // one lane per pixel
   pl.kernel = pathtracer ? PT_KERNEL_PATH : PT_KERNEL_SIMPLE;
   pl.simple_hoist = pl.hoist;
-  if (pathtracer) pl.lds_main = pl.lds_frames ? frame_lds : 0;
+  if (pathtracer) pl.lds_main = 0;
 }
 
 static inline const char *pt_plan_kernel_name(const PtPlan &pl, int renderer, int which, char *buf, size_t n) {
@@ -567,7 +548,7 @@ static inline const char *pt_plan_kernel_name(const PtPlan &pl, int renderer, in
     if (pl.zero_frame)
       snprintf(buf, n, "memset");
     else if (pl.tile4)
-      snprintf(buf, n, "pt_tile4_kernel<%s, %s, %d>", r, pl.t4lds ? "LDS" : "noLDS", pl.npx);
+      snprintf(buf, n, "pt_tile4_kernel<%s, %s>", r, pl.t4lds ? "LDS" : "noLDS");
     else if (pl.path_tiled) {
       static const char *S2[9] = {"", "pt_path_regions_kernel<LDS, SCENE, LEAN>", "pt_path_regions_kernel<LDS, SCENE>",
                                   "pt_path_regions_kernel<LDS, NOGRID>", "pt_path_regions_kernel<LDS>", "pt_path_regions_kernel<HBM>",
@@ -576,12 +557,11 @@ static inline const char *pt_plan_kernel_name(const PtPlan &pl, int renderer, in
     } else if (pl.tile)
       snprintf(buf, n, "pt_tile_kernel<%s%s>", r, TM[pl.tile_mode]);
     else if (pl.kernel == PT_KERNEL_PATH)
-      snprintf(buf, n, "pt_path_kernel<%s>", pl.lds_frames ? "LDS" : "HBM");
+      snprintf(buf, n, "pt_path_kernel");
     else
       snprintf(buf, n, "pt_simple_kernel<%s, %s>", r, pl.simple_hoist ? "HOIST" : "noHOIST");
   } else if (which == 3) {
-    static const char *A[8] = {"", "pt_path_flagged_kernel<LEAN, HBM>", "pt_path_flagged_kernel<HBM>", "pt_path_kernel<LDS, FLAGGED>",
-                               "pt_path_flagged_kernel<LEAN, LDS>", "pt_path_flagged_kernel<LDS>",
+    static const char *A[5] = {"", "pt_path_flagged_kernel<LEAN, LDS>", "pt_path_flagged_kernel<LDS>",
                                "pt_path_flagged_kernel<LEAN, SPLIT>", "pt_path_flagged_kernel<SPLIT>"};
     snprintf(buf, n, "%s", A[pl.alt]);
   }

@@ -29,11 +29,14 @@ PT_DEV void hit_details(RP rec, AP ax, const Ray &r, double t, Hit &h, bool need
     nn.y = keep ? hp.y : -hp.y;
     nn.z = keep ? hp.z : -hp.z;
     if (need_uv) {  // shapes.py:36-42
-      const double uu = (INL ? atan2(hp.y, hp.x) : pt_atan2(hp.y, hp.x)) / (2.0 * PT_PI);
+      // (atan2 / acos ALWAYS behind a call, also in the inlined second-pass kernels: a sphere's (u, v) is needed only under a
+      //  checkered or image pigment, and inlined their ~35 polynomial constants were hoisted to the kernels' entry and spilled --
+      //  152 - 328 B of scratch re-read one dependent load per coefficient, tools/scratch_sites.py; the values are ocml's either way)
+      const double uu = pt_atan2(hp.y, hp.x) / (2.0 * PT_PI);
       h.u = (uu >= 0.0) ? uu : uu + 1.0;
       double z = hp.z;  // the reference raises ValueError outside [-1, 1]: clamp
       z = (z > 1.0) ? 1.0 : ((z < -1.0) ? -1.0 : z);
-      h.v = (INL ? acos(z) : pt_acos(z)) / PT_PI;
+      h.v = pt_acos(z) / PT_PI;
     }
   } else {
     nn.x = 0.0;

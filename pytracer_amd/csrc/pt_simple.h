@@ -22,6 +22,17 @@ PT_DEV V3 pointlight_shade(const PtKArgs &a, const Ray &ray, int hit, double bes
     res.y = ca->ambient[1] + em.y;
     res.z = ca->ambient[2] + em.z;
   }
+  // the BRDF's pigment at the hit point (materials.py:129, 172: `self.pigment.get_color(uv)`) does not depend on the light: the
+  // reference evaluates it once per visible light, here once per hit -- the same value, and (u, v), the shape's record and
+  // the checker's arithmetic no longer live across the shadow rays' queries
+  V3 pc = {0.0, 0.0, 0.0};
+  bool diffuse = true;
+  double spec_threshold = 0.0;
+  if (lit) {
+    pc = brdf_pigment(a, ax, h.u, h.v);
+    diffuse = ax->brdf_kind == PT_BRDF_DIFFUSE;
+    spec_threshold = ax->brdf_param;
+  }
   const int n_lights = ca->n_lights;
   const PtLight *lights = ca->lights;
   for (int l = 0; l < n_lights; ++l) {
@@ -49,8 +60,7 @@ PT_DEV V3 pointlight_shade(const PtKArgs &a, const Ray &ray, int hit, double bes
       const double q = lr / dist;
       const double df = (lr > 0) ? q * q : 1.0;
       V3 bc = {0.0, 0.0, 0.0};
-      if (ax->brdf_kind == PT_BRDF_DIFFUSE) {  // materials.py:129-130
-        const V3 pc = brdf_pigment(a, ax, h.u, h.v);
+      if (diffuse) {  // materials.py:129-130
         const double k = 1.0 / PT_PI;
         bc.x = pc.x * k;
         bc.y = pc.y * k;
@@ -59,7 +69,7 @@ PT_DEV V3 pointlight_shade(const PtKArgs &a, const Ray &ray, int hit, double bes
         const V3 out_dir = {-ray.d.x, -ray.d.y, -ray.d.z};
         const double th_in = pt_acos(dot3(normalize3(h.n), normalize3(in_dir)));
         const double th_out = pt_acos(dot3(normalize3(h.n), normalize3(out_dir)));
-        if (fabs(th_in - th_out) < ax->brdf_param) bc = brdf_pigment(a, ax, h.u, h.v);
+        if (fabs(th_in - th_out) < spec_threshold) bc = pc;
       }
       res.x = res.x + bc.x * L[3] * cos_theta * df;
       res.y = res.y + bc.y * L[4] * cos_theta * df;

@@ -967,15 +967,15 @@ PT_DEV void sphere_roots1(const PtKArgs &a, int slot, bool active, double tmin, 
 
 // SLDS (small worlds, Flat): the shapes' records (128 B + 256 B each) are staged in LDS by the workgroup and shading
 //   gathers from there instead of through the vector memory path (C2: 14.4 -> 13.9 us per frame).
-// NPX = 4: 16x16 tiles, four pixels per lane.  NPX = 2: 16x8 tiles, two pixels per lane (the upper two quadrants only) --
-//   twice the waves with half the pixels each, for frames whose 16x16 tiles would not fill the chip.
+// (A variant with 16x8 tiles and two pixels per lane -- twice the waves, half the pixels each, for frames whose 16x16 tiles do
+//  not fill the chip -- was measured slower on every frame and deleted in round 6: profiles/DROPPED_VARIANTS.md.)
 #ifndef PT_TILE4_WAVES
 #define PT_TILE4_WAVES 4  // waves per SIMD the register allocation aims at (5 / 6 measured: profiles/DROPPED_VARIANTS.md)
 #endif
-template <int RENDERER, bool SLDS = false, int NPX = 4>
+template <int RENDERER, bool SLDS = false>
 __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_TILE4_WAVES, 8))) void pt_tile4_kernel(const PtKArgs a) {
-  static_assert(NPX == 2 || NPX == 4, "two or four pixels per lane");
-  constexpr int TH = NPX == 4 ? 16 : 8;  // tile height
+  constexpr int NPX = 4;  // pixels per lane: the four 8x8 quadrants of the tile
+  constexpr int TH = 16;  // tile height
   constexpr bool ANYHIT = RENDERER == PT_RENDERER_ONOFF;
 #ifdef PT_DEBUG_TIME
   // cycles of this wave in: 0 prologue, 1 cone, 2 cull, 3 dome tile, 4 rays, 5 query, 6 shade, 7 store
@@ -1038,7 +1038,7 @@ __global__ __launch_bounds__(PT_BLOCK) __attribute__((amdgpu_waves_per_eu(PT_TIL
     // pixel k of this lane: quadrant (k & 1, k >> 1)
     const int colA = tx * 16 + (lane & 7), colB = colA + 8;
     const int lrowA = lr0 + (lane >> 3), lrowB = lrowA + 8;
-    const bool okcA = colA < W, okcB = colB < W, okrA = lrowA < rows_local, okrB = NPX == 4 && lrowB < rows_local;
+    const bool okcA = colA < W, okcB = colB < W, okrA = lrowA < rows_local, okrB = lrowB < rows_local;
     const bool act[4] = {okcA && okrA, okcB && okrA, okcA && okrB, okcB && okrB};
     const int ccA = okcA ? colA : W - 1, ccB = okcB ? colB : W - 1;  // idle lanes stand on a real pixel
     const int crA = okrA ? lrowA : rows_local - 1, crB = okrB ? lrowB : rows_local - 1;

@@ -126,8 +126,6 @@ PT_DEV void path_tree(const PtKArgs &a) {
   unsigned long long nrays = 0;  // (wave-uniform: committed rays of this wave's pixels)
   // small worlds: the wave-uniform loop over every shape (records through the scalar cache) has a shorter critical
   // path than per-lane candidate lists -- and a round's latency, not its throughput, is what a pixel's tree waits for
-  const bool uniform_loop = a.n_shapes <= cold_args(a)->tree_uniform_max;
-  const bool fuse_on = cold_args(a)->tree_fuse != 0;
   // lane b: complete leaf families so far (of this wave, whatever the pixel) that had b survivors -- where the next family's
   // guesses go (an exponentially fading count)
   int b_count = 0;
@@ -433,7 +431,7 @@ PT_DEV void path_tree(const PtKArgs &a) {
         //  tree of the CLI's N = 10, D = 3 saved one round per leaf family this way in round 3 and saves the ten re-traced
         //  children of the root now.)
         int up = 0;
-        if (leaf && sp >= 2 && t_next == 0 && nrows == N && leaf_lanes < 64 && fuse_on)
+        if (leaf && sp >= 2 && t_next == 0 && nrows == N && leaf_lanes < 64)
           for (int u = 1; u <= sp - 1; ++u)
             if ((int)rfl_f64(frame(sp - 1 - u)[19]) < N) {
               up = u;
@@ -485,11 +483,9 @@ PT_DEV void path_tree(const PtKArgs &a) {
         }
         PT_TT(2);
         double ts = INFINITY;
-        int hs;
-        if (uniform_loop)
-          hs = world_query<false, false>(a, ray, INFINITY, ts, act);
-        else
-          hs = world_query_lanes<false, SMALL ? 1 : 0>(a, ray, INFINITY, ts, act, diag_lds);
+        // (the wave-uniform loop over all shapes was measured against the per-lane candidate lists on C3, N = 10 -- 2.48 against
+        //  1.92 ms -- and deleted in round 6)
+        const int hs = world_query_lanes<false, SMALL ? 1 : 0>(a, ray, INFINITY, ts, act, diag_lds);
         PT_TT(3);
         if (act) shade_ray(hs, ts, sib ? sp - up : sp);
         PT_TT(4);

@@ -110,7 +110,7 @@ struct pt_scene {
   int queue_parity = 0;
   bool queue_clean = false;
   PtKArgs *args_dev = nullptr;          // device copy of the argument block (cold fields)
-  PtKArgs *args_dev2 = nullptr;         // ... of pt_path_kernel<., true>'s, when a frame enqueues both second-pass kernels (PT_Q_CHOICE)
+  PtKArgs *args_dev2 = nullptr;         // ... of pt_path_flagged_kernel's, when a frame enqueues both second-pass kernels (PT_Q_CHOICE)
   PtKArgs args2_last;
   bool args2_valid = false;
   hipStream_t args2_stream = nullptr;
@@ -1193,8 +1193,6 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
     a.region_keys = s->region_keys;
     a.region_mask = s->region_mask;
     a.spec_draws = pl.spec_draws;
-    a.tree_uniform_max = (int)tn.tree_uniform_max;  // (measured on C3, N = 10: the uniform loop 2.48 ms, candidate lists 1.92)
-    a.tree_fuse = (int)tn.tree_fuse;
     a.tree_jump_lds = pl.tree_jump_lds;
     if (pl.q_alt) {
       int rc = ensure(&s->handover, &s->handover_doubles, pl.handover_doubles, st);
@@ -1281,18 +1279,17 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
     // small worlds: the shapes' records ride in LDS for shading (Flat; OnOff reads none of them)
     s->stats.lds_bytes = (int)pl.lds_main;
     const dim3 grid4(pl.grid4_x, pl.grid4_y, 1);
-#define PT_LAUNCH4(R_, L_, N_)                                                                                              \
+#define PT_LAUNCH4(R_, L_)                                                                                                  \
   do {                                                                                                                      \
-    main_fn = (const void *)pt_tile4_kernel<R_, L_, N_>;                                                                    \
-    hipExtLaunchKernelGGL((pt_tile4_kernel<R_, L_, N_>), grid4, dim3(PT_BLOCK), pl.lds_main, st, ev_a, ev_b, 0, a);         \
+    main_fn = (const void *)pt_tile4_kernel<R_, L_>;                                                                        \
+    hipExtLaunchKernelGGL((pt_tile4_kernel<R_, L_>), grid4, dim3(PT_BLOCK), pl.lds_main, st, ev_a, ev_b, 0, a);             \
   } while (0)
-    if (R == PT_RENDERER_ONOFF) {
-      if (pl.npx == 4) PT_LAUNCH4(PT_RENDERER_ONOFF, false, 4); else PT_LAUNCH4(PT_RENDERER_ONOFF, false, 2);
-    } else if (pl.t4lds) {
-      if (pl.npx == 4) PT_LAUNCH4(PT_RENDERER_FLAT, true, 4); else PT_LAUNCH4(PT_RENDERER_FLAT, true, 2);
-    } else {
-      if (pl.npx == 4) PT_LAUNCH4(PT_RENDERER_FLAT, false, 4); else PT_LAUNCH4(PT_RENDERER_FLAT, false, 2);
-    }
+    if (R == PT_RENDERER_ONOFF)
+      PT_LAUNCH4(PT_RENDERER_ONOFF, false);
+    else if (pl.t4lds)
+      PT_LAUNCH4(PT_RENDERER_FLAT, true);
+    else
+      PT_LAUNCH4(PT_RENDERER_FLAT, false);
 #undef PT_LAUNCH4
   } else if (pl.tile || pl.path_tiled) {
     const size_t lds = pl.lds_tile;
@@ -1367,9 +1364,6 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
     PT_LAUNCH((K_), pl.grid_q, pl.lds_q, false, aq);            \
   } while (0)
         switch (pl.alt) {
-          case PT_ALT_FLAGGED_LEAN_HBM: PT_ALT((pt_path_flagged_kernel<1, 0>)); break;
-          case PT_ALT_FLAGGED_HBM: PT_ALT((pt_path_flagged_kernel<0, 0>)); break;
-          case PT_ALT_PATH_UNIFORM: PT_ALT((pt_path_kernel<true, true>)); break;
           case PT_ALT_FLAGGED_LEAN_LDS: PT_ALT((pt_path_flagged_kernel<1, 1>)); break;
           case PT_ALT_FLAGGED_LEAN_SPLIT: PT_ALT((pt_path_flagged_kernel<1, 2>)); break;
           case PT_ALT_FLAGGED_SPLIT: PT_ALT((pt_path_flagged_kernel<0, 2>)); break;
@@ -1402,12 +1396,7 @@ static int launch(pt_scene *s, const pt_camera *cam, const pt_params *p, void *o
       }
     }
   } else if (R == PT_RENDERER_PATHTRACER) {
-    if (pl.lds_frames) {
-      HIP_TRY(path_lds_limit((const void *)pt_path_kernel<true>, pl.lds_main));
-      PT_LAUNCH((pt_path_kernel<true>), pl.grid, pl.lds_main, true, a);
-    } else {
-      PT_LAUNCH((pt_path_kernel<false>), pl.grid, 0, true, a);
-    }
+    PT_LAUNCH(pt_path_kernel, pl.grid, 0, true, a);
   } else {
 #define PT_SIMPLE(R_)                                                              \
   do {                                                                             \
@@ -1928,7 +1917,7 @@ static void plan_info(const PtPlan &pl, const PtSceneFacts &f, const pt_params *
   out->grid_alt = pl.grid_q;
   out->grid4_x = (int)pl.grid4_x;
   out->grid4_y = (int)pl.grid4_y;
-  out->npx = pl.npx;
+  out->npx = 4;  // (pt_tile4_kernel: four pixels per lane; the two-pixel variant is gone)
   out->lds_first = pl.path_tiled ? (long long)pl.lds_tile : 0;
   out->lds_main = (long long)pl.lds_main;
   out->lds_alt = (long long)pl.lds_q;

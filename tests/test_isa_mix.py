@@ -20,7 +20,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 LLVM = "/opt/rocm/lib/llvm/bin"
 pytestmark = pytest.mark.skipif(not os.path.exists(os.path.join(LLVM, "llvm-objdump")) or shutil.which("c++filt") is None,
                                 reason="needs the ROCm llvm tools")
-KERNEL = "pt_tile4_kernel<1, true, 4>"
+KERNEL = "pt_tile4_kernel<1, true>"
 
 
 def test_classes_and_prices():

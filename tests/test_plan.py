@@ -53,11 +53,11 @@ def tuning():
 # ---- BASELINE.json's configurations -----------------------------------------------------------------------------------------
 def test_c2_is_one_launch_of_the_16x16_tile_kernel():
     p = plan(world(32, plane=True), 1280, 720, renderer=abi.RENDERER_FLAT)
-    assert p.kernels == ["pt_tile4_kernel<FLAT, LDS, 4>"] and p.kernel == abi.KERNEL_TILE4
+    assert p.kernels == ["pt_tile4_kernel<FLAT, LDS>"] and p.kernel == abi.KERNEL_TILE4
     assert (p.grid4_x, p.grid4_y, p.grid, p.npx) == (40, 23, 920, 4)  # 80 x 45 tiles of 16 x 16, 2 x 2 per workgroup
     assert p.lds_main == 33 * (128 + 256) and p.tile4_lds == 1 and p.hoist == 1 and p.frame_stack is None
     q = plan(world(32, plane=True), 1280, 720, renderer=abi.RENDERER_ONOFF)
-    assert q.kernels == ["pt_tile4_kernel<ONOFF, noLDS, 4>"] and q.lds_main == 0
+    assert q.kernels == ["pt_tile4_kernel<ONOFF, noLDS>"] and q.lds_main == 0
 
 
 def test_c3_two_passes_frame_stack_and_scene_in_lds():
@@ -134,12 +134,12 @@ def test_world_sizes():
     flat3, flat4 = world(3), world(4)
     assert plan(flat3, 320, 180, renderer=abi.RENDERER_FLAT).kernels == ["pt_simple_kernel<FLAT, HOIST>"]
     assert plan(flat4, 320, 180, renderer=abi.RENDERER_FLAT).main_kernel.startswith("pt_tile4_kernel<FLAT")
-    assert plan(world(256), 320, 180, renderer=abi.RENDERER_FLAT).main_kernel == "pt_tile4_kernel<FLAT, noLDS, 4>"  # 96 KB of records: not staged
+    assert plan(world(256), 320, 180, renderer=abi.RENDERER_FLAT).main_kernel == "pt_tile4_kernel<FLAT, noLDS>"  # 96 KB of records: not staged
     assert plan(world(257), 320, 180, renderer=abi.RENDERER_FLAT).kernels == ["pt_cell_kernel", "pt_tile_kernel<FLAT, HIER>"]
     assert plan(world(127), 320, 180, **C3).ball_levels == 0 and plan(world(129), 320, 180, **C3).ball_levels == 1
     empty = flatten.flatten_world(hm.World())
     assert plan(empty, 64, 36, renderer=abi.RENDERER_FLAT).kernels == ["pt_simple_kernel<FLAT, noHOIST>"]
-    assert plan(empty, 64, 36, **C3).kernels == ["pt_path_kernel<LDS>"]
+    assert plan(empty, 64, 36, **C3).kernels == ["pt_path_kernel"]
     assert plan(world(32), 64, 36, **dict(C3, max_depth=-1)).kernels == ["memset"]
 
 
@@ -170,15 +170,12 @@ def test_switches_select_the_documented_variants(tuning):
     tuning("tile4", 0)
     assert plan(w, 1280, 720, renderer=abi.RENDERER_FLAT).kernels == ["pt_tile_kernel<FLAT>"]
     tuning("tile4", 1)
-    tuning("PTRACE_TILE4_NPX", 2)  # (environment spelling accepted too)
-    assert plan(w, 1280, 720, renderer=abi.RENDERER_FLAT).main_kernel == "pt_tile4_kernel<FLAT, LDS, 2>"
-    tuning("tile4_npx", 0)
-    tuning("tile4_lds", 0)
-    assert plan(w, 1280, 720, renderer=abi.RENDERER_FLAT).main_kernel == "pt_tile4_kernel<FLAT, noLDS, 4>"
+    tuning("PTRACE_TILE4_LDS", 0)  # (environment spelling accepted too)
+    assert plan(w, 1280, 720, renderer=abi.RENDERER_FLAT).main_kernel == "pt_tile4_kernel<FLAT, noLDS>"
     tuning("tile4_lds", 1)
     tuning("cull", 0)
     assert plan(w, 1280, 720, renderer=abi.RENDERER_FLAT).kernels == ["pt_simple_kernel<FLAT, HOIST>"]
-    assert plan(world(32), 1280, 720, **C3).kernels == ["pt_path_kernel<LDS>"]
+    assert plan(world(32), 1280, 720, **C3).kernels == ["pt_path_kernel"]  # (one lane per pixel, every shape, the frame stack in HBM)
     tuning("cull", 1)
     tuning("tree", 0)
     assert plan(world(32), 1280, 720, **CLI).kernels == ["pt_tile_kernel<PATHTRACER>", "pt_path_regions_kernel<LDS, NOGRID>"]  # (120 KB of frames: no room for the scene)
@@ -188,18 +185,18 @@ def test_switches_select_the_documented_variants(tuning):
     tuning("qchoice", 2)
     assert plan(world(32), 1280, 720, **CLI).q_min_flagged == 0
     tuning("qchoice", 1)
-    tuning("q_lds_frames", 0)
-    assert plan(world(32), 1280, 720, **CLI).alt_kernel == "pt_path_flagged_kernel<LEAN, HBM>"
-    tuning("q_lds_frames", 1)
     tuning("q_frames_home", 2)  # only the deepest slot in LDS (40 KB: two workgroups per CU), the others in HBM: measured slower at D <= 3
     two = plan(world(32), 1280, 720, **CLI)
     assert two.alt_kernel == "pt_path_flagged_kernel<LEAN, SPLIT>" and two.grid_alt == 512 and two.lds_alt == 20 * 256 * 8 + 32 * 64
     assert two.workspace_bytes == 3 * 20 * 256 * 8 * 512
     tuning("q_frames_home", 1)
     assert plan(world(32), 1280, 720, **dict(CLI, max_depth=5)).alt_kernel == "pt_path_flagged_kernel<LEAN, SPLIT>"  # (does not fit: split)
-    tuning("q_lanes", 0)
-    assert plan(world(32), 1280, 720, **CLI).alt_kernel == "pt_path_kernel<LDS, FLAGGED>"
-    tuning("q_lanes", 1)
+    for gone in ("q_lanes", "q_lds_frames", "tile4_npx", "tree_fuse", "tree_uniform_max"):  # variants deleted in round 6: no switch left
+        with pytest.raises(Exception, match="unknown tuning switch"):
+            device.set_tuning(gone, 0)
+    tuning("q_frames_home", 0)  # (all of the stack in HBM is gone: not a choice any more, the plan decides)
+    assert plan(world(32), 1280, 720, **CLI).alt_kernel == "pt_path_flagged_kernel<LEAN, LDS>"
+    tuning("q_frames_home", -1)
     tuning("q_budget", 5)  # (the GPU suite's way of handing nearly every pixel over in the middle of its tree)
     assert plan(world(32), 1280, 720, **CLI).alt_budget == 5
     tuning("q_budget", 0)

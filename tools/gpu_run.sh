@@ -8,6 +8,9 @@
 #   gloo2[:FAIL]      PT_DIST_BACKEND=gloo python bench.py --gpus 2 --steps 4 --warmup 2 (two ranks share the card);
 #                     FAIL = "timed sparse:raise" | "timed sparse:hang" rehearses the fallback paths (PT_BENCH_FAIL)
 #   kbench:CFG        python tools/kbench.py CFG --rounds 4
+#   ab:LIBS:CFGS      A/B of library builds: for every name in LIBS (commas; `cur` = pytracer_amd/libptrace.so, anything else
+#                     build_variants/libptrace_<name>.so, tools/build_variant.sh) tools/kbench.py CFGS (commas) --rounds 8, the whole
+#                     list twice, alternating -> ab_<LIBS>.txt
 #   py:SCRIPT[:ARGS]  python SCRIPT ARGS (ARGS separated by commas)
 # TAG (environment, default r06) names the output directory.
 set -e -o pipefail
@@ -41,6 +44,16 @@ for step in "$@"; do
       cp bench_detail.json ${log%.log}_detail.json; grep "^\[bench " $log | cut -c1-200; tail -1 $log | cut -c1-4200 ;;
     kbench)
       timeout -k 10 600 python3 tools/kbench.py $arg --rounds 4 > $OUT/kbench_$(echo "$arg" | tr ' :' '__').txt 2>&1; tail -12 $OUT/kbench_$(echo "$arg" | tr ' :' '__').txt ;;
+    ab)
+      libs=$(echo "${arg%%:*}" | tr ',' ' '); cfgs=$(echo "${arg#*:}" | tr ',' ' ')
+      log=$OUT/ab_$(echo "${arg%%:*}" | tr ',' '_').txt
+      : > $log
+      for pass in 1 2; do for l in $libs; do
+        lib=pytracer_amd/libptrace.so; [ "$l" != "cur" ] && lib=build_variants/libptrace_$l.so
+        echo "== $l (pass $pass)" >> $log
+        PTRACE_LIB=$lib timeout -k 10 600 python3 tools/kbench.py $cfgs --rounds 8 2>&1 | cut -c1-120 >> $log
+      done; done
+      cat $log ;;
     py)
       script=${arg%%:*}; rest=""; [ "$script" != "$arg" ] && rest=$(echo "${arg#*:}" | tr ',' ' ')
       timeout -k 10 900 python3 $script $rest > $OUT/$(basename $script .py).txt 2>&1 || { tail -20 $OUT/$(basename $script .py).txt; exit 1; }

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """What a kernel's VALU instructions ARE, instruction by instruction, and what they cost -- from the code object itself.
 
-    python tools/isa_mix.py "pt_tile4_kernel<1, true, 4>" [--lib libptrace.so] [--pmc profiles/pmc_c2.json [--update]]
+    python tools/isa_mix.py "pt_tile4_kernel<1, true>" [--lib libptrace.so] [--pmc profiles/pmc_c2.json [--update]]
 
 rocprofv3's class counters (SQ_INSTS_VALU_ADD_F64, ..._INT32, ...) leave a third of pt_tile4_kernel's VALU instructions in no
 class -- compares, selects, moves, lane reads, division helpers -- and bench.py priced those at a guessed 3 cycles (VERDICT r4

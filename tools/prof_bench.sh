@@ -29,8 +29,8 @@ rocprofv3 --pmc $P3 --output-format csv -d $OUT/pmc2b -- $BENCH > $OUT/pmc2b.log
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc3 -- $BENCH > $OUT/pmc3.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc4 -- $BENCH > $OUT/pmc4.log 2>&1
 SRC="rocprofv3 --pmc (five separate passes: SQ issue counters, fp64 / integer instruction classes, fp32 / conversion classes, FETCH_SIZE, WRITE_SIZE) on '$BENCH'; medians over the dispatches of the kernel; tools/prof_bench.sh $TAG"
-( cd $ROOT && python3 tools/pmc_summary.py $OUT/pmc1 $OUT/pmc2 $OUT/pmc2b $OUT/pmc3 $OUT/pmc4 --kernel "pt_tile4_kernel<1, true, 4>" --grid 235520 --json $OUT/pmc_c2.json --source "$SRC" > /dev/null )
-( cd $ROOT && python3 tools/isa_mix.py "pt_tile4_kernel<1, true, 4>" --pmc $OUT/pmc_c2.json --update > $OUT/isa_mix_c2.txt 2>&1 ) || true
+( cd $ROOT && python3 tools/pmc_summary.py $OUT/pmc1 $OUT/pmc2 $OUT/pmc2b $OUT/pmc3 $OUT/pmc4 --kernel "pt_tile4_kernel<1, true>" --grid 235520 --json $OUT/pmc_c2.json --source "$SRC" > /dev/null )
+( cd $ROOT && python3 tools/isa_mix.py "pt_tile4_kernel<1, true>" --pmc $OUT/pmc_c2.json --update > $OUT/isa_mix_c2.txt 2>&1 ) || true
 if [ "$MODE" = "c2-only" ]; then cat $OUT/pmc_c2.json; exit 0; fi
 # the other kernels, each through tools/kbench.py (one configuration, several rounds in one process): three PMC passes
 #   name : kbench configuration : kernel substring : json : what it is
