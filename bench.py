@@ -1094,21 +1094,31 @@ class Watchdog:
                 phase, deadline = self.phase, self.deadline
             if deadline is None or time.perf_counter() < deadline:
                 continue
-            why = f"phase '{phase}' exceeded its deadline"
-            if self.rank == 0:
-                print(f"[bench] {why}: leaving", file=sys.stderr, flush=True)
-                if self.fallback is not None:
-                    full, compact = self.fallback
-                    full = dict(full)
-                    full["gather"] = dict(full.get("gather") or {}, used="whole", fallback_reason=f"{why} (the job ended there)")
-                    full["phases_not_run"] = why
-                    emit(full, compact_multi(full))
-                else:
-                    stub = dict(self.error_stub, error=why)
-                    emit(stub, dict(stub))
+            self.bail(f"phase '{phase}' exceeded its deadline")
+
+    def bail(self, why):
+        """End the job from this rank NOW (any thread): rank 0 prints the line measured so far, every rank leaves with the same
+        status -- 0 when a complete measurement exists, 1 otherwise."""
+        with self.lock:
+            if getattr(self, "bailing", False):
+                time.sleep(30.0)  # (another thread of this rank is already on its way out)
+                os._exit(0 if self.have_fallback else 1)
+            self.bailing = True
+        if self.rank == 0:
+            print(f"[bench] {why}: leaving", file=sys.stderr, flush=True)
+            if self.fallback is not None:
+                full = dict(self.fallback[0])
+                full["gather"] = dict(full.get("gather") or {})
+                if full["gather"].get("used") != "sparse":
+                    full["gather"].update(used="whole", fallback_reason=f"{why} (the job ended there)")
+                full["phases_not_run"] = why
+                emit(full, compact_multi(full))
             else:
-                time.sleep(3.0)  # (rank 0 prints first)
-            os._exit(0 if self.have_fallback else 1)
+                stub = dict(self.error_stub, error=why)
+                emit(stub, dict(stub))
+        else:
+            time.sleep(3.0)  # (rank 0 prints first)
+        os._exit(0 if self.have_fallback else 1)
 
 
 PHASE_DEADLINE_S = float(os.environ.get("PT_BENCH_PHASE_S", "120"))
@@ -1154,6 +1164,8 @@ class Agreement:
                 self.error = f"{phase}: another rank failed"
         except Exception as e:  # noqa: BLE001
             self.error = self.error or f"{phase}: agreement failed: {type(e).__name__}: {e}"[:400]
+            if self.watchdog is not None:  # the ranks can no longer talk (a peer has left): nothing collective can follow
+                self.watchdog.bail(f"phase '{phase}': the ranks' agreement failed ({type(e).__name__}: a peer has left?)")
         if self.watchdog is not None:
             self.watchdog.disarm()
         self.log.append((phase, time.perf_counter() - t0))

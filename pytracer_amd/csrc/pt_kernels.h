@@ -25,7 +25,9 @@
 //                         pixel's samples spread over lanes, speculated generator states committed in order;
 //                         scattered rays walk per-lane candidate lists (world_query_lanes) or a uniform grid.
 //   pt_path_tree_kernel   ... for num_of_rays > 1: one pixel per wave, a node's children on lanes.
-//   pt_simple_kernel / pt_path_kernel   one lane per pixel (tiny worlds, orthogonal path tracing, PTRACE_CULL=0): the
+//   pt_path_flagged_kernel  ... for frames FULL of scattering pixels: a lane per flagged pixel from one queue, in front of
+//                         the tree kernel, which takes over the pixels whose trees outlast the frame (PT_Q_CHOICE, PT_Q_HEAVY).
+//   pt_simple_kernel / pt_path_kernel   one lane per pixel (worlds of fewer than four shapes, PTRACE_CULL=0): the
 //                         shape loop index is wave-uniform, records come through the scalar cache into SGPRs.
 // MFMA is not used (no dense contraction on this path); what binds is vector issue and dependent latency
 // (profiles/r03_issue_rates.txt: fp64 4, fp32 / int32 2, SALU 4 SIMD-cycles per wave-instruction).
@@ -47,9 +49,6 @@
 #endif
 #ifndef PT_REGION
 #define PT_REGION 8  // path tracer: a wave's region is PT_REGION x PT_REGION pixels
-#endif
-#ifndef PT_WAVES_PATH
-#define PT_WAVES_PATH 3
 #endif
 
 // Uniform (wave-invariant) reads go through the constant address space so the backend emits
@@ -81,7 +80,7 @@ PT_DEV pt_kargs cold_args(const PtKArgs &a) {
 // num_of_rays > 1 on a perspective camera: BOTH second-pass kernels are enqueued behind the first pass and this word of the
 // frame's queue block, written by pt_unit_scatter from F (the flagged pixels the first pass counted), says which of
 // them works -- 0: pt_path_tree_kernel (one pixel per wave: few flagged pixels, the frame waits for its deepest tree),
-// 1: pt_path_kernel<., true> (a lane per flagged pixel, refilled from one queue: frames full of flagged pixels are
+// 1: pt_path_flagged_kernel (a lane per flagged pixel, refilled from one queue: frames full of flagged pixels are
 // throughput-bound).  The other one returns at once -- unless the one-queue kernel hands pixels over (round 5): a lane per
 // pixel walks a pixel's rays one after the other, so a frame would wait for its heaviest pixels' chains (1 111 rays at the
 // CLI's N = 10, D = 3) while the lanes that have finished idle.  Such a lane writes its pixel's state into a record and

@@ -50,13 +50,6 @@ PT_DEV void hit_details(RP rec, AP ax, const Ray &r, double t, Hit &h, bool need
   h.n = normalize3(xf_normal(im, nn));
 }
 
-// Out-of-line entry for the path tracer: its kernel keeps ~40 VGPRs of path state alive; inlining the
-// HitRecord code (24 matrix doubles in flight) on top of that costs a wave of occupancy.
-PT_NOINLINE void hit_details_call(const PtShapeRec *rec, const PtShapeAux *ax, const Ray *r, double t, Hit *h,
-                                  bool need_uv) {
-  hit_details(rec, ax, *r, t, *h, need_uv);
-}
-
 // ---- pigments (materials.py:50-100) --------------------------------------------------------------------
 template <typename CP>
 PT_DEV V3 pigment_color(const PtKArgs &a, int kind, CP c1, CP c2, double steps, int tex, double u, double v) {

@@ -40,7 +40,7 @@ for step in "$@"; do
       tail -5 $OUT/prof.log ;;
     gloo2)
       log=$OUT/gloo2${arg:+_$(echo "$arg" | tr ' :' '__')}.log
-      PT_BENCH_FAIL="$arg" PT_BENCH_PHASE_S=${PT_BENCH_PHASE_S:-90} PT_DIST_BACKEND=gloo timeout -k 10 900 python3 bench.py --gpus 2 --steps 4 --warmup 2 > $log 2>&1 || { echo "exit $?"; tail -5 $log | cut -c1-600; exit 1; }
+      PT_BENCH_FAIL="$arg" PT_BENCH_PHASE_S=${PT_BENCH_PHASE_S:-90} PT_DIST_BACKEND=gloo timeout -k 10 900 python3 bench.py --gpus 2 --steps 4 --warmup 2 > $log 2>&1 || { echo "exit $?"; grep -v "^\[bench detail\]" $log | tail -8 | cut -c1-600; exit 1; }
       cp bench_detail.json ${log%.log}_detail.json; grep "^\[bench " $log | cut -c1-200; tail -1 $log | cut -c1-4200 ;;
     kbench)
       timeout -k 10 600 python3 tools/kbench.py $arg --rounds 4 > $OUT/kbench_$(echo "$arg" | tr ' :' '__').txt 2>&1; tail -12 $OUT/kbench_$(echo "$arg" | tr ' :' '__').txt ;;
