@@ -1167,6 +1167,41 @@ def test_frames_in_flight_are_the_frames_of_one_stream(dev):
         assert not np.array_equal(outs[0].cpu().numpy(), outs[5].cpu().numpy())
 
 
+def test_frames_in_flight_in_buffers_of_the_c_abi(dev):
+    """The same pipeline with the frames in `pytracer_amd.devmem.DeviceBuffer`s (pt_device_alloc, ABI 1.5) instead of torch
+    tensors: what a caller without a GPU framework uses.  Buffers download through pt_device_download, freeing twice is
+    harmless, a freed buffer refuses to hand out its pointer, and a zero-byte buffer is a null pointer."""
+    from pytracer_amd import flatten, hostmodel as hm, scenes
+    from pytracer_amd.devmem import DeviceBuffer, Stream
+    from pytracer_amd.pipeline import FramePipeline
+
+    W, H = 320, 176
+    flat = flatten.flatten_world(scenes.synthetic_world(32, with_plane=True))
+    cams = [flatten.flatten_camera(hm.PerspectiveCamera(1.0, W / H, hm.rotation_z(7.0 * k) * hm.translation(hm.Vec(-1.0, 0.0, 1.0))))
+            for k in range(5)]
+    par = abi.make_params(W, H, abi.RENDERER_FLAT, out_format=abi.OUT_F64)
+    outs = [DeviceBuffer((H, W, 3), np.float64) for _ in cams]
+    with FramePipeline(flat, n_in_flight=2) as pipe:
+        for cam, out in zip(cams, outs):
+            pipe.submit(cam, par, out)
+        pipe.wait()
+        with pytest.raises(ValueError, match="DeviceBuffer or a contiguous CUDA tensor"):
+            pipe.submit(cams[0], par, np.zeros((H, W, 3)))
+    with dev.DeviceScene(flat) as ds:
+        for k, cam in enumerate(cams):
+            assert util.bits_equal(outs[k].numpy(), ds.render(cam, par)), k
+    st = Stream()
+    assert util.bits_equal(outs[2].numpy(st), outs[2].numpy())  # (ordered behind a stream of the C-ABI as well)
+    st.close()
+    st.close()
+    outs[0].free()
+    outs[0].free()
+    with pytest.raises(RuntimeError, match="after free"):
+        outs[0].data_ptr()
+    empty = DeviceBuffer((0, W, 3), np.float32)
+    assert empty.data_ptr() == 0 and empty.numpy().shape == (0, W, 3)
+
+
 def test_cloned_handles_share_the_scene_and_outlive_the_first(dev):
     """pt_scene_clone: further handles on one uploaded scene (own per-camera constants and queues, shared tables) render
     the frames the first handle renders, for a world with a grid and cell lists as well, and keep working after the
