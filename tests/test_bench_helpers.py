@@ -180,3 +180,46 @@ def test_the_headline_gather_falls_back_on_the_whole_shards():
     assert est < 8 * 60 and 0 < oracle_s < b.ORACLE_LIMIT_S
     est16, oracle16 = b.estimate_wall_s(8, 16)
     assert est16 < 8 * 60  # (16 cores: ~95 s of oracle, inside the limit; beyond the limit the check is skipped and costs nothing)
+
+
+def test_a_phase_that_overruns_ends_the_job_with_the_line_measured_so_far(tmp_path, monkeypatch, capsys):
+    """bench.py --gpus N: the watchdog's way out (a deadline passed, or the ranks can no longer talk).  Rank 0 prints the stashed
+    whole-shard measurement marked with what happened and every rank leaves with status 0; with nothing stashed the line is an
+    `error` line and the status 1.  (os._exit is replaced: the test process must survive.)"""
+    b = _bench()
+    monkeypatch.setattr(b, "ROOT", str(tmp_path))
+    left = []
+
+    class Left(Exception):
+        pass
+
+    def fake_exit(code):
+        left.append(code)
+        raise Left()
+
+    monkeypatch.setattr(b.os, "_exit", fake_exit)
+    dog = b.Watchdog(0)
+    dog.error_stub.update(n_gpus=8, steps=20, warmup=3, backend="nccl")
+    import pytest
+
+    with pytest.raises(Left):  # nothing measured yet: an error line, status 1
+        dog.bail("phase 'warm-up C4 PT_PCG_SAMPLE whole gather' exceeded its deadline")
+    line = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    assert left == [1] and line["value"] is None and "exceeded its deadline" in line["error"] and line["n_gpus"] == 8
+    dog2 = b.Watchdog(0)
+    full = _canned_multi()
+    full["gather"] = {"used": "whole", "probe_ms_per_frame": {"whole": 0.9}, "gather_bytes_per_frame": 87091200, "fallback_reason": "sparse not measured yet"}
+    dog2.fallback, dog2.have_fallback = (full, None), True
+    with pytest.raises(Left):
+        dog2.bail("phase 'timed loop C4 PT_PCG_SAMPLE sparse gather gather=True' exceeded its deadline")
+    line = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    assert left == [1, 0] and line["value"] == 30000.0 and line["gather"]["used"] == "whole"
+    assert "sparse gather gather=True' exceeded its deadline" in line["gather"]["fallback_reason"]
+    assert line["comparable_with_the_n1_line"] is False and line["parity_check"]["bit_identical"] is True
+    # a remote rank prints nothing and leaves with the same status (after a pause that lets rank 0 print first)
+    monkeypatch.setattr(b.time, "sleep", lambda s: None)
+    dog3 = b.Watchdog(3)
+    dog3.have_fallback = True
+    with pytest.raises(Left):
+        dog3.bail("phase 'x': the ranks' agreement failed")
+    assert left == [1, 0, 0] and capsys.readouterr().out == ""
