@@ -31,8 +31,13 @@ def _tuned(name):
 
 
 # (num_of_rays > 1: the tree kernel, unless a switch forces the one-queue alternative on every frame or takes the tree kernel away)
-TREE_KERNEL = (abi.KERNEL_PATH_REGIONS if _tuned("tree") == 0 else (abi.KERNEL_PATH if _tuned("qchoice") == 2 else abi.KERNEL_PATH_TREE))
-TILE4_KERNEL = abi.KERNEL_TILE4 if _tuned("tile4") != 0 else abi.KERNEL_TILE
+# (PTRACE_CULL=0: every frame on the one-lane-per-pixel kernels, the brute-force device path the culled kernels are checked against)
+NO_CULL = _tuned("cull") == 0
+TREE_KERNEL = abi.KERNEL_PATH if NO_CULL else (
+    abi.KERNEL_PATH_REGIONS if _tuned("tree") == 0 else (abi.KERNEL_PATH if _tuned("qchoice") == 2 else abi.KERNEL_PATH_TREE))
+REGIONS_KERNEL = abi.KERNEL_PATH if NO_CULL else abi.KERNEL_PATH_REGIONS
+TILE4_KERNEL = abi.KERNEL_SIMPLE if NO_CULL else (abi.KERNEL_TILE4 if _tuned("tile4") != 0 else abi.KERNEL_TILE)
+TILE_KERNELS = (abi.KERNEL_SIMPLE,) if NO_CULL else (abi.KERNEL_TILE, abi.KERNEL_TILE4)
 
 
 @pytest.fixture(scope="module")
@@ -367,7 +372,7 @@ def test_tile_culling_is_invisible(dev, oracle, n, spread, rotated, W, H, S, ren
     oracle.set_sqr_mode(oracle.SQR_POW)
     with dev.DeviceScene(scene) as ds:
         out = ds.render(cam, par)
-        assert ds.stats().kernel in (abi.KERNEL_TILE, abi.KERNEL_TILE4), "expected a tile kernel"
+        assert ds.stats().kernel in TILE_KERNELS, "expected a tile kernel"
         assert util.bits_equal(out, ora), f"max rel {util.rel_err(out, ora).max()}"
         assert ds.stats().n_rays == n_rays
         # and under an awkward row partition (blocks of 7 rows over 3 ranks), the usual one, and 16- / 32-row blocks
@@ -378,7 +383,7 @@ def test_tile_culling_is_invisible(dev, oracle, n, spread, rotated, W, H, S, ren
                 p = abi.copy_params(par, n_ranks=3, rank=rank, row_block=rb)
                 got[abi.rows_for_rank(H, rb, 3, rank)] = ds.render(cam, p)
                 if S == 0 and n <= 254 and renderer in (abi.RENDERER_FLAT, abi.RENDERER_ONOFF):
-                    assert ds.stats().kernel == (TILE4_KERNEL if rb % 16 == 0 else abi.KERNEL_TILE), (rb, ds.stats().kernel)
+                    assert ds.stats().kernel == (TILE4_KERNEL if rb % 16 == 0 or NO_CULL else abi.KERNEL_TILE), (rb, ds.stats().kernel)
             assert util.bits_equal(got, ora), rb
 
 
@@ -404,7 +409,7 @@ def test_orthogonal_camera_beam_culling_is_invisible(dev, oracle, n, renderer, S
     oracle.set_sqr_mode(oracle.SQR_POW)
     with dev.DeviceScene(scene) as ds:
         out = ds.render(cam, par)
-        assert ds.stats().kernel in (abi.KERNEL_TILE, abi.KERNEL_TILE4), "expected a tile kernel"
+        assert ds.stats().kernel in TILE_KERNELS, "expected a tile kernel"
         assert util.bits_equal(out, ora), f"max rel {util.rel_err(out, ora).max()}"
         assert ds.stats().n_rays == n_rays
         got = np.zeros_like(out)
@@ -508,7 +513,7 @@ def test_dome_shortcut_and_plane_culling_are_invisible(dev, oracle, case):
             for c in (cam, cam_o):  # (the orthogonal view: the dome test looks at the four corner origins)
                 ora, n_rays = oracle.render(scene, c, par, sqr_mode=oracle.SQR_MUL)
                 out = ds.render(c, par)
-                assert ds.stats().kernel in (abi.KERNEL_TILE, abi.KERNEL_TILE4), "expected a tile kernel"
+                assert ds.stats().kernel in TILE_KERNELS, "expected a tile kernel"
                 assert util.bits_equal(out, ora), f"{case} renderer {renderer} S={S}: max rel {util.rel_err(out, ora).max()}"
                 assert ds.stats().n_rays == n_rays
         if case != "checkered":  # (sin/cos/atan2 of the device differ from libm in the last bit: not bit-exact)
@@ -536,7 +541,7 @@ def test_c3_pathtracer_vs_oracle(dev, oracle, n_rays, depth, S, mode):
     with dev.DeviceScene(scene) as ds:
         out = ds.render(cam, par)
         st = ds.stats()
-    assert st.kernel == (TREE_KERNEL if n_rays > 1 else abi.KERNEL_PATH_REGIONS)
+    assert st.kernel == (TREE_KERNEL if n_rays > 1 else REGIONS_KERNEL)
     ora, n = oracle.render(scene, cam, par, sqr_mode=oracle.SQR_MUL)
     oracle.set_sqr_mode(oracle.SQR_POW)
     err = util.rel_err(out, ora)
