@@ -339,3 +339,41 @@ def test_one_queue_second_pass_under_an_orthogonal_camera_with_textures_and_mirr
         ora, n = _oracle(oracle, scene, cam, par)
         _path_check(f"one-queue second pass, {type(cam_obj).__name__}", out, ora, st.n_rays, n, 1, W * H)
         assert util.bits_equal(got, out)
+
+
+@pytest.mark.parametrize("name,n_spheres,plane,wide,W,H,kw", [
+    ("C2 flat", 32, True, False, 1280, 720, dict(renderer=abi.RENDERER_FLAT)),
+    ("C3 pixel", 32, False, False, 1280, 720, dict(renderer=abi.RENDERER_PATHTRACER, samples_per_side=4, num_of_rays=1, max_depth=3, rr_limit=3,
+                                                   path_state=45, path_seq=54, pcg_mode=abi.PCG_PIXEL)),
+    ("C3 sample", 32, False, False, 1280, 720, dict(renderer=abi.RENDERER_PATHTRACER, samples_per_side=4, num_of_rays=1, max_depth=3, rr_limit=3,
+                                                    path_state=45, path_seq=54, pcg_mode=abi.PCG_SAMPLE)),
+    ("C2 + plane N=10", 32, True, False, 1280, 720, dict(renderer=abi.RENDERER_PATHTRACER, samples_per_side=1, num_of_rays=10, max_depth=3, rr_limit=3,
+                                                         path_state=45, path_seq=54)),
+    ("C4 sample", 256, False, True, 3840, 2160, dict(renderer=abi.RENDERER_PATHTRACER, samples_per_side=8, num_of_rays=1, max_depth=5, rr_limit=3,
+                                                     path_state=45, path_seq=54, pcg_mode=abi.PCG_SAMPLE)),
+    ("C5 flat", 10000, False, True, 1280, 720, dict(renderer=abi.RENDERER_FLAT)),
+    ("C2 point lights", 32, True, False, 1280, 720, dict(renderer=abi.RENDERER_POINTLIGHT, _lights=2))])
+def test_full_size_frames_are_linear_in_the_emitted_radiance(dev, name, n_spheres, plane, wide, W, H, kw):
+    """A size-independent property at BASELINE's full sizes (tests/test_properties.py has the argument and the oracle's side):
+    the scene with every emitted radiance, light colour, the background and the ambient term doubled renders EXACTLY twice
+    the frame, bit for bit, with the same rays traced -- on every kernel family (tile4, cells + tiles, regions in both
+    alignments, the one-queue kernel with its hand-over to the tree kernel, point lights)."""
+    from pytracer_amd import flatten, hostmodel as hm, scenes
+    from tests.test_properties import doubled
+
+    kw = dict(kw)
+    world = scenes.synthetic_world(n_spheres, with_plane=plane, wide=wide)
+    for l in range(kw.pop("_lights", 0)):
+        world.add_light(hm.PointLight(hm.Vec(-3.0 + 4.0 * l, 6.0 - 9.0 * l, 8.0), hm.Color(1.0, 0.9, 0.8), 0.0))
+    flat = flatten.flatten_world(world)
+    cam = flatten.flatten_camera(scenes.synthetic_camera(W, H))
+    bg, amb = (0.125, 0.25, 0.0625), (0.0625, 0.03125, 0.125)
+    frames, rays = [], []
+    for k, scene in ((1.0, flat), (2.0, doubled(flat, pigments_too=kw["renderer"] == abi.RENDERER_FLAT))):
+        par = abi.make_params(W, H, background=tuple(k * c for c in bg), ambient=tuple(k * c for c in amb), **kw)
+        with dev.DeviceScene(scene) as ds:
+            frames.append(ds.render(cam, par))
+            rays.append(int(ds.stats().n_rays))
+    assert rays[0] == rays[1], f"{name}: {rays}"
+    assert np.isfinite(frames[0]).all() and (frames[0] > 0).any()
+    assert (2.0 * frames[0]).tobytes() == frames[1].tobytes(), f"{name}: doubling every source does not double the frame bit for bit"
