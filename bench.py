@@ -401,6 +401,7 @@ def boundary_rows(flat, device: int, rays_per_frame: int):
     upload_ms = (time.perf_counter() - t0) * 1e3
     rows = {"scene_upload_ms": upload_ms}
     ds.set_count_rays(False)  # (the frame's rays are known: the headline counted them)
+    ds.set_dome_shortcut(False)  # (the headline's frame: every primary ray traced)
     for fmt, tag, nbytes in ((abi.OUT_F32, "f32", 4), (abi.OUT_F64, "f64", 8)):
         par = abi.make_params(W, H, abi.RENDERER_FLAT, out_format=fmt)
         for pinned in (True, False):
